@@ -1,0 +1,180 @@
+/*
+ * include/swt.h -- C ABI of libswt_hip.so: the MI355X (gfx950) subword-tokenizer hot path.
+ *
+ * The reference (phtryll/subword-tokenizers) is pure Python and has NO FFI/plugin boundary of its own; the
+ * drop-in boundary is its Python class surface.  This header is the C ABI a
+ * maintainer binds underneath those classes (ctypes stub in INTEGRATION.md).  Each entry point names
+ * the reference lines whose inner loop it replaces; citations are relative to /root/reference.
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = SWT_OK, negative = error (swt_last_error() has text);
+ *     nothing throws, aborts or falls back to a CPU path: if the HIP runtime or the device is missing
+ *     the call fails with SWT_ERR_NO_DEVICE.
+ *   - handles are opaque; buffers are caller-owned; sizes are in elements of the pointed-to type.
+ *   - text is UTF-8 of the ALREADY LOWERCASED string (Python str.lower() stays with the caller:
+ *     source/utils.py:27, source/wordpiece.py:248), sentences concatenated, with n_sent+1 byte offsets.
+ *     Lone surrogates encoded "surrogatepass"-style are accepted and decoded as their code point.
+ *   - `_dev` entry points take DEVICE pointers (e.g. torch tensors' data_ptr()) and a hipStream_t passed
+ *     as void* (NULL = default stream); they enqueue work and return without synchronising.
+ *   - a handle may be used by one host thread at a time.
+ *
+ * Token ids
+ *   BPE:  symbol id = the code point for a one-code-point symbol, else 0x110000 + k, where k is the
+ *         caller's interning index of the merged string (symbols are identified by their STRING,
+ *         source/bpe.py:41,103,227-228).  Token id = symbol id | SWT_BPE_CONT for every token after the
+ *         first of its word (the '##' prefix of source/bpe.py:240-241).
+ *   WP:   index into the vocabulary list given to swt_wp_trie_create; n_vocab = "['UNK']"
+ *         (source/wordpiece.py:257); n_vocab+1 = "[UNK]" (source/wordpiece.py:149); n_vocab+2 =
+ *         SWT_WP corner marker, emitted when NaiveWP.encode_word("##") (source/wordpiece.py:260-261)
+ *         yields more than one token -- the caller substitutes the list it got from swt_wp_trie_corner.
+ */
+#ifndef SWT_H
+#define SWT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWT_OK 0
+#define SWT_ERR_NO_DEVICE (-1)    /* no HIP device / runtime */
+#define SWT_ERR_INVALID (-2)      /* bad argument */
+#define SWT_ERR_CAPACITY (-3)     /* caller buffer too small; the needed size is reported */
+#define SWT_ERR_HIP (-4)          /* a HIP call failed */
+#define SWT_ERR_UNSUPPORTED (-5)
+#define SWT_ERR_STATE (-6)        /* call out of order */
+
+#define SWT_SYM_BASE 0x110000u
+#define SWT_BPE_CONT 0x80000000u
+
+/* per-sentence status of the WordPiece encoder */
+#define SWT_WP_OK 0
+#define SWT_WP_NONTERMINATING 1   /* the reference loops forever on this input */
+#define SWT_WP_INDEXERROR 2       /* the reference raises IndexError (source/wordpiece.py:285, i == len) */
+
+const char *swt_last_error(void);
+int swt_version(void);
+/* Selects the HIP device for this process (one process per GPU).  Fails loudly without a GPU. */
+int swt_init(int device_ordinal);
+int swt_device_count(void);
+/* multiprocessor count / name of the selected device (for launch sizing and reports) */
+int swt_device_info(int *n_cu, char *name, size_t name_cap);
+
+/* Code-point classes compiled into the library (fixture data probed from the wheel/interpreter the
+ * reference runs on; tools/gen_unicode_tables.py).  bit0 pre-tokenizer whitespace, bit1 pre-tokenizer
+ * punctuation (source/utils.py:27), bit2 str.isspace, bit3 str.isalnum (source/wordpiece.py:285-288). */
+#define SWT_CLS_BERT_WS 1u
+#define SWT_CLS_BERT_PUNCT 2u
+#define SWT_CLS_PY_SPACE 4u
+#define SWT_CLS_PY_ALNUM 8u
+unsigned swt_class_of(uint32_t code_point);
+
+/* ------------------------------------------------------------------------------------------------
+ * FastBPE encode: replaces FastBPE.load_resources' rank dict (source/bpe.py:251-257, :200) and the
+ * per-sentence loop FastBPE.tokenize -> encode_word (source/bpe.py:245-249, 205-243) including the
+ * pre-tokenizer split of SubwordTokenizer.preprocessing (source/utils.py:26-29).
+ */
+typedef struct swt_bpe_table swt_bpe_table;
+
+/* merges in list order as symbol-id triples; a later duplicate (left,right) overrides an earlier one
+ * (dict semantics of source/bpe.py:257). */
+int swt_bpe_table_create(const uint32_t *left, const uint32_t *right, const uint32_t *merged,
+                         uint32_t n_merges, swt_bpe_table **out);
+void swt_bpe_table_destroy(swt_bpe_table *t);
+
+/* Host-buffer form: copies in, encodes on the device, copies out.
+ *   text[n_bytes], sent_off[n_sent+1] -> out_ids[<= out_cap], out_off[n_sent+1], *n_tokens
+ * out_cap >= n_bytes is always sufficient (every token covers at least one byte). */
+int swt_bpe_encode(swt_bpe_table *t, const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent,
+                   uint32_t *out_ids, uint64_t out_cap, uint64_t *out_off, uint64_t *n_tokens);
+
+/* Device-buffer form.  d_out_ids needs room for n_bytes ids (worst case); d_out_off[n_sent+1].
+ * d_n_tokens (device, 1 element) receives the total. */
+int swt_bpe_encode_dev(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off,
+                       uint64_t n_sent, uint32_t *d_out_ids, uint64_t *d_out_off, uint64_t *d_n_tokens,
+                       void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * FastWP encode: replaces WPTrie_E2E (source/utils.py:66-139: insert + precompute, built on the host
+ * and flattened into device arrays) and FastWP.tokenize/matchloop/iswdbndry/ispunc
+ * (source/wordpiece.py:233-316).
+ */
+typedef struct swt_wp_trie swt_wp_trie;
+
+/* vocabulary as UTF-32 code points + n_vocab+1 offsets; token id = index (first wins on duplicates) */
+int swt_wp_trie_create(const uint32_t *vocab_cps, const uint64_t *vocab_off, uint32_t n_vocab, swt_wp_trie **out);
+void swt_wp_trie_destroy(swt_wp_trie *t);
+int swt_wp_trie_stats(const swt_wp_trie *t, uint32_t *n_nodes, uint32_t *n_edges, uint32_t *n_pops);
+/* NaiveWP.encode_word("##") evaluated once at build: returns its length in ids (copied to out up to
+ * cap), or -1 when the reference never returns from it. */
+int64_t swt_wp_trie_corner(const swt_wp_trie *t, uint32_t *out, uint64_t cap);
+/* Debug/parity view of one node of the flattened trie, addressed by its path string (with the '##'
+ * prefix where the token has one): failure link as a node id, pops copied out.  Node ids: 0 root,
+ * 1 root_p, 2.. in creation order.  Returns SWT_ERR_INVALID when the path does not exist. */
+int swt_wp_trie_node(const swt_wp_trie *t, const uint32_t *path, uint64_t path_len, uint32_t *node_id,
+                     int32_t *link, uint8_t *is_end, uint32_t *pops, uint32_t pops_cap, uint32_t *n_pops);
+int swt_wp_trie_node_path(const swt_wp_trie *t, uint32_t node_id, uint32_t *out, uint64_t cap, uint64_t *len);
+
+int swt_wp_encode(swt_wp_trie *t, const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent,
+                  uint32_t *out_ids, uint64_t out_cap, uint64_t *out_off, uint8_t *status, uint64_t *n_tokens);
+int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off,
+                      uint64_t n_sent, uint32_t *d_out_ids, uint64_t *d_out_off, uint8_t *d_status,
+                      uint64_t *d_n_tokens, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BPE training: replaces the merge loop of NaiveBPE.train (source/bpe.py:88-111; FastBPE.train
+ * inherits it, source/bpe.py:198-200) and its word dedup (source/bpe.py:73-81).
+ *
+ * The caller keeps the string set and the stop test (`len(vocab) < max_vocab`, source/bpe.py:88,103):
+ *   swt_bpe_train_create*  ->  loop { swt_bpe_train_best; intern(left+right); swt_bpe_train_apply }.
+ * Device state: the unique-word symbol stream (uint32), word offsets/lengths/frequencies, and the pair
+ * histogram (hash table of 64-bit pair keys with 64-bit counts) which is built once and then updated
+ * incrementally by every merge -- the same counts the reference recomputes from scratch each round.
+ */
+typedef struct swt_bpe_trainer swt_bpe_trainer;
+
+/* From lowercased UTF-8 text: pre-tokenize, dedup words in first-occurrence order, symbolise
+ * (source/bpe.py:70-81).  n_base_symbols = number of distinct code points (the initial len(vocab)). */
+int swt_bpe_train_create_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent,
+                              swt_bpe_trainer **out);
+/* From an already deduplicated word list (symbol ids, CSR offsets, frequencies). */
+int swt_bpe_train_create_words(const uint32_t *syms, const uint64_t *word_off, const uint32_t *freq,
+                               uint64_t n_words, swt_bpe_trainer **out);
+void swt_bpe_train_destroy(swt_bpe_trainer *t);
+/* Rank-sharded training: pos_base orders this shard's words after those of lower ranks in the
+ * first-occurrence tie-break (source/bpe.py:102).  Default 0. */
+int swt_bpe_train_set_pos_base(swt_bpe_trainer *t, uint64_t pos_base);
+int swt_bpe_train_info(const swt_bpe_trainer *t, uint64_t *n_words, uint64_t *n_symbols, uint32_t *n_base_symbols,
+                       uint64_t *n_pairs);
+/* distinct code points of the corpus, ascending (the initial vocab, source/bpe.py:75) */
+int swt_bpe_train_base_symbols(const swt_bpe_trainer *t, uint32_t *out, uint32_t cap);
+/* Most frequent pair, ties broken by earliest (word, position) (source/bpe.py:90-102).
+ * *count == 0 means no pair is left (source/bpe.py:98-99). *first_pos is the tie-break key. */
+int swt_bpe_train_best(swt_bpe_trainer *t, uint32_t *left, uint32_t *right, uint64_t *count, uint64_t *first_pos);
+/* Replace every L->R non-overlapping occurrence of (left,right) by merged (source/bpe.py:25-48,
+ * 108-111) and update the histogram. */
+int swt_bpe_train_apply(swt_bpe_trainer *t, uint32_t left, uint32_t right, uint32_t merged);
+/* Copies the current stream back (parity checks): syms[n_symbols], word_off[n_words+1]. */
+int swt_bpe_train_export(swt_bpe_trainer *t, uint32_t *syms, uint64_t syms_cap, uint64_t *word_off);
+/* Copies the histogram back: up to cap (key = left<<32|right, count) entries with count > 0. */
+int swt_bpe_train_histogram(swt_bpe_trainer *t, uint64_t *keys, uint64_t *counts, uint64_t cap, uint64_t *n);
+
+/* -- sharded training (one process per GPU; the caller moves the buffers with RCCL) --
+ * Every rank keeps the histogram of the WHOLE corpus: after create, ranks exchange their local
+ * histograms once (export_local / add_remote); after every apply they exchange the delta lists the
+ * merge produced (take_deltas on each rank, all-gather, add_remote of the other ranks' lists).
+ * Ties are resolved with swt_bpe_train_tied / first_pos all-reduced with MIN by the caller. */
+int swt_bpe_train_take_deltas(swt_bpe_trainer *t, uint64_t *d_keys, int64_t *d_vals, uint64_t cap, uint64_t *n,
+                              void *stream);
+int swt_bpe_train_add_remote(swt_bpe_trainer *t, const uint64_t *d_keys, const int64_t *d_vals, uint64_t n,
+                             void *stream);
+/* Candidates tied at the maximum count: up to cap keys (ascending); then their local first positions. */
+int swt_bpe_train_tied(swt_bpe_trainer *t, uint64_t *keys, uint32_t cap, uint32_t *n, uint64_t *count);
+int swt_bpe_train_first_pos(swt_bpe_trainer *t, const uint64_t *keys, uint32_t n, uint64_t *first_pos);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWT_H */

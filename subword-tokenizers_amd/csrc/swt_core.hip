@@ -1,0 +1,145 @@
+// swt_core.hip -- process-level state of libswt_hip.so: error text, device selection, class tables.
+#include <mutex>
+
+#include "swt_common.h"
+#include "unicode_classes.inc"
+
+namespace swt {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+int fail(int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+static int g_device = -1;
+static int g_cus = 0;
+static std::mutex g_mu;
+
+static int select_device(int ordinal) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(SWT_ERR_NO_DEVICE, "no HIP device available (%s); libswt_hip has no CPU path",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (ordinal < 0 || ordinal >= n) return fail(SWT_ERR_INVALID, "device ordinal %d out of range [0,%d)", ordinal, n);
+  SWT_HIP(hipSetDevice(ordinal));
+  hipDeviceProp_t prop;
+  SWT_HIP(hipGetDeviceProperties(&prop, ordinal));
+  g_device = ordinal;
+  g_cus = prop.multiProcessorCount;
+  return SWT_OK;
+}
+
+int ensure_device() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_device >= 0) {
+    // keep the calling thread on the selected device
+    hipError_t e = hipSetDevice(g_device);
+    if (e != hipSuccess) return fail(SWT_ERR_HIP, "hipSetDevice(%d): %s", g_device, hipGetErrorString(e));
+    return SWT_OK;
+  }
+  return select_device(0);
+}
+
+int device_cus() { return g_cus > 0 ? g_cus : 256; }
+
+int DevBuf::reserve(size_t bytes) {
+  if (bytes <= cap) return SWT_OK;
+  size_t want = bytes + bytes / 4 + 256;
+  void *np = nullptr;
+  SWT_HIP(hipMalloc(&np, want));
+  if (p) (void)hipFree(p);
+  p = np;
+  cap = want;
+  return SWT_OK;
+}
+
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+}
+
+static std::vector<uint8_t> g_cls;
+static std::once_flag g_cls_once;
+static uint8_t *g_cls_dev = nullptr;
+
+static void fill(const unsigned int (*r)[2], unsigned int n, uint8_t bit) {
+  for (unsigned int i = 0; i < n; i++)
+    for (unsigned int c = r[i][0]; c <= r[i][1]; c++) g_cls[c] |= bit;
+}
+
+const uint8_t *host_class_table() {
+  std::call_once(g_cls_once, [] {
+    g_cls.assign(kNumCodePoints, 0);
+    fill(SWT_BERT_WS_RANGES, SWT_BERT_WS_NRANGES, SWT_CLS_BERT_WS);
+    fill(SWT_BERT_PUNCT_RANGES, SWT_BERT_PUNCT_NRANGES, SWT_CLS_BERT_PUNCT);
+    fill(SWT_PY_SPACE_RANGES, SWT_PY_SPACE_NRANGES, SWT_CLS_PY_SPACE);
+    fill(SWT_PY_ALNUM_RANGES, SWT_PY_ALNUM_NRANGES, SWT_CLS_PY_ALNUM);
+  });
+  return g_cls.data();
+}
+
+int device_class_table(const uint8_t **d) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_cls_dev) {
+    const uint8_t *h = host_class_table();
+    SWT_HIP(hipMalloc((void **)&g_cls_dev, kNumCodePoints));
+    SWT_HIP(hipMemcpy(g_cls_dev, h, kNumCodePoints, hipMemcpyHostToDevice));
+  }
+  *d = g_cls_dev;
+  return SWT_OK;
+}
+
+}  // namespace swt
+
+extern "C" {
+
+const char *swt_last_error(void) { return swt::g_err.c_str(); }
+
+int swt_version(void) { return 1; }
+
+int swt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int swt_init(int device_ordinal) {
+  std::lock_guard<std::mutex> lk(swt::g_mu);
+  if (swt::g_device >= 0 && swt::g_device != device_ordinal && swt::g_cls_dev)
+    return swt::fail(SWT_ERR_STATE, "device %d already selected for this process", swt::g_device);
+  return swt::select_device(device_ordinal);
+}
+
+int swt_device_info(int *n_cu, char *name, size_t name_cap) {
+  int rc = swt::ensure_device();
+  if (rc) return rc;
+  hipDeviceProp_t prop;
+  SWT_HIP(hipGetDeviceProperties(&prop, swt::g_device));
+  if (n_cu) *n_cu = prop.multiProcessorCount;
+  if (name && name_cap) {
+    snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  return SWT_OK;
+}
+
+unsigned swt_class_of(uint32_t cp) { return cp < swt::kNumCodePoints ? swt::host_class_table()[cp] : 0u; }
+
+}  // extern "C"
