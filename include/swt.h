@@ -87,14 +87,16 @@ void swt_bpe_table_destroy(swt_bpe_table *t);
 /* Host-buffer form: copies in, encodes on the device, copies out.
  *   text[n_bytes], sent_off[n_sent+1] -> out_ids[<= out_cap], out_off[n_sent+1], *n_tokens
  * out_cap >= n_bytes is always sufficient (every token covers at least one byte). */
+#define SWT_BPE_RAW_WORDS 1u   /* flags: every "sentence" is ONE word, no pre-tokenizer split -- this is
+                                  FastBPE.encode_word(word) (source/bpe.py:205), batched */
 int swt_bpe_encode(swt_bpe_table *t, const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent,
-                   uint32_t *out_ids, uint64_t out_cap, uint64_t *out_off, uint64_t *n_tokens);
+                   uint32_t *out_ids, uint64_t out_cap, uint64_t *out_off, uint64_t *n_tokens, uint32_t flags);
 
 /* Device-buffer form.  d_out_ids needs room for n_bytes ids (worst case); d_out_off[n_sent+1].
  * d_n_tokens (device, 1 element) receives the total. */
 int swt_bpe_encode_dev(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off,
                        uint64_t n_sent, uint32_t *d_out_ids, uint64_t *d_out_off, uint64_t *d_n_tokens,
-                       void *stream);
+                       uint32_t flags, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * FastWP encode: replaces WPTrie_E2E (source/utils.py:66-139: insert + precompute, built on the host
@@ -150,14 +152,20 @@ int swt_bpe_train_info(const swt_bpe_trainer *t, uint64_t *n_words, uint64_t *n_
                        uint64_t *n_pairs);
 /* distinct code points of the corpus, ascending (the initial vocab, source/bpe.py:75) */
 int swt_bpe_train_base_symbols(const swt_bpe_trainer *t, uint32_t *out, uint32_t cap);
-/* Most frequent pair, ties broken by earliest (word, position) (source/bpe.py:90-102).
- * *count == 0 means no pair is left (source/bpe.py:98-99). *first_pos is the tie-break key. */
-int swt_bpe_train_best(swt_bpe_trainer *t, uint32_t *left, uint32_t *right, uint64_t *count, uint64_t *first_pos);
+/* Most frequent pair (source/bpe.py:90-102).  *count == 0 means no pair is left (source/bpe.py:98-99).
+ * *n_tied = number of pairs holding the maximum.  When it is 1, (left,right) is that pair and *first_pos is
+ * ~0.  When it is > 1 the tie is broken by the earliest (word, position) in THIS handle's stream:
+ * (left,right) is the pair found there and *first_pos = pos_base + its stream position; if none of the tied
+ * pairs occurs in this shard, *first_pos = ~0 and left = right = 0xFFFFFFFF.  Sharded callers keep the
+ * (first_pos, left, right) of the rank with the smallest first_pos. */
+int swt_bpe_train_best(swt_bpe_trainer *t, uint32_t *left, uint32_t *right, uint64_t *count, uint64_t *n_tied,
+                       uint64_t *first_pos);
 /* Replace every L->R non-overlapping occurrence of (left,right) by merged (source/bpe.py:25-48,
  * 108-111) and update the histogram. */
 int swt_bpe_train_apply(swt_bpe_trainer *t, uint32_t left, uint32_t right, uint32_t merged);
-/* Copies the current stream back (parity checks): syms[n_symbols], word_off[n_words+1]. */
-int swt_bpe_train_export(swt_bpe_trainer *t, uint32_t *syms, uint64_t syms_cap, uint64_t *word_off);
+/* Copies the current stream back (parity checks, corpus_as_symbols): syms[n_symbols], word_off[n_words+1],
+ * freq[n_words] (freq may be NULL). */
+int swt_bpe_train_export(swt_bpe_trainer *t, uint32_t *syms, uint64_t syms_cap, uint64_t *word_off, uint32_t *freq);
 /* Copies the histogram back: up to cap (key = left<<32|right, count) entries with count > 0. */
 int swt_bpe_train_histogram(swt_bpe_trainer *t, uint64_t *keys, uint64_t *counts, uint64_t cap, uint64_t *n);
 
@@ -165,15 +173,11 @@ int swt_bpe_train_histogram(swt_bpe_trainer *t, uint64_t *keys, uint64_t *counts
  * Every rank keeps the histogram of the WHOLE corpus: after create, ranks exchange their local
  * histograms once (export_local / add_remote); after every apply they exchange the delta lists the
  * merge produced (take_deltas on each rank, all-gather, add_remote of the other ranks' lists).
- * Ties are resolved with swt_bpe_train_tied / first_pos all-reduced with MIN by the caller. */
+ * The first take_deltas call switches the delta log on and returns the whole local histogram. */
 int swt_bpe_train_take_deltas(swt_bpe_trainer *t, uint64_t *d_keys, int64_t *d_vals, uint64_t cap, uint64_t *n,
                               void *stream);
 int swt_bpe_train_add_remote(swt_bpe_trainer *t, const uint64_t *d_keys, const int64_t *d_vals, uint64_t n,
                              void *stream);
-/* Candidates tied at the maximum count: up to cap keys (ascending); then their local first positions. */
-int swt_bpe_train_tied(swt_bpe_trainer *t, uint64_t *keys, uint32_t cap, uint32_t *n, uint64_t *count);
-int swt_bpe_train_first_pos(swt_bpe_trainer *t, const uint64_t *keys, uint32_t n, uint64_t *first_pos);
-
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,328 @@
+"""ctypes binding of libswt_hip.so (include/swt.h).
+
+The library is the product: there is no Python or CPU implementation of the hot path behind it.  If the
+shared object has not been built, or a call needs a GPU that is not there, this module raises -- loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+SYM_BASE = 0x110000
+BPE_CONT = 0x80000000
+BPE_RAW_WORDS = 1
+WP_OK, WP_NONTERMINATING, WP_INDEXERROR = 0, 1, 2
+ERR_NO_DEVICE, ERR_INVALID, ERR_CAPACITY, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = -1, -2, -3, -4, -5, -6
+CLS_BERT_WS, CLS_BERT_PUNCT, CLS_PY_SPACE, CLS_PY_ALNUM = 1, 2, 4, 8
+NO_POS = 0xFFFFFFFFFFFFFFFF
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
+u64p = C.POINTER(C.c_uint64)
+i64p = C.POINTER(C.c_int64)
+vpp = C.POINTER(C.c_void_p)
+
+# every symbol include/swt.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "swt_last_error": (C.c_char_p, []),
+    "swt_version": (C.c_int, []),
+    "swt_init": (C.c_int, [C.c_int]),
+    "swt_device_count": (C.c_int, []),
+    "swt_device_info": (C.c_int, [C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    "swt_class_of": (C.c_uint, [C.c_uint32]),
+    "swt_bpe_table_create": (C.c_int, [u32p, u32p, u32p, C.c_uint32, vpp]),
+    "swt_bpe_table_destroy": (None, [C.c_void_p]),
+    "swt_bpe_encode": (C.c_int, [C.c_void_p, u8p, u64p, C.c_uint64, u32p, C.c_uint64, u64p, u64p, C.c_uint32]),
+    "swt_bpe_encode_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_uint32, C.c_void_p]),
+    "swt_wp_trie_create": (C.c_int, [u32p, u64p, C.c_uint32, vpp]),
+    "swt_wp_trie_destroy": (None, [C.c_void_p]),
+    "swt_wp_trie_stats": (C.c_int, [C.c_void_p, u32p, u32p, u32p]),
+    "swt_wp_trie_corner": (C.c_int64, [C.c_void_p, u32p, C.c_uint64]),
+    "swt_wp_trie_node": (C.c_int, [C.c_void_p, u32p, C.c_uint64, u32p, i32p, u8p, u32p, C.c_uint32, u32p]),
+    "swt_wp_trie_node_path": (C.c_int, [C.c_void_p, C.c_uint32, u32p, C.c_uint64, u64p]),
+    "swt_wp_encode": (C.c_int, [C.c_void_p, u8p, u64p, C.c_uint64, u32p, C.c_uint64, u64p, u8p, u64p]),
+    "swt_wp_encode_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "swt_bpe_train_create_text": (C.c_int, [u8p, u64p, C.c_uint64, vpp]),
+    "swt_bpe_train_create_words": (C.c_int, [u32p, u64p, u32p, C.c_uint64, vpp]),
+    "swt_bpe_train_destroy": (None, [C.c_void_p]),
+    "swt_bpe_train_set_pos_base": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "swt_bpe_train_info": (C.c_int, [C.c_void_p, u64p, u64p, u32p, u64p]),
+    "swt_bpe_train_base_symbols": (C.c_int, [C.c_void_p, u32p, C.c_uint32]),
+    "swt_bpe_train_best": (C.c_int, [C.c_void_p, u32p, u32p, u64p, u64p, u64p]),
+    "swt_bpe_train_apply": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "swt_bpe_train_export": (C.c_int, [C.c_void_p, u32p, C.c_uint64, u64p, u32p]),
+    "swt_bpe_train_histogram": (C.c_int, [C.c_void_p, u64p, u64p, C.c_uint64, u64p]),
+    "swt_bpe_train_take_deltas": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, u64p, C.c_void_p]),
+    "swt_bpe_train_add_remote": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+}
+
+
+class SwtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libswt_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+class NoDeviceError(SwtError):
+    """Raised when a compute call is made without a HIP device: there is no CPU path."""
+
+
+_lib = None
+
+
+def lib():
+    """Load libswt_hip.so (built by `_build.build()`); never falls back to anything else."""
+    global _lib
+    if _lib is None:
+        path = _build.LIB_PATH
+        if not os.path.exists(path):
+            raise ImportError(
+                "libswt_hip.so is not built (%s). Run `python -c \"import __graft_entry__ as g; g.build()\"` "
+                "or `python subword-tokenizers_amd/_build.py`; there is no Python/CPU fallback." % path)
+        L = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = the .so is stale against include/swt.h
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = lib().swt_last_error().decode("utf-8", "replace")
+    if rc == ERR_NO_DEVICE:
+        raise NoDeviceError(rc, msg)
+    raise SwtError(rc, msg)
+
+
+def ptr(a, typ):
+    return a.ctypes.data_as(typ)
+
+
+def class_of(cp):
+    return lib().swt_class_of(cp)
+
+
+def device_count():
+    return lib().swt_device_count()
+
+
+def init(device=0):
+    check(lib().swt_init(device))
+
+
+def device_info():
+    n = C.c_int()
+    name = C.create_string_buffer(256)
+    check(lib().swt_device_info(C.byref(n), name, 256))
+    return n.value, name.value.decode()
+
+
+# --------------------------------------------------------------------------------------------------
+# packing: what the reference does per sentence in Python (str.lower(), utils.py:27 / wordpiece.py:248)
+# stays in Python; the device consumes the lowercased UTF-8 bytes of the whole batch.
+
+def pack_utf8(lowered):
+    """list[str] (already lowercased) -> (uint8 bytes, uint64 offsets[n+1])."""
+    enc = [s.encode("utf-8", "surrogatepass") for s in lowered]
+    off = np.zeros(len(enc) + 1, dtype=np.uint64)
+    if enc:
+        np.cumsum(np.fromiter(map(len, enc), dtype=np.uint64, count=len(enc)), out=off[1:])
+    buf = np.frombuffer(b"".join(enc), dtype=np.uint8)
+    if buf.size == 0:
+        buf = np.zeros(1, dtype=np.uint8)[:0]
+    return buf, off
+
+
+def pack_utf32(strings):
+    """list[str] -> (uint32 code points, uint64 offsets[n+1])."""
+    off = np.zeros(len(strings) + 1, dtype=np.uint64)
+    if strings:
+        np.cumsum(np.fromiter(map(len, strings), dtype=np.uint64, count=len(strings)), out=off[1:])
+    blob = np.frombuffer("".join(strings).encode("utf-32-le", "surrogatepass"), dtype=np.uint32)
+    return blob, off
+
+
+class BpeTable:
+    """Device merge-rank table (swt_bpe_table)."""
+
+    def __init__(self, left, right, merged):
+        left = np.ascontiguousarray(left, dtype=np.uint32)
+        right = np.ascontiguousarray(right, dtype=np.uint32)
+        merged = np.ascontiguousarray(merged, dtype=np.uint32)
+        self.n_merges = int(left.size)
+        h = C.c_void_p()
+        check(lib().swt_bpe_table_create(ptr(left, u32p), ptr(right, u32p), ptr(merged, u32p), self.n_merges, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().swt_bpe_table_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def encode(self, text_u8, sent_off, flags=0):
+        """host buffers in -> (ids uint32, offsets uint64[n+1])"""
+        n_sent = int(sent_off.size - 1)
+        n_bytes = int(sent_off[-1])
+        out = np.empty(max(n_bytes, 1), dtype=np.uint32)
+        out_off = np.zeros(n_sent + 1, dtype=np.uint64)
+        nt = C.c_uint64()
+        check(lib().swt_bpe_encode(self._h, ptr(text_u8, u8p), ptr(sent_off, u64p), n_sent, ptr(out, u32p), out.size,
+                                   ptr(out_off, u64p), C.byref(nt), flags))
+        return out[:nt.value], out_off
+
+    def encode_dev(self, d_text, n_bytes, d_off, n_sent, d_out, d_out_off, d_ntok, flags=0, stream=0):
+        """device pointers (ints) in; enqueues on `stream` and returns"""
+        check(lib().swt_bpe_encode_dev(self._h, d_text, n_bytes, d_off, n_sent, d_out, d_out_off, d_ntok, flags, stream))
+
+
+class WpTrie:
+    """Flattened failure-link trie (swt_wp_trie)."""
+
+    def __init__(self, vocab_list):
+        self.n_vocab = len(vocab_list)
+        blob, off = pack_utf32(list(vocab_list))
+        h = C.c_void_p()
+        check(lib().swt_wp_trie_create(ptr(blob, u32p) if blob.size else None, ptr(off, u64p), self.n_vocab, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().swt_wp_trie_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def stats(self):
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib().swt_wp_trie_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"nodes": a.value, "edges": b.value, "pops": c.value}
+
+    def corner(self):
+        """ids of NaiveWP.encode_word("##"), or None when the reference never returns from it"""
+        buf = np.zeros(64, dtype=np.uint32)
+        n = lib().swt_wp_trie_corner(self._h, ptr(buf, u32p), buf.size)
+        if n > buf.size:
+            buf = np.zeros(n, dtype=np.uint32)
+            n = lib().swt_wp_trie_corner(self._h, ptr(buf, u32p), buf.size)
+        return None if n < 0 else buf[:n].copy()
+
+    def node(self, path):
+        """(node_id, link, is_end, pops) of the node spelled by `path`, or None"""
+        a, _ = pack_utf32([path])
+        nid, link, end, npops = C.c_uint32(), C.c_int32(), C.c_uint8(), C.c_uint32()
+        pops = np.zeros(256, dtype=np.uint32)
+        rc = lib().swt_wp_trie_node(self._h, ptr(a, u32p) if a.size else None, a.size, C.byref(nid), C.byref(link),
+                                    C.byref(end), ptr(pops, u32p), pops.size, C.byref(npops))
+        if rc == ERR_INVALID:
+            return None
+        check(rc)
+        return nid.value, link.value, bool(end.value), pops[:npops.value].copy()
+
+    def node_path(self, node_id):
+        buf = np.zeros(512, dtype=np.uint32)
+        n = C.c_uint64()
+        check(lib().swt_wp_trie_node_path(self._h, node_id, ptr(buf, u32p), buf.size, C.byref(n)))
+        return bytes(buf[:n.value]).decode("utf-32-le", "surrogatepass")
+
+    def encode(self, text_u8, sent_off):
+        n_sent = int(sent_off.size - 1)
+        n_bytes = int(sent_off[-1])
+        out = np.empty(max(n_bytes, 1), dtype=np.uint32)
+        out_off = np.zeros(n_sent + 1, dtype=np.uint64)
+        status = np.zeros(max(n_sent, 1), dtype=np.uint8)
+        nt = C.c_uint64()
+        check(lib().swt_wp_encode(self._h, ptr(text_u8, u8p), ptr(sent_off, u64p), n_sent, ptr(out, u32p), out.size,
+                                  ptr(out_off, u64p), ptr(status, u8p), C.byref(nt)))
+        return out[:nt.value], out_off, status[:n_sent]
+
+    def encode_dev(self, d_text, n_bytes, d_off, n_sent, d_out, d_out_off, d_status, d_ntok, stream=0):
+        check(lib().swt_wp_encode_dev(self._h, d_text, n_bytes, d_off, n_sent, d_out, d_out_off, d_status, d_ntok, stream))
+
+
+class BpeTrainer:
+    """Device BPE trainer (swt_bpe_trainer): histogram + argmax + merge-apply."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def from_text(cls, text_u8, sent_off):
+        h = C.c_void_p()
+        n_sent = int(sent_off.size - 1)
+        check(lib().swt_bpe_train_create_text(ptr(text_u8, u8p), ptr(sent_off, u64p), n_sent, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_words(cls, syms, word_off, freq):
+        syms = np.ascontiguousarray(syms, dtype=np.uint32)
+        word_off = np.ascontiguousarray(word_off, dtype=np.uint64)
+        freq = np.ascontiguousarray(freq, dtype=np.uint32)
+        h = C.c_void_p()
+        check(lib().swt_bpe_train_create_words(ptr(syms, u32p), ptr(word_off, u64p), ptr(freq, u32p), int(word_off.size - 1),
+                                               C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().swt_bpe_train_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_pos_base(self, base):
+        check(lib().swt_bpe_train_set_pos_base(self._h, base))
+
+    def info(self):
+        a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint64()
+        check(lib().swt_bpe_train_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return {"n_words": a.value, "n_symbols": b.value, "n_base_symbols": c.value, "n_pairs": d.value}
+
+    def base_symbols(self):
+        n = self.info()["n_base_symbols"]
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        check(lib().swt_bpe_train_base_symbols(self._h, ptr(out, u32p), out.size))
+        return out[:n]
+
+    def best(self):
+        """-> (left, right, count, n_tied, first_pos)"""
+        l, r = C.c_uint32(), C.c_uint32()
+        cnt, tied, pos = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(lib().swt_bpe_train_best(self._h, C.byref(l), C.byref(r), C.byref(cnt), C.byref(tied), C.byref(pos)))
+        return l.value, r.value, cnt.value, tied.value, pos.value
+
+    def apply(self, left, right, merged):
+        check(lib().swt_bpe_train_apply(self._h, left, right, merged))
+
+    def export(self):
+        inf = self.info()
+        syms = np.zeros(max(inf["n_symbols"], 1), dtype=np.uint32)
+        woff = np.zeros(inf["n_words"] + 1, dtype=np.uint64)
+        freq = np.zeros(max(inf["n_words"], 1), dtype=np.uint32)
+        check(lib().swt_bpe_train_export(self._h, ptr(syms, u32p), syms.size, ptr(woff, u64p), ptr(freq, u32p)))
+        return syms[:int(woff[-1])], woff, freq[:inf["n_words"]]
+
+    def histogram(self):
+        cap = max(self.info()["n_pairs"], 1) + 16
+        keys = np.zeros(cap, dtype=np.uint64)
+        cnts = np.zeros(cap, dtype=np.uint64)
+        n = C.c_uint64()
+        check(lib().swt_bpe_train_histogram(self._h, ptr(keys, u64p), ptr(cnts, u64p), cap, C.byref(n)))
+        return keys[:n.value], cnts[:n.value]
+
+    def take_deltas(self, d_keys, d_vals, cap, stream=0):
+        n = C.c_uint64()
+        check(lib().swt_bpe_train_take_deltas(self._h, d_keys, d_vals, cap, C.byref(n), stream))
+        return n.value
+
+    def add_remote(self, d_keys, d_vals, n, stream=0):
+        check(lib().swt_bpe_train_add_remote(self._h, d_keys, d_vals, n, stream))

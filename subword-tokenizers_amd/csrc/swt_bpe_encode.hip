@@ -6,16 +6,14 @@
 //   FastBPE.encode_word / _pairs     /root/reference/source/bpe.py:202-243
 //   the rank dict                    /root/reference/source/bpe.py:200,257
 //
-// Work decomposition (DESIGN.md "BPE encode"):
-//   tile   = the sentences whose first byte lies in one kTile-byte window of the text; a tile owns whole
-//            sentences, so no sentence is ever seen by two workgroups and no data-path atomics exist.
-//   chunk  = up to kCap bytes of a tile's span staged in LDS; a span longer than kCap is walked in several
-//            chunks cut at word boundaries (long sentences), a single word longer than kCap falls to a
-//            one-lane global-memory path (correct, slow, pathological inputs only).
-//   lane   = one pre-tokenized word during the merge loop; one byte position everywhere else.
-// Kernels: plan (tile -> first sentence), encode (tokens compact per tile + per-sentence local
-// offsets), scan (tile totals), gather (final CSR).
-#include "swt_common.h"
+// Runs on the tile/chunk skeleton of swt_tile.h.  Encoder-specific phases:
+//   B  per byte: decode the code point at every UTF-8 lead byte, look its pre-tokenizer class up
+//   C  per byte: word starts (whitespace removed, every punctuation code point its own word) -> per-wave lists
+//   D  one lane per word: gather the word's code points, run the lowest-rank merge loop against the
+//      device rank table (open-addressing hash, one 16-byte slot per probe), set the '##' flag
+// A span longer than kCap is cut at word boundaries; a single word longer than kCap falls to a one-lane
+// global-memory path (correct, slow, pathological inputs only).
+#include "swt_tile.h"
 
 namespace swt {
 
@@ -24,13 +22,6 @@ struct alignas(16) BpeSlot {
   uint32_t rank;    // index in merges_list (last duplicate wins)
   uint32_t merged;  // symbol id of left+right
 };
-
-constexpr int kTile = 2048;
-constexpr int kCap = 4096;
-constexpr int kThreads = 256;
-constexpr int kWaves = kThreads / 64;
-constexpr int kQuarter = kCap / kWaves;  // positions per wave
-constexpr int kBlocks64 = kCap / 64;
 
 constexpr uint8_t kClsWs = 1, kClsPunct = 2, kClsCont = 0x80;
 
@@ -73,20 +64,6 @@ __device__ __forceinline__ uint32_t merge_word(Ptr s, uint32_t n, const BpeSlot 
   return n;
 }
 
-__global__ void plan_kernel(const uint64_t *__restrict__ sent_off, uint64_t n_sent, uint64_t n_tiles, uint32_t tile,
-                            uint64_t *__restrict__ plan) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t > n_tiles) return;
-  if (t == n_tiles) { plan[t] = n_sent; return; }
-  const uint64_t target = t * tile;
-  uint64_t lo = 0, hi = n_sent;
-  while (lo < hi) {
-    const uint64_t mid = (lo + hi) >> 1;
-    if (sent_off[mid] < target) lo = mid + 1; else hi = mid;
-  }
-  plan[t] = lo;
-}
-
 struct GiantResult { uint64_t end; uint32_t ntok; };
 
 // One lane, global memory only: the word (or single separator) starting at byte `pos`, bounded by
@@ -106,7 +83,7 @@ __device__ GiantResult giant_word(const uint8_t *__restrict__ text, uint64_t pos
       cp = b & (0xFF >> (len + 1));
       for (int i = 1; i < len; i++) cp = (cp << 6) | (text[r.end + i] & 0x3F);
     }
-    const uint8_t c = utf8_is_cont(b) ? kClsWs : (cp < kNumCodePoints ? cls_tab[cp] : 0);
+    const uint8_t c = utf8_is_cont(b) ? kClsWs : ((cls_tab && cp < kNumCodePoints) ? cls_tab[cp] : (uint8_t)0);
     if (c & kClsWs) { if (first) r.end += len; break; }
     if (c & kClsPunct) { if (first) { out[n++] = cp; r.end += len; } break; }
     out[n++] = cp;
@@ -123,16 +100,8 @@ __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
     const uint8_t *__restrict__ text, uint64_t n_bytes, const uint64_t *__restrict__ sent_off,
     const uint64_t *__restrict__ plan, const uint8_t *__restrict__ cls_tab, const BpeSlot *__restrict__ slots,
     uint32_t bits, uint32_t *__restrict__ scratch, uint32_t *__restrict__ sent_local, uint32_t *__restrict__ tile_tok) {
-  __shared__ __attribute__((aligned(16))) uint8_t txt[kCap + 16];
-  __shared__ uint8_t cls[kCap + 16];
-  __shared__ uint32_t sym[kCap];
-  __shared__ uint16_t wl[kCap];
-  __shared__ unsigned long long sbits[kBlocks64 + 1];
-  __shared__ unsigned long long vmask[kBlocks64 + 1];
-  __shared__ uint32_t blkpre[kBlocks64 + 1];
-  __shared__ uint32_t wtot[kWaves];
-  __shared__ int s_cut;
-  __shared__ uint32_t s_cnt;
+  __shared__ TileLds L;
+  __shared__ uint16_t wl[kCap];  // word starts, one list per wave (its quarter of the chunk)
   __shared__ GiantResult s_giant;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -156,22 +125,11 @@ __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
     const bool last = avail <= (uint64_t)kCap;
     const uint32_t staged = last ? (uint32_t)avail : (uint32_t)kCap;
 
-    // ---- A. stage text [abase, abase+staged) into LDS, 16 B per lane where the chunk is inside the buffer
-    for (uint32_t c = tid * 16; c < staged; c += kThreads * 16) {
-      const uint64_t g = abase + c;
-      if (g + 16 <= n_bytes && ((reinterpret_cast<uintptr_t>(text + g) & 15) == 0)) {
-        *reinterpret_cast<uint4 *>(&txt[c]) = *reinterpret_cast<const uint4 *>(text + g);
-      } else {
-        for (int i = 0; i < 16; i++) txt[c + i] = (g + i < n_bytes) ? text[g + i] : (uint8_t)' ';
-      }
-    }
-    for (int i = tid; i <= kBlocks64; i += kThreads) sbits[i] = 0ull;
-    if (tid == 0) { s_cut = -1; s_cnt = 0; }
-    __syncthreads();
+    tile_stage(L, text, n_bytes, abase, staged);
 
-    // ---- B. per byte: decode the code point at every lead byte, class lookup; mark sentence starts
+    // ---- B. per byte: code point + pre-tokenizer class at every lead byte; sentence-start bits
     for (uint32_t p = tid; p < staged; p += kThreads) {
-      const uint8_t b = txt[p];
+      const uint8_t b = L.txt[p];
       uint32_t sv = kInvalidTok;
       uint8_t cv = kClsCont;
       if (!utf8_is_cont(b) && p >= off0) {
@@ -180,20 +138,16 @@ __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
         uint32_t cp = b;
         if (b >= 0x80 && len > 1) {
           cp = b & (0xFF >> (len + 1));
-          for (int i = 1; i < len; i++) cp = (cp << 6) | (txt[p + i] & 0x3F);
+          for (int i = 1; i < len; i++) cp = (cp << 6) | (L.txt[p + i] & 0x3F);
         }
-        const uint8_t c = cp < kNumCodePoints ? cls_tab[cp] : (uint8_t)0;
+        const uint8_t c = (cls_tab && cp < kNumCodePoints) ? cls_tab[cp] : (uint8_t)0;
         cv = c & (kClsWs | kClsPunct);
         if (!(c & kClsWs)) sv = cp;
       }
-      sym[p] = sv;
-      cls[p] = cv;
+      L.sym[p] = sv;
+      L.cls[p] = cv;
     }
-    for (uint64_t s = s_next + tid; s < s_hi; s += kThreads) {
-      const uint64_t o = sent_off[s];
-      if (o >= abase + staged) break;
-      if (o >= cb) atomicOr(&sbits[(o - abase) >> 6], 1ull << ((o - abase) & 63));
-    }
+    tile_mark_sentences(L, sent_off, s_next, s_hi, cb, abase, staged);
     __syncthreads();
 
     // ---- chunk end: the whole rest of the span, or the last word boundary that fits
@@ -202,36 +156,35 @@ __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
       int best = -1;
       for (uint32_t p = tid; p + 4 <= staged; p += kThreads) {
         if (p <= off0) continue;
-        const uint8_t c = cls[p];
+        const uint8_t c = L.cls[p];
         if (c & kClsCont) continue;
-        if ((c & (kClsWs | kClsPunct)) || ((sbits[p >> 6] >> (p & 63)) & 1ull)) best = (int)p;
+        if ((c & (kClsWs | kClsPunct)) || tile_sbit(L, p)) best = (int)p;
       }
-      if (best >= 0) atomicMax(&s_cut, best);
+      if (best >= 0) atomicMax(&L.cut, best);
       __syncthreads();
-      if (s_cut < 0) {
+      if (L.cut < 0) {
         // a single word longer than the LDS chunk: one lane, global memory
         if (tid == 0) {
           uint64_t s = s_next;
           while (s < s_hi && sent_off[s] <= cb) s++;
-          const uint64_t send = sent_off[s];  // s <= s_hi, sent_off[s_hi] = span_end > cb
+          const uint64_t send = sent_off[s];  // s <= s_hi and sent_off[s_hi] = span_end > cb
           s_giant = giant_word(text, cb, send, cls_tab, slots, bits, tile_out + run);
         }
         __syncthreads();
         const GiantResult g = s_giant;
         for (uint64_t s = s_next + tid; s < s_hi; s += kThreads) {
-          const uint64_t o = sent_off[s];
-          if (o >= g.end) break;
+          if (sent_off[s] >= g.end) break;
           sent_local[s] = run;
-          atomicAdd(&s_cnt, 1u);
+          atomicAdd(&L.cnt, 1u);
         }
         __syncthreads();
-        s_next += s_cnt;
+        s_next += L.cnt;
         run += g.ntok;
         cb = g.end;
         __syncthreads();
         continue;
       }
-      ce = (uint32_t)s_cut;
+      ce = (uint32_t)L.cut;
     }
 
     // ---- C. word starts (utils.py:27 split): each wave lists the words that begin in its quarter
@@ -241,14 +194,14 @@ __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
       const uint32_t p = wave * kQuarter + r * 64 + lane;
       bool is = false;
       if (p >= off0 && p < ce) {
-        const uint8_t c = cls[p];
+        const uint8_t c = L.cls[p];
         if (!(c & (kClsCont | kClsWs))) {
           if (c & kClsPunct) is = true;
-          else if (p == off0 || ((sbits[p >> 6] >> (p & 63)) & 1ull)) is = true;
+          else if (p == off0 || tile_sbit(L, p)) is = true;
           else {
             uint32_t q = p - 1;
-            while (q > off0 && (cls[q] & kClsCont)) q--;
-            is = (cls[q] & (kClsWs | kClsPunct | kClsCont)) != 0;
+            while (q > off0 && (L.cls[q] & kClsCont)) q--;
+            is = (L.cls[q] & (kClsWs | kClsPunct | kClsCont)) != 0;
           }
         }
       }
@@ -261,121 +214,36 @@ __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
     for (uint32_t k = lane; k < nwords; k += 64) {
       const uint32_t ws = mywl[k];
       uint32_t n = 0, p = ws;
-      if (cls[ws] & kClsPunct) {
+      if (L.cls[ws] & kClsPunct) {
         n = 1;
-        p = ws + utf8_len(txt[ws]);
+        p = ws + utf8_len(L.txt[ws]);
       } else {
         for (;;) {
-          const uint32_t cp = sym[p];
-          sym[ws + n] = cp;
+          const uint32_t cp = L.sym[p];
+          L.sym[ws + n] = cp;
           n++;
-          p += utf8_len(txt[p]);
-          while (p < ce && (cls[p] & kClsCont)) p++;
+          p += utf8_len(L.txt[p]);
+          while (p < ce && (L.cls[p] & kClsCont)) p++;
           if (p >= ce) break;
-          if ((sbits[p >> 6] >> (p & 63)) & 1ull) break;
-          if (cls[p] & (kClsWs | kClsPunct)) break;
+          if (tile_sbit(L, p)) break;
+          if (L.cls[p] & (kClsWs | kClsPunct)) break;
         }
       }
       if (p > ce) p = ce;
-      n = merge_word(&sym[ws], n, slots, bits);
-      for (uint32_t i = 1; i < n; i++) sym[ws + i] |= SWT_BPE_CONT;
-      for (uint32_t q = ws + n; q < p; q++) sym[q] = kInvalidTok;
+      n = merge_word(&L.sym[ws], n, slots, bits);
+      for (uint32_t i = 1; i < n; i++) L.sym[ws + i] |= SWT_BPE_CONT;
+      for (uint32_t q = ws + n; q < p; q++) L.sym[q] = kInvalidTok;
     }
     __syncthreads();
 
-    // ---- E. order-preserving compaction of the valid positions into the tile's output run
-    uint32_t mytot = 0;
-    for (int r = 0; r < kQuarter / 64; r++) {
-      const uint32_t p = wave * kQuarter + r * 64 + lane;
-      const bool v = p >= off0 && p < ce && sym[p] != kInvalidTok;
-      const unsigned long long m = __ballot(v);
-      if (lane == 0) vmask[wave * (kQuarter / 64) + r] = m;
-      mytot += __popcll(m);
-    }
-    if (lane == 0) wtot[wave] = mytot;
-    __syncthreads();
-    uint32_t wbase = 0, total = 0;
-    for (int w = 0; w < kWaves; w++) {
-      if (w < wave) wbase += wtot[w];
-      total += wtot[w];
-    }
-    uint32_t pre = wbase;
-    for (int r = 0; r < kQuarter / 64; r++) {
-      const int blk = wave * (kQuarter / 64) + r;
-      const uint32_t p = blk * 64 + lane;
-      const unsigned long long m = vmask[blk];
-      if (lane == 0) blkpre[blk] = pre;
-      if ((m >> lane) & 1ull) tile_out[run + pre + __popcll(m & lt)] = sym[p];
-      pre += __popcll(m);
-    }
-    __syncthreads();
-
-    // ---- F. local token offset of every sentence that starts in this chunk
-    for (uint64_t s = s_next + tid; s < s_hi; s += kThreads) {
-      const uint64_t o = sent_off[s];
-      const uint64_t rel = o - abase;
-      if (rel > ce || (rel == ce && !last)) break;
-      uint32_t e = total;
-      if (rel < ce) e = blkpre[rel >> 6] + __popcll(vmask[rel >> 6] & ((1ull << (rel & 63)) - 1ull));
-      sent_local[s] = run + e;
-      atomicAdd(&s_cnt, 1u);
-    }
-    __syncthreads();
-    s_next += s_cnt;
+    // ---- E, F
+    const uint32_t total = tile_compact(L, off0, ce, tile_out + run);
+    s_next += tile_record(L, sent_off, sent_local, s_next, s_hi, abase, ce, last, run, total);
     run += total;
     if (last) break;
     cb = abase + ce;
-    __syncthreads();
   }
   if (tid == 0) tile_tok[t] = run;
-}
-
-// Exclusive scan of the tile totals (one workgroup; n_tiles is small next to the text).
-__global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t *__restrict__ tile_tok, uint64_t n_tiles,
-                                                         uint64_t *__restrict__ tile_base, uint64_t *__restrict__ n_tokens) {
-  __shared__ uint64_t wsum[16];
-  __shared__ uint64_t carry_s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (uint64_t base = 0; base < n_tiles; base += 1024) {
-    const uint64_t i = base + tid;
-    const uint64_t v = i < n_tiles ? tile_tok[i] : 0;
-    uint64_t x = v;
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint64_t y = __shfl_up(x, d);
-      if (lane >= d) x += y;
-    }
-    if (lane == 63) wsum[wave] = x;
-    __syncthreads();
-    uint64_t wb = 0;
-    for (int w = 0; w < wave; w++) wb += wsum[w];
-    const uint64_t carry = carry_s;
-    if (i < n_tiles) tile_base[i] = carry + wb + x - v;
-    __syncthreads();
-    if (tid == 1023) carry_s = carry + wb + x;
-    __syncthreads();
-  }
-  if (tid == 0) {
-    tile_base[n_tiles] = carry_s;
-    *n_tokens = carry_s;
-  }
-}
-
-__global__ __launch_bounds__(kThreads) void gather_kernel(const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
-                                                          uint64_t n_tiles, uint64_t n_sent, const uint32_t *__restrict__ scratch,
-                                                          const uint32_t *__restrict__ sent_local, const uint32_t *__restrict__ tile_tok,
-                                                          const uint64_t *__restrict__ tile_base, uint32_t *__restrict__ out_ids,
-                                                          uint64_t *__restrict__ out_off) {
-  const uint64_t t = blockIdx.x;
-  const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
-  if (t == n_tiles - 1 && threadIdx.x == 0) out_off[n_sent] = tile_base[n_tiles];
-  if (s_lo == s_hi) return;
-  const uint64_t base = tile_base[t];
-  const uint32_t n = tile_tok[t];
-  const uint32_t *src = scratch + sent_off[s_lo];
-  for (uint32_t i = threadIdx.x; i < n; i += kThreads) out_ids[base + i] = src[i];
-  for (uint64_t s = s_lo + threadIdx.x; s < s_hi; s += kThreads) out_off[s] = base + sent_local[s];
 }
 
 }  // namespace swt
@@ -383,43 +251,49 @@ __global__ __launch_bounds__(kThreads) void gather_kernel(const uint64_t *__rest
 using namespace swt;
 
 struct swt_bpe_table {
+  std::vector<BpeSlot> h_slots;  // built on the host at create; uploaded on first encode
   BpeSlot *d_slots = nullptr;
   uint32_t bits = 0;
   uint32_t n_merges = 0;
-  DevBuf plan, scratch, sent_local, tile_tok, tile_base;  // per-call workspaces (grow-only)
-  DevBuf in_text, in_off, out_ids, out_off, n_tok;       // staging for the host-buffer entry point
+  TileWorkspace ws;
+  DevBuf in_text, in_off, out_ids, out_off, n_tok;  // staging for the host-buffer entry point
 };
+
+static int bpe_upload(swt_bpe_table *t) {
+  if (t->d_slots) return SWT_OK;
+  int rc = ensure_device();
+  if (rc) return rc;
+  SWT_HIP(hipMalloc((void **)&t->d_slots, t->h_slots.size() * sizeof(BpeSlot)));
+  SWT_HIP(hipMemcpy(t->d_slots, t->h_slots.data(), t->h_slots.size() * sizeof(BpeSlot), hipMemcpyHostToDevice));
+  return SWT_OK;
+}
 
 extern "C" {
 
 int swt_bpe_table_create(const uint32_t *left, const uint32_t *right, const uint32_t *merged, uint32_t n_merges,
                          swt_bpe_table **out) {
   if (!out || (n_merges && (!left || !right || !merged))) return fail(SWT_ERR_INVALID, "null argument");
-  int rc = ensure_device();
-  if (rc) return rc;
   uint32_t bits = 4;
   while ((1ull << bits) < 2ull * n_merges + 2) bits++;
   const size_t cap = (size_t)1 << bits;
-  std::vector<BpeSlot> slots(cap);
+  auto *t = new swt_bpe_table();
+  t->bits = bits;
+  t->n_merges = n_merges;
+  std::vector<BpeSlot> &slots = t->h_slots;
+  slots.resize(cap);
   for (auto &s : slots) { s.key = kEmptyKey; s.rank = 0; s.merged = 0; }
   const uint32_t mask = (uint32_t)cap - 1;
   for (uint32_t i = 0; i < n_merges; i++) {
-    if ((left[i] | right[i] | merged[i]) & SWT_BPE_CONT) return fail(SWT_ERR_INVALID, "symbol id %u out of range at merge %u", left[i], i);
+    if ((left[i] | right[i] | merged[i]) & SWT_BPE_CONT) {
+      delete t;
+      return fail(SWT_ERR_INVALID, "symbol id out of range at merge %u", i);
+    }
     const uint64_t key = pair_key(left[i], right[i]);
     uint32_t h = hash_slot(key, bits);
     while (slots[h].key != kEmptyKey && slots[h].key != key) h = (h + 1) & mask;
     slots[h].key = key;  // {pair: i}: a later duplicate overwrites (bpe.py:257)
     slots[h].rank = i;
     slots[h].merged = merged[i];
-  }
-  auto *t = new swt_bpe_table();
-  t->bits = bits;
-  t->n_merges = n_merges;
-  hipError_t e = hipMalloc((void **)&t->d_slots, cap * sizeof(BpeSlot));
-  if (e == hipSuccess) e = hipMemcpy(t->d_slots, slots.data(), cap * sizeof(BpeSlot), hipMemcpyHostToDevice);
-  if (e != hipSuccess) {
-    swt_bpe_table_destroy(t);
-    return fail(SWT_ERR_HIP, "table upload failed: %s", hipGetErrorString(e));
   }
   *out = t;
   return SWT_OK;
@@ -428,56 +302,50 @@ int swt_bpe_table_create(const uint32_t *left, const uint32_t *right, const uint
 void swt_bpe_table_destroy(swt_bpe_table *t) {
   if (!t) return;
   if (t->d_slots) (void)hipFree(t->d_slots);
-  for (DevBuf *b : {&t->plan, &t->scratch, &t->sent_local, &t->tile_tok, &t->tile_base, &t->in_text, &t->in_off,
-                    &t->out_ids, &t->out_off, &t->n_tok})
-    b->release();
+  t->ws.release();
+  for (DevBuf *b : {&t->in_text, &t->in_off, &t->out_ids, &t->out_off, &t->n_tok}) b->release();
   delete t;
 }
 
 int swt_bpe_encode_dev(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off,
-                       uint64_t n_sent, uint32_t *d_out_ids, uint64_t *d_out_off, uint64_t *d_n_tokens, void *stream) {
+                       uint64_t n_sent, uint32_t *d_out_ids, uint64_t *d_out_off, uint64_t *d_n_tokens, uint32_t flags,
+                       void *stream) {
   if (!t || !d_sent_off || !d_out_off || !d_n_tokens || (n_bytes && (!d_text || !d_out_ids)))
     return fail(SWT_ERR_INVALID, "null argument");
-  int rc = ensure_device();
+  int rc = bpe_upload(t);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   const uint8_t *d_cls = nullptr;
   if ((rc = device_class_table(&d_cls))) return rc;
-  const uint64_t n_tiles = n_bytes ? (n_bytes + kTile - 1) / kTile : 1;
-  if (n_tiles > 0x7FFFFFFFull) return fail(SWT_ERR_UNSUPPORTED, "text too large for one call (%llu bytes)", (unsigned long long)n_bytes);
-  if ((rc = t->plan.reserve((n_tiles + 1) * 8))) return rc;
-  if ((rc = t->scratch.reserve((n_bytes + 64) * 4))) return rc;
-  if ((rc = t->sent_local.reserve((n_sent + 1) * 4))) return rc;
-  if ((rc = t->tile_tok.reserve((n_tiles + 1) * 4))) return rc;
-  if ((rc = t->tile_base.reserve((n_tiles + 2) * 8))) return rc;
+  if (flags & SWT_BPE_RAW_WORDS) d_cls = nullptr;  // no classes: nothing splits, nothing is dropped
+  const uint64_t n_tiles = tile_count(n_bytes);
+  if (n_tiles > 0x7FFFFFFFull)
+    return fail(SWT_ERR_UNSUPPORTED, "text too large for one call (%llu bytes)", (unsigned long long)n_bytes);
+  if ((rc = t->ws.reserve(n_bytes, n_sent, n_tiles))) return rc;
   if (n_sent == 0) {
     SWT_HIP(hipMemsetAsync(d_out_off, 0, 8, st));
     SWT_HIP(hipMemsetAsync(d_n_tokens, 0, 8, st));
     return SWT_OK;
   }
-  hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n_tiles + 1 + 255) / 256)), dim3(256), 0, st, d_sent_off, n_sent, n_tiles,
-                     (uint32_t)kTile, t->plan.as<uint64_t>());
+  launch_plan(d_sent_off, n_sent, n_tiles, t->ws.plan.as<uint64_t>(), st);
   hipLaunchKernelGGL(bpe_encode_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, st, d_text, n_bytes, d_sent_off,
-                     t->plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->scratch.as<uint32_t>(), t->sent_local.as<uint32_t>(),
-                     t->tile_tok.as<uint32_t>());
-  hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, t->tile_tok.as<uint32_t>(), n_tiles,
-                     t->tile_base.as<uint64_t>(), d_n_tokens);
-  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, st, d_sent_off, t->plan.as<uint64_t>(), n_tiles,
-                     n_sent, t->scratch.as<uint32_t>(), t->sent_local.as<uint32_t>(), t->tile_tok.as<uint32_t>(),
-                     t->tile_base.as<uint64_t>(), d_out_ids, d_out_off);
+                     t->ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->ws.scratch.as<uint32_t>(),
+                     t->ws.sent_local.as<uint32_t>(), t->ws.tile_tok.as<uint32_t>());
+  launch_scan_gather(d_sent_off, n_sent, n_tiles, t->ws, d_out_ids, d_out_off, d_n_tokens, st);
   SWT_HIP(hipGetLastError());
   return SWT_OK;
 }
 
 int swt_bpe_encode(swt_bpe_table *t, const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, uint32_t *out_ids,
-                   uint64_t out_cap, uint64_t *out_off, uint64_t *n_tokens) {
+                   uint64_t out_cap, uint64_t *out_off, uint64_t *n_tokens, uint32_t flags) {
   if (!t || !sent_off || !out_off || !n_tokens) return fail(SWT_ERR_INVALID, "null argument");
-  int rc = ensure_device();
+  int rc = bpe_upload(t);
   if (rc) return rc;
   const uint64_t n_bytes = sent_off[n_sent];
-  for (uint64_t s = 0; s < n_sent; s++)
-    if (sent_off[s] > sent_off[s + 1]) return fail(SWT_ERR_INVALID, "sentence offsets must be non-decreasing (at %llu)", (unsigned long long)s);
   if (sent_off[0] != 0) return fail(SWT_ERR_INVALID, "sent_off[0] must be 0");
+  for (uint64_t s = 0; s < n_sent; s++)
+    if (sent_off[s] > sent_off[s + 1])
+      return fail(SWT_ERR_INVALID, "sentence offsets must be non-decreasing (at %llu)", (unsigned long long)s);
   if (n_bytes && !text) return fail(SWT_ERR_INVALID, "null text");
   if ((rc = t->in_text.reserve(n_bytes + 64))) return rc;
   if ((rc = t->in_off.reserve((n_sent + 1) * 8))) return rc;
@@ -487,13 +355,14 @@ int swt_bpe_encode(swt_bpe_table *t, const uint8_t *text, const uint64_t *sent_o
   if (n_bytes) SWT_HIP(hipMemcpyAsync(t->in_text.p, text, n_bytes, hipMemcpyHostToDevice, 0));
   SWT_HIP(hipMemcpyAsync(t->in_off.p, sent_off, (n_sent + 1) * 8, hipMemcpyHostToDevice, 0));
   rc = swt_bpe_encode_dev(t, t->in_text.as<uint8_t>(), n_bytes, t->in_off.as<uint64_t>(), n_sent, t->out_ids.as<uint32_t>(),
-                          t->out_off.as<uint64_t>(), t->n_tok.as<uint64_t>(), nullptr);
+                          t->out_off.as<uint64_t>(), t->n_tok.as<uint64_t>(), flags, nullptr);
   if (rc) return rc;
   uint64_t nt = 0;
   SWT_HIP(hipMemcpy(&nt, t->n_tok.p, 8, hipMemcpyDeviceToHost));
   *n_tokens = nt;
   SWT_HIP(hipMemcpy(out_off, t->out_off.p, (n_sent + 1) * 8, hipMemcpyDeviceToHost));
-  if (nt > out_cap) return fail(SWT_ERR_CAPACITY, "out_ids too small: need %llu ids, have %llu", (unsigned long long)nt, (unsigned long long)out_cap);
+  if (nt > out_cap)
+    return fail(SWT_ERR_CAPACITY, "out_ids too small: need %llu ids, have %llu", (unsigned long long)nt, (unsigned long long)out_cap);
   if (nt) SWT_HIP(hipMemcpy(out_ids, t->out_ids.p, nt * 4, hipMemcpyDeviceToHost));
   return SWT_OK;
 }

@@ -1,0 +1,612 @@
+// swt_bpe_train.hip -- BPE training merge loop on gfx950.
+//
+// Replaces NaiveBPE.train's loop (FastBPE.train inherits it):
+//   word dedup + symbolisation   /root/reference/source/bpe.py:73-81   (host C++ here; device later)
+//   pair histogram               /root/reference/source/bpe.py:90-95
+//   argmax with first-seen tie   /root/reference/source/bpe.py:98-102
+//   merge-apply (_replace_pair)  /root/reference/source/bpe.py:25-48, 108-111
+//
+// Device state
+//   sym[]   packed uint32 symbol stream of the UNIQUE words, word w at [woff[w], woff[w]+wlen[w]); a merge
+//           rewrites the word in place (its slot keeps its offset, only wlen shrinks), so stream order = the
+//           reference's scan order and a position woff[w]+i is a valid first-occurrence key.
+//   pair histogram: open-addressing hash, keys[] (left<<32|right) + cnt[] (64-bit, weighted by word
+//           frequency).  Built once by a full scan, then kept exact incrementally: a merge only touches pairs
+//           adjacent to its occurrences, so each step subtracts the pairs it destroys and adds the pairs it
+//           creates (atomicAdd on the table) -- the same counts the reference recomputes from scratch.
+// Per merge: argmax over cnt[] (max via atomicMax, then tie census); only when the maximum is tied, one read-only
+// scan finds the earliest (word, position) among the tied pairs (bpe.py:102: Counter.most_common(1) returns
+// the first-inserted maximum).  One host round trip per merge: the caller owns the string set and the stop test.
+#include <algorithm>
+#include <unordered_map>
+
+#include "swt_common.h"
+
+namespace swt {
+
+constexpr int kTrainThreads = 256;
+
+struct TrainResult {
+  unsigned long long max_count;
+  unsigned long long n_tied;
+  unsigned long long best_pos;   // local stream position of the winner (kEmptyKey: none found locally)
+  unsigned long long best_key;   // a key with count == max (the winner when n_tied == 1)
+  unsigned long long n_used;     // distinct keys ever inserted in the table
+  unsigned long long n_log;      // delta-log entries of the last apply
+  unsigned long long n_syms;     // live symbols after the last apply
+  unsigned long long win_key;    // pair at best_pos (tie winner)
+};
+
+struct PairTable {
+  unsigned long long *keys;
+  long long *cnt;
+  uint32_t bits;
+};
+
+__device__ __forceinline__ void table_add(const PairTable &T, unsigned long long key, long long delta, TrainResult *res) {
+  const uint32_t mask = (1u << T.bits) - 1u;
+  uint32_t h = hash_slot(key, T.bits);
+  for (;;) {
+    unsigned long long k = __hip_atomic_load(&T.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == kEmptyKey) {
+      k = atomicCAS(&T.keys[h], kEmptyKey, key);
+      if (k == kEmptyKey) {
+        atomicAdd(&res->n_used, 1ull);
+        k = key;
+      }
+    }
+    if (k == key) {
+      atomicAdd(reinterpret_cast<unsigned long long *>(&T.cnt[h]), (unsigned long long)delta);
+      return;
+    }
+    h = (h + 1) & mask;
+  }
+}
+
+__device__ __forceinline__ long long table_get(const PairTable &T, unsigned long long key) {
+  const uint32_t mask = (1u << T.bits) - 1u;
+  uint32_t h = hash_slot(key, T.bits);
+  for (;;) {
+    const unsigned long long k = T.keys[h];
+    if (k == key) return T.cnt[h];
+    if (k == kEmptyKey) return 0;
+    h = (h + 1) & mask;
+  }
+}
+
+__global__ void table_clear_kernel(unsigned long long *keys, long long *cnt, uint64_t cap) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
+    keys[i] = kEmptyKey;
+    cnt[i] = 0;
+  }
+}
+
+// bpe.py:90-95 -- every adjacent pair of every unique word, weighted by the word's frequency
+__global__ __launch_bounds__(kTrainThreads) void hist_build_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
+                                                                   const uint32_t *__restrict__ wlen, const uint32_t *__restrict__ freq,
+                                                                   uint64_t n_words, PairTable T, TrainResult *res) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  const uint32_t n = wlen[w];
+  if (n < 2) return;
+  const uint32_t *s = sym + woff[w];
+  const long long f = freq[w];
+  uint32_t a = s[0];
+  for (uint32_t i = 1; i < n; i++) {
+    const uint32_t b = s[i];
+    table_add(T, pair_key(a, b), f, res);
+    a = b;
+  }
+}
+
+__global__ void result_reset_kernel(TrainResult *res) {
+  res->max_count = 0;
+  res->n_tied = 0;
+  res->best_pos = kEmptyKey;
+  res->best_key = kEmptyKey;
+  res->win_key = kEmptyKey;
+}
+
+__global__ __launch_bounds__(256) void argmax_max_kernel(const long long *__restrict__ cnt, uint64_t cap, TrainResult *res) {
+  long long m = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
+    const long long c = cnt[i];
+    m = c > m ? c : m;
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    const long long o = __shfl_xor(m, d);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&res->max_count, (unsigned long long)m);
+}
+
+// census of the slots that hold the maximum; best_key = the smallest such key (deterministic)
+__global__ __launch_bounds__(256) void argmax_tie_kernel(const unsigned long long *__restrict__ keys, const long long *__restrict__ cnt,
+                                                         uint64_t cap, TrainResult *res) {
+  const unsigned long long mx = res->max_count;
+  if (mx == 0) return;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
+    if ((unsigned long long)cnt[i] == mx && keys[i] != kEmptyKey) {
+      atomicAdd(&res->n_tied, 1ull);
+      atomicMin(&res->best_key, keys[i]);
+    }
+  }
+}
+
+// bpe.py:102 tie-break: the earliest (word, position) whose pair holds the maximum count
+__global__ __launch_bounds__(kTrainThreads) void first_pos_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
+                                                                  const uint32_t *__restrict__ wlen, uint64_t n_words, PairTable T,
+                                                                  TrainResult *res) {
+  if (res->n_tied < 2) return;
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  const uint32_t n = wlen[w];
+  if (n < 2) return;
+  const uint64_t base = woff[w];
+  if (base >= res->best_pos) return;  // an earlier word already holds a candidate
+  const long long mx = (long long)res->max_count;
+  const uint32_t *s = sym + base;
+  uint32_t a = s[0];
+  for (uint32_t i = 1; i < n; i++) {
+    const uint32_t b = s[i];
+    if (table_get(T, pair_key(a, b)) == mx) {
+      atomicMin(&res->best_pos, (unsigned long long)(base + i - 1));
+      return;
+    }
+    a = b;
+  }
+}
+
+__global__ void winner_kernel(const uint32_t *__restrict__ sym, TrainResult *res) {
+  if (res->n_tied < 2 || res->best_pos == kEmptyKey) return;
+  res->win_key = pair_key(sym[res->best_pos], sym[res->best_pos + 1]);
+}
+
+// bpe.py:108-111 + _replace_pair (bpe.py:25-48), with the histogram kept exact:
+//   an old pair (x[i],x[i+1]) disappears iff x[i] or x[i+1] is consumed by an occurrence;
+//   a new pair (y[j],y[j+1]) appears iff y[j] or y[j+1] is a freshly merged symbol.
+__global__ __launch_bounds__(kTrainThreads) void apply_kernel(uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
+                                                              uint32_t *__restrict__ wlen, const uint32_t *__restrict__ freq,
+                                                              uint64_t n_words, uint32_t l, uint32_t r, uint32_t m, PairTable T,
+                                                              TrainResult *res, unsigned long long *__restrict__ log_keys,
+                                                              long long *__restrict__ log_vals, uint64_t log_cap) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  const uint32_t n = wlen[w];
+  if (n < 2) return;
+  uint32_t *s = sym + woff[w];
+  // cheap reject: does the word hold an occurrence at all?
+  bool any = false;
+  {
+    uint32_t a = s[0];
+    for (uint32_t i = 1; i < n; i++) {
+      const uint32_t b = s[i];
+      any |= (a == l) & (b == r);
+      a = b;
+    }
+  }
+  if (!any) return;
+  const long long f = freq[w];
+#define EMIT(key, delta)                                              \
+  do {                                                                \
+    table_add(T, (key), (delta), res);                                \
+    if (log_keys) {                                                   \
+      const unsigned long long k_ = atomicAdd(&res->n_log, 1ull);     \
+      if (k_ < log_cap) { log_keys[k_] = (key); log_vals[k_] = (delta); } \
+    }                                                                 \
+  } while (0)
+  uint32_t i = 0, j = 0;
+  uint32_t po = 0, pn = 0;      // previous old / new symbol
+  bool po_cov = false, pn_new = false, have = false;
+  while (i < n) {
+    const uint32_t x = s[i];
+    const bool occ = (i + 1 < n) && x == l && s[i + 1] == r;
+    if (occ) {
+      if (have) EMIT(pair_key(po, x), -f);      // (prev, l): l is consumed
+      EMIT(pair_key(x, r), -f);                 // (l, r) itself
+      if (have) EMIT(pair_key(pn, m), f);       // (prev_new, merged)
+      po = r; po_cov = true; pn = m; pn_new = true; have = true;
+      s[j++] = m;
+      i += 2;
+    } else {
+      if (have) {
+        if (po_cov) EMIT(pair_key(po, x), -f);  // (r, x): r was consumed
+        if (pn_new) EMIT(pair_key(pn, x), f);   // (merged, x)
+      }
+      po = x; po_cov = false; pn = x; pn_new = false; have = true;
+      s[j++] = x;
+      i += 1;
+    }
+  }
+#undef EMIT
+  wlen[w] = j;
+  atomicAdd(&res->n_syms, (unsigned long long)0 - (unsigned long long)(n - j));
+}
+
+__global__ void add_remote_kernel(const unsigned long long *__restrict__ keys, const long long *__restrict__ vals, uint64_t n,
+                                  PairTable T, TrainResult *res) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    if (vals[i] != 0) table_add(T, keys[i], vals[i], res);
+}
+
+// live entries -> (keys, counts) list
+__global__ void table_export_kernel(const unsigned long long *__restrict__ keys, const long long *__restrict__ cnt, uint64_t cap,
+                                    unsigned long long *__restrict__ out_keys, long long *__restrict__ out_vals, uint64_t out_cap,
+                                    unsigned long long *n_out) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
+    if (keys[i] != kEmptyKey && cnt[i] != 0) {
+      const unsigned long long k = atomicAdd(n_out, 1ull);
+      if (k < out_cap) { out_keys[k] = keys[i]; out_vals[k] = cnt[i]; }
+    }
+  }
+}
+
+__global__ void table_rehash_kernel(const unsigned long long *__restrict__ keys, const long long *__restrict__ cnt, uint64_t cap,
+                                    PairTable dst, TrainResult *res) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x)
+    if (keys[i] != kEmptyKey && cnt[i] != 0) table_add(dst, keys[i], cnt[i], res);
+}
+
+}  // namespace swt
+
+using namespace swt;
+
+struct swt_bpe_trainer {
+  uint64_t n_words = 0, n_syms0 = 0;
+  uint32_t n_base = 0;
+  std::vector<uint32_t> base_syms;
+  uint32_t *d_sym = nullptr;
+  uint64_t *d_woff = nullptr;
+  uint32_t *d_wlen = nullptr;
+  uint32_t *d_freq = nullptr;
+  PairTable T{nullptr, nullptr, 0};
+  TrainResult *d_res = nullptr;
+  TrainResult h_res{};
+  uint64_t pos_base = 0;
+  bool hist_ready = false;
+  // delta log (sharded training)
+  bool logging = false;
+  unsigned long long *d_log_keys = nullptr;
+  long long *d_log_vals = nullptr;
+  uint64_t log_cap = 0;
+  DevBuf tmp;
+};
+
+static unsigned grid_for(uint64_t n, int threads, unsigned cap = 1u << 20) {
+  uint64_t g = (n + threads - 1) / threads;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (unsigned)g;
+}
+
+static int table_alloc(PairTable &T, uint32_t bits) {
+  const size_t cap = (size_t)1 << bits;
+  T.bits = bits;
+  SWT_HIP(hipMalloc((void **)&T.keys, cap * 8));
+  SWT_HIP(hipMalloc((void **)&T.cnt, cap * 8));
+  hipLaunchKernelGGL(table_clear_kernel, dim3(grid_for(cap, 256, 4096)), dim3(256), 0, 0, T.keys, T.cnt, (uint64_t)cap);
+  return SWT_OK;
+}
+
+static void table_free(PairTable &T) {
+  if (T.keys) (void)hipFree(T.keys);
+  if (T.cnt) (void)hipFree(T.cnt);
+  T.keys = nullptr;
+  T.cnt = nullptr;
+}
+
+static int sync_result(swt_bpe_trainer *t) {
+  SWT_HIP(hipMemcpy(&t->h_res, t->d_res, sizeof(TrainResult), hipMemcpyDeviceToHost));
+  return SWT_OK;
+}
+
+// Rebuild the table at `bits` from its live entries (drops zero-count keys).
+static int table_resize(swt_bpe_trainer *t, uint32_t bits) {
+  PairTable nt{nullptr, nullptr, 0};
+  int rc = table_alloc(nt, bits);
+  if (rc) return rc;
+  SWT_HIP(hipMemset(&t->d_res->n_used, 0, 8));
+  const uint64_t cap = 1ull << t->T.bits;
+  hipLaunchKernelGGL(table_rehash_kernel, dim3(grid_for(cap, 256, 4096)), dim3(256), 0, 0, t->T.keys, t->T.cnt, cap, nt, t->d_res);
+  SWT_HIP(hipDeviceSynchronize());
+  table_free(t->T);
+  t->T = nt;
+  return SWT_OK;
+}
+
+static int build_histogram(swt_bpe_trainer *t) {
+  // size for the worst case first (every position a distinct pair), then shrink to what is used
+  uint32_t bits = 10;
+  while ((1ull << bits) < 2 * t->n_syms0 + 16 && bits < 31) bits++;
+  int rc = table_alloc(t->T, bits);
+  if (rc) return rc;
+  if (t->n_words)
+    hipLaunchKernelGGL(hist_build_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff,
+                       t->d_wlen, t->d_freq, t->n_words, t->T, t->d_res);
+  SWT_HIP(hipDeviceSynchronize());
+  if ((rc = sync_result(t))) return rc;
+  uint32_t want = 10;
+  while ((1ull << want) < 4 * t->h_res.n_used + 1024) want++;
+  if (want < bits) {
+    if ((rc = table_resize(t, want))) return rc;
+  }
+  t->hist_ready = true;
+  return SWT_OK;
+}
+
+static int trainer_upload(swt_bpe_trainer *t, const uint32_t *syms, const uint64_t *word_off, const uint32_t *freq, uint64_t n_words) {
+  int rc = ensure_device();
+  if (rc) return rc;
+  const uint64_t n_syms = word_off[n_words];
+  t->n_words = n_words;
+  t->n_syms0 = n_syms;
+  std::vector<uint32_t> wlen(n_words + 1);
+  for (uint64_t w = 0; w < n_words; w++) {
+    if (word_off[w + 1] < word_off[w]) return fail(SWT_ERR_INVALID, "word offsets must be non-decreasing");
+    if (word_off[w + 1] - word_off[w] > 0xFFFFFFFFull) return fail(SWT_ERR_UNSUPPORTED, "word too long");
+    wlen[w] = (uint32_t)(word_off[w + 1] - word_off[w]);
+  }
+  SWT_HIP(hipMalloc((void **)&t->d_sym, (n_syms + 16) * 4));
+  SWT_HIP(hipMalloc((void **)&t->d_woff, (n_words + 1) * 8));
+  SWT_HIP(hipMalloc((void **)&t->d_wlen, (n_words + 1) * 4));
+  SWT_HIP(hipMalloc((void **)&t->d_freq, (n_words + 1) * 4));
+  SWT_HIP(hipMalloc((void **)&t->d_res, sizeof(TrainResult)));
+  SWT_HIP(hipMemset(t->d_res, 0, sizeof(TrainResult)));
+  if (n_syms) SWT_HIP(hipMemcpy(t->d_sym, syms, n_syms * 4, hipMemcpyHostToDevice));
+  SWT_HIP(hipMemcpy(t->d_woff, word_off, (n_words + 1) * 8, hipMemcpyHostToDevice));
+  if (n_words) {
+    SWT_HIP(hipMemcpy(t->d_wlen, wlen.data(), n_words * 4, hipMemcpyHostToDevice));
+    SWT_HIP(hipMemcpy(t->d_freq, freq, n_words * 4, hipMemcpyHostToDevice));
+  }
+  unsigned long long ns = n_syms;
+  SWT_HIP(hipMemcpy(&t->d_res->n_syms, &ns, 8, hipMemcpyHostToDevice));
+  // distinct code points (the initial vocab, bpe.py:75)
+  std::vector<uint32_t> b(syms, syms + n_syms);
+  std::sort(b.begin(), b.end());
+  b.erase(std::unique(b.begin(), b.end()), b.end());
+  t->base_syms = b;
+  t->n_base = (uint32_t)b.size();
+  return build_histogram(t);
+}
+
+extern "C" {
+
+int swt_bpe_train_create_words(const uint32_t *syms, const uint64_t *word_off, const uint32_t *freq, uint64_t n_words,
+                               swt_bpe_trainer **out) {
+  if (!out || !word_off || (n_words && (!freq || (word_off[n_words] && !syms)))) return fail(SWT_ERR_INVALID, "null argument");
+  if (word_off[0] != 0) return fail(SWT_ERR_INVALID, "word_off[0] must be 0");
+  auto *t = new swt_bpe_trainer();
+  int rc = trainer_upload(t, syms, word_off, freq, n_words);
+  if (rc) { swt_bpe_train_destroy(t); return rc; }
+  *out = t;
+  return SWT_OK;
+}
+
+// bpe.py:70-81 on the host: pre-tokenize (utils.py:27 split), Counter(words) in first-occurrence order, symbolise.
+int swt_bpe_train_create_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, swt_bpe_trainer **out) {
+  if (!out || !sent_off || (n_sent && sent_off[n_sent] && !text)) return fail(SWT_ERR_INVALID, "null argument");
+  const uint8_t *cls = host_class_table();
+  std::unordered_map<std::string, uint32_t> index;
+  std::vector<uint32_t> syms, freq;
+  std::vector<uint64_t> woff{0};
+  std::vector<uint32_t> cps;
+  for (uint64_t s = 0; s < n_sent; s++) {
+    const uint8_t *p = text + sent_off[s], *end = text + sent_off[s + 1];
+    while (p < end) {
+      int len;
+      uint32_t cp = utf8_decode_host(p, end, &len);
+      const uint8_t c = cp < kNumCodePoints ? cls[cp] : 0;
+      if (c & SWT_CLS_BERT_WS) { p += len; continue; }
+      const uint8_t *w0 = p;
+      cps.clear();
+      cps.push_back(cp);
+      p += len;
+      if (!(c & SWT_CLS_BERT_PUNCT)) {
+        while (p < end) {
+          cp = utf8_decode_host(p, end, &len);
+          const uint8_t c2 = cp < kNumCodePoints ? cls[cp] : 0;
+          if (c2 & (SWT_CLS_BERT_WS | SWT_CLS_BERT_PUNCT)) break;
+          cps.push_back(cp);
+          p += len;
+        }
+      }
+      std::string key(reinterpret_cast<const char *>(w0), (size_t)(p - w0));
+      auto it = index.find(key);
+      if (it == index.end()) {
+        index.emplace(std::move(key), (uint32_t)freq.size());
+        freq.push_back(1);
+        syms.insert(syms.end(), cps.begin(), cps.end());
+        woff.push_back(syms.size());
+      } else {
+        if (freq[it->second] == 0xFFFFFFFFu) return fail(SWT_ERR_UNSUPPORTED, "word frequency overflows 32 bits");
+        freq[it->second]++;
+      }
+    }
+  }
+  auto *t = new swt_bpe_trainer();
+  int rc = trainer_upload(t, syms.data(), woff.data(), freq.data(), freq.size());
+  if (rc) { swt_bpe_train_destroy(t); return rc; }
+  *out = t;
+  return SWT_OK;
+}
+
+void swt_bpe_train_destroy(swt_bpe_trainer *t) {
+  if (!t) return;
+  for (void *p : {(void *)t->d_sym, (void *)t->d_woff, (void *)t->d_wlen, (void *)t->d_freq, (void *)t->d_res,
+                  (void *)t->d_log_keys, (void *)t->d_log_vals})
+    if (p) (void)hipFree(p);
+  table_free(t->T);
+  t->tmp.release();
+  delete t;
+}
+
+int swt_bpe_train_set_pos_base(swt_bpe_trainer *t, uint64_t pos_base) {
+  if (!t) return fail(SWT_ERR_INVALID, "null trainer");
+  t->pos_base = pos_base;
+  return SWT_OK;
+}
+
+int swt_bpe_train_info(const swt_bpe_trainer *t, uint64_t *n_words, uint64_t *n_symbols, uint32_t *n_base_symbols, uint64_t *n_pairs) {
+  if (!t) return fail(SWT_ERR_INVALID, "null trainer");
+  TrainResult r;
+  SWT_HIP(hipMemcpy(&r, t->d_res, sizeof r, hipMemcpyDeviceToHost));
+  if (n_words) *n_words = t->n_words;
+  if (n_symbols) *n_symbols = r.n_syms;
+  if (n_base_symbols) *n_base_symbols = t->n_base;
+  if (n_pairs) *n_pairs = r.n_used;
+  return SWT_OK;
+}
+
+int swt_bpe_train_base_symbols(const swt_bpe_trainer *t, uint32_t *out, uint32_t cap) {
+  if (!t) return fail(SWT_ERR_INVALID, "null trainer");
+  if (cap < t->n_base) return fail(SWT_ERR_CAPACITY, "need room for %u symbols", t->n_base);
+  std::copy(t->base_syms.begin(), t->base_syms.end(), out);
+  return SWT_OK;
+}
+
+int swt_bpe_train_best(swt_bpe_trainer *t, uint32_t *left, uint32_t *right, uint64_t *count, uint64_t *n_tied,
+                       uint64_t *first_pos) {
+  if (!t || !left || !right || !count) return fail(SWT_ERR_INVALID, "null argument");
+  int rc = ensure_device();
+  if (rc) return rc;
+  const uint64_t cap = 1ull << t->T.bits;
+  const unsigned g = grid_for(cap, 256 * 4, 2048);
+  hipLaunchKernelGGL(result_reset_kernel, dim3(1), dim3(1), 0, 0, t->d_res);
+  hipLaunchKernelGGL(argmax_max_kernel, dim3(g), dim3(256), 0, 0, t->T.cnt, cap, t->d_res);
+  hipLaunchKernelGGL(argmax_tie_kernel, dim3(g), dim3(256), 0, 0, t->T.keys, t->T.cnt, cap, t->d_res);
+  if (t->n_words) {
+    hipLaunchKernelGGL(first_pos_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff,
+                       t->d_wlen, t->n_words, t->T, t->d_res);
+    hipLaunchKernelGGL(winner_kernel, dim3(1), dim3(1), 0, 0, t->d_sym, t->d_res);
+  }
+  if ((rc = sync_result(t))) return rc;
+  const TrainResult &r = t->h_res;
+  *count = r.max_count;
+  if (n_tied) *n_tied = r.n_tied;
+  if (r.max_count == 0) { *left = *right = 0; if (first_pos) *first_pos = kEmptyKey; return SWT_OK; }
+  unsigned long long key = r.best_key;
+  unsigned long long pos = kEmptyKey;
+  if (r.n_tied >= 2) {
+    if (r.best_pos != kEmptyKey) { key = r.win_key; pos = t->pos_base + r.best_pos; }
+    else key = kEmptyKey;  // none of the tied pairs occurs in this shard
+  }
+  *left = (uint32_t)(key >> 32);
+  *right = (uint32_t)key;
+  if (first_pos) *first_pos = pos;
+  return SWT_OK;
+}
+
+int swt_bpe_train_apply(swt_bpe_trainer *t, uint32_t left, uint32_t right, uint32_t merged) {
+  if (!t) return fail(SWT_ERR_INVALID, "null trainer");
+  int rc = ensure_device();
+  if (rc) return rc;
+  // keep the load factor below 1/2 even if every occurrence creates two new pairs
+  const uint64_t cap = 1ull << t->T.bits;
+  uint64_t occ = t->h_res.max_count < t->h_res.n_syms ? t->h_res.max_count : t->h_res.n_syms;
+  if (occ == 0) occ = t->n_syms0;
+  if (2 * (t->h_res.n_used + 2 * occ + 64) > cap) {
+    uint32_t bits = t->T.bits;
+    while ((1ull << bits) < 4 * (t->h_res.n_used + 2 * occ + 64)) bits++;
+    if (bits > 32) return fail(SWT_ERR_UNSUPPORTED, "pair table would exceed 2^32 slots");
+    if ((rc = table_resize(t, bits))) return rc;
+  }
+  if (t->logging) SWT_HIP(hipMemsetAsync(&t->d_res->n_log, 0, 8, 0));
+  if (t->n_words)
+    hipLaunchKernelGGL(apply_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff,
+                       t->d_wlen, t->d_freq, t->n_words, left, right, merged, t->T, t->d_res,
+                       t->logging ? t->d_log_keys : nullptr, t->logging ? t->d_log_vals : nullptr, t->log_cap);
+  SWT_HIP(hipGetLastError());
+  // n_used may have grown; the next best() refreshes h_res.  Be conservative until then.
+  t->h_res.n_used += 2 * occ;
+  return SWT_OK;
+}
+
+int swt_bpe_train_export(swt_bpe_trainer *t, uint32_t *syms, uint64_t syms_cap, uint64_t *word_off, uint32_t *freq) {
+  if (!t || !word_off) return fail(SWT_ERR_INVALID, "null argument");
+  std::vector<uint32_t> wlen(t->n_words + 1), all(t->n_syms0 + 1);
+  std::vector<uint64_t> woff(t->n_words + 1);
+  if (t->n_words) SWT_HIP(hipMemcpy(wlen.data(), t->d_wlen, t->n_words * 4, hipMemcpyDeviceToHost));
+  SWT_HIP(hipMemcpy(woff.data(), t->d_woff, (t->n_words + 1) * 8, hipMemcpyDeviceToHost));
+  if (t->n_syms0) SWT_HIP(hipMemcpy(all.data(), t->d_sym, t->n_syms0 * 4, hipMemcpyDeviceToHost));
+  uint64_t o = 0;
+  for (uint64_t w = 0; w < t->n_words; w++) {
+    word_off[w] = o;
+    for (uint32_t i = 0; i < wlen[w]; i++) {
+      if (o >= syms_cap) return fail(SWT_ERR_CAPACITY, "syms buffer too small");
+      syms[o++] = all[woff[w] + i];
+    }
+  }
+  word_off[t->n_words] = o;
+  if (freq && t->n_words) SWT_HIP(hipMemcpy(freq, t->d_freq, t->n_words * 4, hipMemcpyDeviceToHost));
+  return SWT_OK;
+}
+
+int swt_bpe_train_histogram(swt_bpe_trainer *t, uint64_t *keys, uint64_t *counts, uint64_t cap, uint64_t *n) {
+  if (!t || !n) return fail(SWT_ERR_INVALID, "null argument");
+  int rc;
+  if ((rc = t->tmp.reserve(cap * 16 + 16))) return rc;
+  unsigned long long *d_n = t->tmp.as<unsigned long long>();
+  unsigned long long *d_k = d_n + 1;
+  long long *d_v = reinterpret_cast<long long *>(d_k + cap);
+  SWT_HIP(hipMemset(d_n, 0, 8));
+  const uint64_t tcap = 1ull << t->T.bits;
+  hipLaunchKernelGGL(table_export_kernel, dim3(grid_for(tcap, 256, 4096)), dim3(256), 0, 0, t->T.keys, t->T.cnt, tcap, d_k, d_v, cap, d_n);
+  unsigned long long got = 0;
+  SWT_HIP(hipMemcpy(&got, d_n, 8, hipMemcpyDeviceToHost));
+  *n = got;
+  if (got > cap) return fail(SWT_ERR_CAPACITY, "histogram holds %llu live pairs", got);
+  if (got) {
+    SWT_HIP(hipMemcpy(keys, d_k, got * 8, hipMemcpyDeviceToHost));
+    SWT_HIP(hipMemcpy(counts, d_v, got * 8, hipMemcpyDeviceToHost));
+  }
+  return SWT_OK;
+}
+
+// ---- sharded training -----------------------------------------------------------------------------
+
+int swt_bpe_train_take_deltas(swt_bpe_trainer *t, uint64_t *d_keys, int64_t *d_vals, uint64_t cap, uint64_t *n, void *stream) {
+  if (!t || !n) return fail(SWT_ERR_INVALID, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (!t->logging) {
+    // first call: switch logging on and hand out the whole local histogram as the initial "delta"
+    t->log_cap = 4 * t->n_syms0 + 1024;
+    SWT_HIP(hipMalloc((void **)&t->d_log_keys, t->log_cap * 8));
+    SWT_HIP(hipMalloc((void **)&t->d_log_vals, t->log_cap * 8));
+    t->logging = true;
+    SWT_HIP(hipMemsetAsync(&t->d_res->n_log, 0, 8, st));
+    const uint64_t tcap = 1ull << t->T.bits;
+    hipLaunchKernelGGL(table_export_kernel, dim3(grid_for(tcap, 256, 4096)), dim3(256), 0, st, t->T.keys, t->T.cnt, tcap,
+                       t->d_log_keys, t->d_log_vals, t->log_cap, &t->d_res->n_log);
+  }
+  unsigned long long got = 0;
+  SWT_HIP(hipMemcpyAsync(&got, &t->d_res->n_log, 8, hipMemcpyDeviceToHost, st));
+  SWT_HIP(hipStreamSynchronize(st));
+  *n = got;
+  if (got > t->log_cap) return fail(SWT_ERR_CAPACITY, "delta log overflow (%llu entries)", got);
+  if (got > cap) return fail(SWT_ERR_CAPACITY, "delta buffer too small: need %llu entries", got);
+  if (got) {
+    SWT_HIP(hipMemcpyAsync(d_keys, t->d_log_keys, got * 8, hipMemcpyDeviceToDevice, st));
+    SWT_HIP(hipMemcpyAsync(d_vals, t->d_log_vals, got * 8, hipMemcpyDeviceToDevice, st));
+  }
+  return SWT_OK;
+}
+
+int swt_bpe_train_add_remote(swt_bpe_trainer *t, const uint64_t *d_keys, const int64_t *d_vals, uint64_t n, void *stream) {
+  if (!t || (n && (!d_keys || !d_vals))) return fail(SWT_ERR_INVALID, "null argument");
+  if (!n) return SWT_OK;
+  int rc = sync_result(t);
+  if (rc) return rc;
+  const uint64_t cap = 1ull << t->T.bits;
+  if (2 * (t->h_res.n_used + n + 64) > cap) {
+    uint32_t bits = t->T.bits;
+    while ((1ull << bits) < 4 * (t->h_res.n_used + n + 64)) bits++;
+    if (bits > 32) return fail(SWT_ERR_UNSUPPORTED, "pair table would exceed 2^32 slots");
+    if ((rc = table_resize(t, bits))) return rc;
+  }
+  hipLaunchKernelGGL(add_remote_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const unsigned long long *>(d_keys), reinterpret_cast<const long long *>(d_vals), n, t->T, t->d_res);
+  SWT_HIP(hipGetLastError());
+  return SWT_OK;
+}
+
+}  // extern "C"

@@ -4,9 +4,10 @@
 The reference (/root/reference) never travels to the GPU box, so everything the parity tests need from
 it is produced here and committed as data:
 
-  ref/                          data artefacts copied verbatim from the reference (JSON corpora, the
-                                pretrained merges/vocab, the tutorial KATs, the author-generated
-                                pan_tadeusz token lists) -- data, not code
+  ref/                          data artefacts copied verbatim from the reference, in the reference's own
+                                layout (data/*.json corpora, resources/pretrained/<Model>/ merges+vocab,
+                                resources/tests/<Model>/ tutorial KATs, the author-generated pan_tadeusz
+                                token lists) -- data, not code
   bpe_train5k_1000.json         FastBPE.train(train-5K, max_vocab=1000): the 922 merges + digests
   bpe_train_micro.json          tie-break / overlap / exhaustion micro-corpora with their merges
   fuzz_bpe.json                 seeded fuzz sentences -> FastBPE.tokenize (pretrained + 922 tables)
@@ -135,20 +136,21 @@ def main():
     ref_dir = os.path.join(HERE, "ref")
     os.makedirs(ref_dir, exist_ok=True)
     copies = {
-        "data/train-5K.json": "train-5K.json",
-        "data/pan_tadeusz.json": "pan_tadeusz.json",
-        "resources/pretrained/FastBPE/merges.json": "pretrained_merges.json",
-        "resources/pretrained/FastWordPiece/vocab.json": "pretrained_vocab.json",
-        "resources/tests/FastBPE/merges.json": "tutorial_merges.json",
-        "resources/tests/FastWordPiece/vocab.json": "tutorial_vocab.json",
+        "data/train-5K.json": "data/train-5K.json",
+        "data/pan_tadeusz.json": "data/pan_tadeusz.json",
+        "resources/pretrained/FastBPE/merges.json": "resources/pretrained/FastBPE/merges.json",
+        "resources/pretrained/FastWordPiece/vocab.json": "resources/pretrained/FastWordPiece/vocab.json",
+        "resources/tests/FastBPE/merges.json": "resources/tests/FastBPE/merges.json",
+        "resources/tests/FastWordPiece/vocab.json": "resources/tests/FastWordPiece/vocab.json",
     }
     for src, dst in copies.items():
+        os.makedirs(os.path.dirname(os.path.join(ref_dir, dst)), exist_ok=True)
         shutil.copyfile(os.path.join(REF, src), os.path.join(ref_dir, dst))
         os.chmod(os.path.join(ref_dir, dst), 0o644)
     gold = json.load(open(os.path.join(REF, "data/pan_tadeusz.tokens.json"), encoding="utf-8"))
     assert gold["NaiveBPE"] == gold["FastBPE"] and gold["NaiveWordPiece"] == gold["FastWordPiece"]
     # the author-generated token lists (the Naive lists are identical, so one copy of each family is kept)
-    dump("ref/pan_tadeusz.tokens.json", {"FastBPE": gold["FastBPE"], "FastWordPiece": gold["FastWordPiece"]})
+    dump("ref/data/pan_tadeusz.tokens.json", {"FastBPE": gold["FastBPE"], "FastWordPiece": gold["FastWordPiece"]})
 
     train5k = json.load(open(os.path.join(REF, "data/train-5K.json"), encoding="utf-8"))
     pan = json.load(open(os.path.join(REF, "data/pan_tadeusz.json"), encoding="utf-8"))
