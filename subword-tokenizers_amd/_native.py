@@ -32,6 +32,8 @@ SIGNATURES = {
     "swt_init": (C.c_int, [C.c_int]),
     "swt_device_count": (C.c_int, []),
     "swt_device_info": (C.c_int, [C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    "swt_profile_enable": (C.c_int, [C.c_int]),
+    "swt_profile_read": (C.c_int, [C.POINTER(C.c_double), u64p]),
     "swt_class_of": (C.c_uint, [C.c_uint32]),
     "swt_bpe_table_create": (C.c_int, [u32p, u32p, u32p, C.c_uint32, vpp]),
     "swt_bpe_table_destroy": (None, [C.c_void_p]),
@@ -84,6 +86,14 @@ def lib():
             raise ImportError(
                 "libswt_hip.so is not built (%s). Run `python -c \"import __graft_entry__ as g; g.build()\"` "
                 "or `python subword-tokenizers_amd/_build.py`; there is no Python/CPU fallback." % path)
+        # One HIP runtime per process: PyTorch ships its own libamdhip64.so.7 (same SONAME as /opt/rocm's).  When
+        # torch is importable, load it FIRST so that libswt_hip.so binds to the runtime torch already holds;
+        # the other order leaves torch unable to see the GPU ("No HIP GPUs are available").
+        if not os.environ.get("SWT_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = the .so is stale against include/swt.h
@@ -116,6 +126,17 @@ def device_count():
 
 def init(device=0):
     check(lib().swt_init(device))
+
+
+def profile_enable(on=True):
+    check(lib().swt_profile_enable(1 if on else 0))
+
+
+def profile_read():
+    """-> (summed milliseconds of the dominant kernel, launches) since the last read"""
+    ms, n = C.c_double(), C.c_uint64()
+    check(lib().swt_profile_read(C.byref(ms), C.byref(n)))
+    return ms.value, n.value
 
 
 def device_info():

@@ -24,6 +24,7 @@ struct alignas(16) BpeSlot {
 };
 
 constexpr uint8_t kClsWs = 1, kClsPunct = 2, kClsCont = 0x80;
+constexpr uint32_t kNoRank = 0xFFFFFFFFu, kDirtyRank = 0xFFFFFFFEu;
 
 __device__ __forceinline__ bool slot_lookup(const BpeSlot *__restrict__ slots, uint32_t bits, uint32_t l, uint32_t r,
                                             uint32_t &rank, uint32_t &merged) {
@@ -99,9 +100,12 @@ __device__ GiantResult giant_word(const uint8_t *__restrict__ text, uint64_t pos
 __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
     const uint8_t *__restrict__ text, uint64_t n_bytes, const uint64_t *__restrict__ sent_off,
     const uint64_t *__restrict__ plan, const uint8_t *__restrict__ cls_tab, const BpeSlot *__restrict__ slots,
-    uint32_t bits, uint32_t *__restrict__ scratch, uint32_t *__restrict__ sent_local, uint32_t *__restrict__ tile_tok) {
+    uint32_t bits, const uint32_t *__restrict__ merged_of_rank, uint32_t *__restrict__ scratch,
+    uint32_t *__restrict__ sent_local, uint32_t *__restrict__ tile_tok) {
   __shared__ TileLds L;
+  __shared__ uint32_t rk[kCap];  // rank of the pair (symbol here, next symbol of the word); kNoRank when none
   __shared__ uint16_t wl[kCap];  // word starts, one list per wave (its quarter of the chunk)
+  __shared__ uint32_t wnext[kWaves];
   __shared__ GiantResult s_giant;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -187,12 +191,15 @@ __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
       ce = (uint32_t)L.cut;
     }
 
-    // ---- C. word starts (utils.py:27 split): each wave lists the words that begin in its quarter
+    // ---- C. per byte position, all lanes busy: (1) word starts (utils.py:27 split) into per-wave lists,
+    // (2) the rank of the pair this symbol forms with the NEXT symbol of its word -- every lookup of the first
+    // merge round is issued here, one independent table probe per lane, instead of serially per word
     uint32_t nwords = 0;
     uint16_t *const mywl = wl + wave * kQuarter;
     for (int r = 0; r < kQuarter / 64; r++) {
       const uint32_t p = wave * kQuarter + r * 64 + lane;
       bool is = false;
+      uint32_t rank = kNoRank;
       if (p >= off0 && p < ce) {
         const uint8_t c = L.cls[p];
         if (!(c & (kClsCont | kClsWs))) {
@@ -203,15 +210,28 @@ __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
             while (q > off0 && (L.cls[q] & kClsCont)) q--;
             is = (L.cls[q] & (kClsWs | kClsPunct | kClsCont)) != 0;
           }
+          if (!(c & kClsPunct)) {
+            uint32_t q = p + utf8_len(L.txt[p]);
+            while (q < ce && (L.cls[q] & kClsCont)) q++;
+            if (q < ce && !tile_sbit(L, q) && !(L.cls[q] & (kClsWs | kClsPunct))) {
+              uint32_t rk_, mg_;
+              if (slot_lookup(slots, bits, L.sym[p], L.sym[q], rk_, mg_)) rank = rk_;
+            }
+          }
         }
       }
+      if (p < kCap) rk[p] = rank;
       const unsigned long long m = __ballot(is);
       if (is) mywl[nwords + __popcll(m & lt)] = (uint16_t)p;
       nwords += __popcll(m);
     }
+    if (lane == 0) wnext[wave] = 64;
+    // (rk[] of a word is written by the lanes of this wave or the next one: a word may cross the quarter)
+    __syncthreads();
 
-    // ---- D. one lane per word: gather symbols, merge loop (bpe.py:205-243), '##' flag, invalidate the tail
-    for (uint32_t k = lane; k < nwords; k += 64) {
+    // ---- D. one lane per word, words handed out dynamically inside the wave: gather symbols + cached ranks,
+    // merge loop (bpe.py:205-243) touching the table only for pairs a merge created, '##' flag, invalidate the tail
+    for (uint32_t k = lane; k < nwords; k = atomicAdd(&wnext[wave], 1u)) {
       const uint32_t ws = mywl[k];
       uint32_t n = 0, p = ws;
       if (L.cls[ws] & kClsPunct) {
@@ -219,8 +239,8 @@ __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
         p = ws + utf8_len(L.txt[ws]);
       } else {
         for (;;) {
-          const uint32_t cp = L.sym[p];
-          L.sym[ws + n] = cp;
+          L.sym[ws + n] = L.sym[p];
+          rk[ws + n] = rk[p];
           n++;
           p += utf8_len(L.txt[p]);
           while (p < ce && (L.cls[p] & kClsCont)) p++;
@@ -230,8 +250,39 @@ __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
         }
       }
       if (p > ce) p = ce;
-      n = merge_word(&L.sym[ws], n, slots, bits);
-      for (uint32_t i = 1; i < n; i++) L.sym[ws + i] |= SWT_BPE_CONT;
+      uint32_t *const s = &L.sym[ws];
+      uint32_t *const rr = &rk[ws];
+      while (n >= 2) {
+        uint32_t best = kNoRank;
+        for (uint32_t i = 0; i + 1 < n; i++) best = min(best, rr[i]);
+        if (best == kNoRank) break;
+        const uint32_t mg = merged_of_rank[best];
+        // replace every occurrence left to right (equal rank <=> equal pair); ranks next to a merge go stale
+        uint32_t i = 0, j = 0;
+        while (i < n) {
+          if (i + 1 < n && rr[i] == best) {
+            s[j] = mg;
+            rr[j] = kDirtyRank;
+            i += 2;
+          } else {
+            const bool next_taken = (i + 2 < n) && rr[i + 1] == best;
+            const uint32_t keep = rr[i];
+            s[j] = s[i];
+            rr[j] = next_taken ? kDirtyRank : keep;
+            i += 1;
+          }
+          j++;
+        }
+        n = j;
+        rr[n - 1] = kNoRank;
+        for (uint32_t q = 0; q + 1 < n; q++) {
+          if (rr[q] == kDirtyRank) {
+            uint32_t rk_, mg_;
+            rr[q] = slot_lookup(slots, bits, s[q], s[q + 1], rk_, mg_) ? rk_ : kNoRank;
+          }
+        }
+      }
+      for (uint32_t i = 1; i < n; i++) s[i] |= SWT_BPE_CONT;
       for (uint32_t q = ws + n; q < p; q++) L.sym[q] = kInvalidTok;
     }
     __syncthreads();
@@ -252,7 +303,9 @@ using namespace swt;
 
 struct swt_bpe_table {
   std::vector<BpeSlot> h_slots;  // built on the host at create; uploaded on first encode
+  std::vector<uint32_t> h_merged;  // merged symbol id by rank
   BpeSlot *d_slots = nullptr;
+  uint32_t *d_merged = nullptr;
   uint32_t bits = 0;
   uint32_t n_merges = 0;
   TileWorkspace ws;
@@ -265,6 +318,9 @@ static int bpe_upload(swt_bpe_table *t) {
   if (rc) return rc;
   SWT_HIP(hipMalloc((void **)&t->d_slots, t->h_slots.size() * sizeof(BpeSlot)));
   SWT_HIP(hipMemcpy(t->d_slots, t->h_slots.data(), t->h_slots.size() * sizeof(BpeSlot), hipMemcpyHostToDevice));
+  SWT_HIP(hipMalloc((void **)&t->d_merged, (t->h_merged.size() + 1) * 4));
+  if (!t->h_merged.empty())
+    SWT_HIP(hipMemcpy(t->d_merged, t->h_merged.data(), t->h_merged.size() * 4, hipMemcpyHostToDevice));
   return SWT_OK;
 }
 
@@ -295,6 +351,7 @@ int swt_bpe_table_create(const uint32_t *left, const uint32_t *right, const uint
     slots[h].rank = i;
     slots[h].merged = merged[i];
   }
+  t->h_merged.assign(merged, merged + n_merges);
   *out = t;
   return SWT_OK;
 }
@@ -302,6 +359,7 @@ int swt_bpe_table_create(const uint32_t *left, const uint32_t *right, const uint
 void swt_bpe_table_destroy(swt_bpe_table *t) {
   if (!t) return;
   if (t->d_slots) (void)hipFree(t->d_slots);
+  if (t->d_merged) (void)hipFree(t->d_merged);
   t->ws.release();
   for (DevBuf *b : {&t->in_text, &t->in_off, &t->out_ids, &t->out_off, &t->n_tok}) b->release();
   delete t;
@@ -328,9 +386,11 @@ int swt_bpe_encode_dev(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes
     return SWT_OK;
   }
   launch_plan(d_sent_off, n_sent, n_tiles, t->ws.plan.as<uint64_t>(), st);
+  prof_begin(st);
   hipLaunchKernelGGL(bpe_encode_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, st, d_text, n_bytes, d_sent_off,
-                     t->ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->ws.scratch.as<uint32_t>(),
+                     t->ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, t->ws.scratch.as<uint32_t>(),
                      t->ws.sent_local.as<uint32_t>(), t->ws.tile_tok.as<uint32_t>());
+  prof_end(st);
   launch_scan_gather(d_sent_off, n_sent, n_tiles, t->ws, d_out_ids, d_out_off, d_n_tokens, st);
   SWT_HIP(hipGetLastError());
   return SWT_OK;

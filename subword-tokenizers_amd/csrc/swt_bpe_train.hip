@@ -511,10 +511,12 @@ int swt_bpe_train_apply(swt_bpe_trainer *t, uint32_t left, uint32_t right, uint3
     if ((rc = table_resize(t, bits))) return rc;
   }
   if (t->logging) SWT_HIP(hipMemsetAsync(&t->d_res->n_log, 0, 8, 0));
+  prof_begin(0);
   if (t->n_words)
     hipLaunchKernelGGL(apply_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff,
                        t->d_wlen, t->d_freq, t->n_words, left, right, merged, t->T, t->d_res,
                        t->logging ? t->d_log_keys : nullptr, t->logging ? t->d_log_vals : nullptr, t->log_cap);
+  prof_end(0);
   SWT_HIP(hipGetLastError());
   // n_used may have grown; the next best() refreshes h_res.  Be conservative until then.
   t->h_res.n_used += 2 * occ;

@@ -76,6 +76,27 @@ void DevBuf::release() {
   cap = 0;
 }
 
+static bool g_prof_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pending, g_prof_pool;
+
+void prof_begin(hipStream_t st) {
+  if (!g_prof_on) return;
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (!g_prof_pool.empty()) {
+    ev = g_prof_pool.back();
+    g_prof_pool.pop_back();
+  } else {
+    if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) return;
+  }
+  (void)hipEventRecord(ev.first, st);
+  g_prof_pending.push_back(ev);
+}
+
+void prof_end(hipStream_t st) {
+  if (!g_prof_on || g_prof_pending.empty()) return;
+  (void)hipEventRecord(g_prof_pending.back().second, st);
+}
+
 static std::vector<uint8_t> g_cls;
 static std::once_flag g_cls_once;
 static uint8_t *g_cls_dev = nullptr;
@@ -137,6 +158,28 @@ int swt_device_info(int *n_cu, char *name, size_t name_cap) {
   if (name && name_cap) {
     snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
   }
+  return SWT_OK;
+}
+
+int swt_profile_enable(int on) {
+  swt::g_prof_on = on != 0;
+  return SWT_OK;
+}
+
+int swt_profile_read(double *ms_total, uint64_t *n_launches) {
+  double ms = 0;
+  uint64_t n = 0;
+  for (auto &ev : swt::g_prof_pending) {
+    float t = 0;
+    SWT_HIP(hipEventSynchronize(ev.second));
+    SWT_HIP(hipEventElapsedTime(&t, ev.first, ev.second));
+    ms += t;
+    n++;
+    swt::g_prof_pool.push_back(ev);
+  }
+  swt::g_prof_pending.clear();
+  if (ms_total) *ms_total = ms;
+  if (n_launches) *n_launches = n;
   return SWT_OK;
 }
 

@@ -40,6 +40,7 @@ struct WpDev {
   uint32_t unk_id;        // "['UNK']"
   uint32_t corner_id;     // single id emitted for the '##' corner (token, "[UNK]" or the marker)
   uint32_t corner_nonterm;  // 1: the reference never returns from NaiveWP.encode_word("##")
+  uint32_t empty_status;    // status of an empty sentence: s = " " raises IndexError iff the root has a ' ' edge
 };
 
 __device__ __forceinline__ int32_t edge_lookup(const WpDev &T, uint32_t node, uint32_t cp) {
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(kThreads) void wp_encode_kernel(
           const uint64_t e = sent_off[s + 1];
           const uint32_t n = wp_sentence(src, cb, e, tile_out + run, T, stt);
           // empty sentences that also start at cb come first and get no tokens
-          for (uint64_t z = s_next; z <= s; z++) { sent_local[z] = run; status[z] = SWT_WP_OK; }
+          for (uint64_t z = s_next; z <= s; z++) { sent_local[z] = run; status[z] = (uint8_t)T.empty_status; }
           status[s] = (uint8_t)stt;
           s_giant.end = e;
           s_giant.ntok = n;
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(kThreads) void wp_encode_kernel(
         __syncthreads();
         if (cb >= span_end) {
           // trailing empty sentences at the very end of the span
-          for (uint64_t z = s_next + tid; z < s_hi; z += kThreads) { sent_local[z] = run; status[z] = SWT_WP_OK; }
+          for (uint64_t z = s_next + tid; z < s_hi; z += kThreads) { sent_local[z] = run; status[z] = (uint8_t)T.empty_status; }
           break;
         }
         continue;
@@ -246,13 +247,10 @@ __global__ __launch_bounds__(kThreads) void wp_encode_kernel(
       if (rel > ce || (rel == ce && !last)) break;
       const uint64_t e = sent_off[s + 1] - abase;  // <= ce: chunks end at sentence starts
       int stt = SWT_WP_OK;
-      uint32_t n = 0;
-      if (rel < e) {
-        LdsSrc src{&L};
-        n = wp_sentence(src, rel, e, &L.sym[rel], T, stt);
-      } else {
-        // empty sentence: s = " " -> no tokens (wordpiece.py:248-270)
-      }
+      // an empty sentence still runs: s = " " (wordpiece.py:248); it yields no token but may raise (a vocabulary
+      // with a " " edge at the root) -- it never writes to out
+      LdsSrc src{&L};
+      const uint32_t n = wp_sentence(src, rel, e, &L.sym[rel < kCap ? rel : 0], T, stt);
       for (uint64_t q = rel + n; q < e; q++) L.sym[q] = kInvalidTok;
       status[s] = (uint8_t)stt;
     }
@@ -522,11 +520,14 @@ int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, c
   T.root_sharp = t->H.root_sharp;
   T.unk_id = t->H.n_vocab;
   T.corner_nonterm = t->H.corner_nonterm ? 1u : 0u;
+  T.empty_status = t->H.child(t->H.root, ' ') >= 0 ? SWT_WP_INDEXERROR : SWT_WP_OK;
   T.corner_id = t->H.corner.size() == 1 ? t->H.corner[0] : t->H.n_vocab + 2;
   launch_plan(d_sent_off, n_sent, n_tiles, t->ws.plan.as<uint64_t>(), st);
+  prof_begin(st);
   hipLaunchKernelGGL(wp_encode_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, st, d_text, n_bytes, d_sent_off,
                      t->ws.plan.as<uint64_t>(), d_cls, T, t->ws.scratch.as<uint32_t>(), t->ws.sent_local.as<uint32_t>(),
                      t->ws.tile_tok.as<uint32_t>(), d_status);
+  prof_end(st);
   launch_scan_gather(d_sent_off, n_sent, n_tiles, t->ws, d_out_ids, d_out_off, d_n_tokens, st);
   SWT_HIP(hipGetLastError());
   return SWT_OK;

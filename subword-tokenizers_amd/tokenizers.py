@@ -147,10 +147,14 @@ class NaiveBPE(SubwordTokenizer):
         trainer = N.BpeTrainer.from_text(text, off)  # bpe.py:70-81 (split, Counter, symbolise)
         syms = _SymbolTable()
         self.vocab.update(chr(int(c)) for c in trainer.base_symbols())  # bpe.py:75
+        done = set()
         while len(self.vocab) < max_vocab:  # bpe.py:88
             left, right, count, _tied, _pos = trainer.best()  # bpe.py:90-102
             if count == 0:  # bpe.py:98-99
                 break
+            if (left, right) in done:  # symbols only ever merge: a merged pair cannot come back
+                raise RuntimeError("pair histogram inconsistent: %r selected twice" % ((left, right),))
+            done.add((left, right))
             ls, rs = syms.string(left), syms.string(right)
             self.vocab.add(ls + rs)  # bpe.py:103
             self.merges_list.append((ls, rs))  # bpe.py:104

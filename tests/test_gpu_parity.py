@@ -1,0 +1,393 @@
+"""Parity of the HIP path (through the C ABI of libswt_hip.so) against the CPU oracle and the committed golden
+vectors.  Needs a real MI355X: run with `-m gpu`.  Bit-exact everywhere: this is integer/index work."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(native):
+    if native.device_count() < 1:
+        pytest.fail("no HIP device: the gpu-marked tests need an MI355X (there is no CPU fallback to test)")
+    native.init(0)
+    return native
+
+
+@pytest.fixture(scope="module")
+def bpe(swt, dev, ref_dir):
+    tok = swt.FastBPE()
+    tok.load_resources(os.path.join(ref_dir, "resources/pretrained/FastBPE"))
+    return tok
+
+
+@pytest.fixture(scope="module")
+def bpe_orc(oracle, bpe):
+    return oracle.OracleBPE(bpe.merges_list)
+
+
+@pytest.fixture(scope="module")
+def wp(swt, dev, ref_dir):
+    tok = swt.FastWP()
+    tok.load_resources(os.path.join(ref_dir, "resources/pretrained/FastWordPiece"))
+    return tok
+
+
+@pytest.fixture(scope="module")
+def wp_orc(oracle, wp):
+    return oracle.OracleWP(wp._tokens)
+
+
+def same_bpe(tok, orc, texts):
+    ids, off = tok.encode_ids_batch(texts)
+    oids, ooff = orc.tokenize_batch_ids(texts)
+    assert np.array_equal(off, ooff)
+    assert np.array_equal(ids, oids)
+    return ids, off
+
+
+def same_wp(tok, orc, texts):
+    ids, off, st = tok.encode_ids_batch(texts)
+    oids, ooff, ost = orc.tokenize_batch_ids(texts)
+    assert np.array_equal(st, ost)
+    assert np.array_equal(off, ooff)
+    assert np.array_equal(ids, oids)
+    return ids, off, st
+
+
+# ---------------------------------------------------------------------------------------------- BPE encode
+
+def test_bpe_author_golden(bpe, corpora):
+    """reference data/pan_tadeusz.tokens.json (989 sentences, 11,117 tokens)"""
+    out = bpe.tokenize_batch(corpora["pan"])
+    assert out == corpora["pan_tokens"]["FastBPE"]
+    assert sum(map(len, out)) == 11117
+    assert bpe.tokenize(corpora["pan"][3]) == corpora["pan_tokens"]["FastBPE"][3]  # the reference's one-sentence call
+
+
+def test_bpe_train5k_ids(bpe, bpe_orc, corpora):
+    ids, off = same_bpe(bpe, bpe_orc, corpora["t5k"])
+    assert ids.size == 101863
+
+
+def test_bpe_fuzz_golden(swt, bpe, golden):
+    fz = golden("fuzz_bpe.json")
+    texts = [c["text"] for c in fz["sentences"]]
+    out = bpe.tokenize_batch(texts)
+    for c, got in zip(fz["sentences"], out):
+        assert got == c["pretrained"], repr(c["text"])
+    t5 = swt.FastBPE()
+    t5.merges_list = [tuple(m) for m in golden("bpe_train5k_1000.json")["merges"]]
+    t5._build_table()
+    out = t5.tokenize_batch(texts)
+    for c, got in zip(fz["sentences"], out):
+        assert got == c["t5k"], repr(c["text"])
+    for c in fz["encode_word"]:
+        assert bpe.encode_word(c["word"]) == c["pretrained"]
+        assert t5.encode_word(c["word"]) == c["t5k"]
+
+
+def test_bpe_encode_word_is_not_pretokenized(bpe, bpe_orc):
+    """encode_word takes the string as ONE word (bpe.py:206): spaces and punctuation are ordinary symbols"""
+    for w in ["a b", "nie wiem, co", "x.y", " ", "ab" * 40, "słowo słowo"]:
+        assert bpe.encode_word(w) == bpe_orc.encode_word(w), repr(w)
+    assert bpe.encode_word("") == [""]
+
+
+def test_bpe_edge_shapes(bpe, bpe_orc):
+    cases = [
+        [],
+        [""],
+        ["", "", ""],
+        ["a"],
+        ["", "a", "", "b", ""],
+        [" ", "  ", "\t\n"],
+        ["!" * 5000],                      # every byte its own word
+        ["słowo " * 3000],                 # one sentence spanning many chunks
+        ["x" * 20000],                     # a single word longer than the LDS chunk (global-memory path)
+        ["ab" * 6000 + " " + "nie " * 10],
+        ["ż" * 3000 + " koniec"],          # multi-byte giant word
+        ["a" * 4095, "b" * 4096, "c" * 4097, "d" * 2047, "e" * 2048, "f" * 2049],  # around tile/chunk sizes
+        ["wyraz"] * 3000,                  # many short sentences per tile
+        [("zdanie numer %d. " % i) * (i % 7) for i in range(500)],
+        ["\U0001F600 emoji \U0001F600\U0001F601 x", "中文 字", "İstanbul", "áb", "a\x00b", "\ud800x"],
+    ]
+    for texts in cases:
+        same_bpe(bpe, bpe_orc, texts)
+
+
+def test_bpe_ragged_random_batches(bpe, bpe_orc, corpora):
+    rng = np.random.default_rng(7)
+    pool = corpora["t5k"] + corpora["pan"] + ["", " ", "x" * 5000, "ala, ma! kota?"]
+    for _ in range(6):
+        k = int(rng.integers(1, 400))
+        texts = [pool[int(i)] for i in rng.integers(0, len(pool), size=k)]
+        same_bpe(bpe, bpe_orc, texts)
+
+
+def test_bpe_duplicate_and_unreachable_merges(swt, oracle, dev):
+    merges = [("a", "b"), ("c", "d"), ("a", "b"), ("ab", "cd"), ("xy", "z"), ("b", "c")]
+    tok = swt.FastBPE()
+    tok.merges_list = list(merges)
+    tok._build_table()
+    orc = oracle.OracleBPE(merges)
+    for w in ["abcd", "abcdabcd", "xyz", "bcbc", "aabbccdd"]:
+        assert tok.tokenize(w) == orc.tokenize(w), w
+
+
+def test_bpe_s85k_full_size_properties(swt, oracle, dev):
+    """config 2 at full size: bit-exact vs the oracle on ALL of S85k, plus size-independent properties"""
+    from subword_tokenizers_amd import synth
+
+    sents = synth.s85k()
+    tok = swt.FastBPE()
+    tok.merges_list = list(synth.pretrained_merges()[:8000])
+    tok._build_table()
+    orc = oracle.OracleBPE(tok.merges_list)
+    ids, off = same_bpe(tok, orc, sents)
+    # determinism and batch-independence: a different batching gives the same per-sentence ids
+    ids2, off2 = tok.encode_ids_batch(sents[::-1])
+    n = len(sents)
+    for i in (0, 1, n // 2, n - 1):
+        a = ids[int(off[i]):int(off[i + 1])]
+        b = ids2[int(off2[n - 1 - i]):int(off2[n - i])]
+        assert np.array_equal(a, b)
+    # detokenisation round trip: concatenated token strings spell the pre-tokenized words
+    words = [w for w, _ in tok.preprocessing([sents[5]])[0]]
+    toks = tok.decode_ids(ids[int(off[5]):int(off[6])])
+    assert "".join(t[2:] if t.startswith("##") else t for t in toks) == "".join(words)
+    assert sum(not t.startswith("##") for t in toks) == len(words)
+
+
+def test_bpe_device_buffer_entry_point(bpe, bpe_orc, dev, corpora):
+    """swt_bpe_encode_dev with caller-owned device buffers (torch is only the allocator here)"""
+    torch = pytest.importorskip("torch")
+    texts = corpora["pan"][:300]
+    text, off = dev.pack_utf8([t.lower() for t in texts])
+    d_text = torch.from_numpy(text.copy()).cuda()
+    d_off = torch.from_numpy(off.view(np.int64).copy()).cuda()
+    d_out = torch.empty(text.size + 64, dtype=torch.int32, device="cuda")
+    d_out_off = torch.empty(len(texts) + 1, dtype=torch.int64, device="cuda")
+    d_n = torch.zeros(1, dtype=torch.int64, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        bpe._table.encode_dev(d_text.data_ptr(), int(text.size), d_off.data_ptr(), len(texts), d_out.data_ptr(),
+                              d_out_off.data_ptr(), d_n.data_ptr(), 0, side.cuda_stream)
+    side.synchronize()
+    n = int(d_n.item())
+    oids, ooff = bpe_orc.tokenize_batch_ids(texts)
+    assert np.array_equal(d_out[:n].cpu().numpy().view(np.uint32), oids)
+    assert np.array_equal(d_out_off.cpu().numpy().view(np.uint64), ooff)
+
+
+# ---------------------------------------------------------------------------------------------- WP encode
+
+def test_wp_author_golden(wp, corpora):
+    out = wp.tokenize_batch(corpora["pan"])
+    assert out == corpora["pan_tokens"]["FastWordPiece"]
+    assert sum(map(len, out)) == 29164
+    assert wp.tokenize(corpora["pan"][3]) == corpora["pan_tokens"]["FastWordPiece"][3]
+
+
+def test_wp_train5k_ids(wp, wp_orc, corpora):
+    ids, off, st = same_wp(wp, wp_orc, corpora["t5k"])
+    assert ids.size == 312665 and not st.any()  # zero UNK-free, all terminate
+
+
+def test_wp_fuzz_golden_with_nontermination(swt, wp, golden, ref_dir):
+    fw = golden("fuzz_wp.json")
+    tut = swt.FastWP()
+    tut.load_resources(os.path.join(ref_dir, "resources/tests/FastWordPiece"))
+
+    def run(tok, text):
+        try:
+            return tok.tokenize(text)
+        except RuntimeError:
+            return "TIMEOUT"  # the reference spins forever; we refuse (documented deviation)
+        except IndexError:
+            return "INDEXERROR"
+
+    for c in fw["sentences"]:
+        assert run(wp, c["text"]) == c["pretrained"], repr(c["text"])
+        if c["tutorial"] is not None:
+            assert run(tut, c["text"]) == c["tutorial"], repr(c["text"])
+    # statuses come back per sentence in a batch
+    texts = [c["text"] for c in fw["sentences"]]
+    ids, off, st = wp.encode_ids_batch(texts)
+    want = np.array([1 if c["pretrained"] == "TIMEOUT" else (2 if c["pretrained"] == "INDEXERROR" else 0) for c in fw["sentences"]])
+    assert np.array_equal(st, want)
+    for i, c in enumerate(fw["sentences"]):
+        if want[i]:
+            assert off[i] == off[i + 1]
+        else:
+            assert wp._decode(ids[int(off[i]):int(off[i + 1])]) == c["pretrained"]
+
+
+def test_wp_odd_vocabularies(swt, dev, golden):
+    """tries with '##' corners, tokens containing spaces/punctuation, empty vocabulary"""
+    for o in golden("fuzz_wp.json")["odd"]:
+        tok = swt.FastWP()
+        tok.vocab = set(o["vocab"])
+        tok._build_trie()
+        for c in o["cases"]:
+            try:
+                got = tok.tokenize(c["text"])
+            except RuntimeError:
+                got = "TIMEOUT"
+            except IndexError:
+                got = "INDEXERROR"
+            assert got == c["tokens"], (o["vocab"], c["text"])
+
+
+def test_wp_edge_shapes(wp, wp_orc):
+    cases = [
+        [],
+        [""],
+        ["", "", ""],
+        ["", "a", "", "b", ""],
+        ["słowo " * 3000],            # one sentence longer than a chunk (global-memory walker)
+        ["x" * 20000],
+        ["nie wiem " * 700, "a", "tak " * 1200, ""],
+        ["a" * 4095, "b" * 4096, "c" * 4097, "d" * 2047, "e" * 2048, "f" * 2049],
+        ["wyraz"] * 3000,
+        ["hello!", "a ## b", "(a", "ok", "abc€def", "dobrze"],   # non-terminating ones mixed with fine ones
+        ["5×2km", "˝zgoda˝", "áb", "zażółć gęślą jaźń"],
+    ]
+    for texts in cases:
+        same_wp(wp, wp_orc, texts)
+
+
+def test_wp_v30k_subsample_and_properties(swt, oracle, dev):
+    """config 3 shape: V30k vocabulary, Zipf corpus; oracle parity on a 20,000-sentence subsample"""
+    from subword_tokenizers_amd import synth
+
+    vocab = synth.v30k()
+    tok = swt.FastWP()
+    tok.vocab = set(vocab)
+    tok._build_trie()
+    text, off = synth.wp_corpus(100000, seed=1000000, vocab=vocab)
+    ids, ooff, st = tok._trie.encode(text, off)
+    assert not st.any()  # the generator only uses characters that are single-char tokens: the reference terminates
+    sub = synth.unpack(text, off, 0, 20000)
+    orc = oracle.OracleWP(tok._tokens)
+    oids, oooff, ost = orc.tokenize_batch_ids(sub)
+    assert np.array_equal(ids[:int(ooff[20000])], oids) and np.array_equal(ooff[:20001], oooff)
+    # batch independence: the same sentences in a smaller batch give the same ids
+    t2, o2 = synth.wp_corpus(100000, seed=1000000, vocab=vocab)
+    assert np.array_equal(t2, text)
+    ids_b, off_b, _ = tok._trie.encode(text[:int(off[5000])].copy(), off[:5001].copy())
+    assert np.array_equal(ids_b, ids[:int(ooff[5000])])
+    # every emitted id is a vocabulary index or the UNK id
+    assert int(ids.max()) <= len(vocab)
+
+
+# ---------------------------------------------------------------------------------------------- BPE train
+
+def test_train_tutorial_kat(swt, dev, golden):
+    """reference resources/tests/FastBPE/merges.json: README tutorial corpus, max_vocab=25"""
+    tok = swt.FastBPE()
+    tok.train(["This is a sentence.", "Another example sentence."], 25)
+    assert [list(p) for p in tok.merges_list] == golden("ref/resources/tests/FastBPE/merges.json")
+    assert len(tok.vocab) == 25 and tok._bpe_ranks[("e", "n")] == 0
+    assert tok.tokenize("This sentence") == ["this", "sentence"]
+
+
+def test_train_micro_tie_breaks(swt, dev, golden):
+    for c in golden("bpe_train_micro.json"):
+        tok = swt.NaiveBPE()
+        tok.train(list(c["corpus"]), c["max_vocab"])
+        assert [list(p) for p in tok.merges_list] == c["merges"], (c["corpus"], c["max_vocab"])
+        assert len(tok.vocab) == c["vocab_size"]
+
+
+def test_train_5k_config1(swt, dev, golden, corpora):
+    """config 1: train-5K, max_vocab=1000 -> the reference's 922 merges and its tokenization digest"""
+    import hashlib
+    import json
+
+    g = golden("bpe_train5k_1000.json")
+    tok = swt.FastBPE()
+    tok.train(corpora["t5k"], 1000)
+    assert [list(p) for p in tok.merges_list] == g["merges"]
+    assert len(tok.vocab) == 1000
+    toks = tok.tokenize_batch(corpora["t5k"])
+    digest = hashlib.sha256(json.dumps(toks, ensure_ascii=False).encode("utf-8")).hexdigest()
+    assert digest == g["tokens_sha256"]
+    # corpus_as_symbols (bpe.py:23): the final segmentation of every unique word with its frequency
+    cas = tok.corpus_as_symbols
+    assert len(cas) == 22971 and sum(f for _, f in cas) == 80161
+
+
+def test_train_state_matches_oracle_stepwise(swt, oracle, dev, corpora):
+    """histogram and stream after every merge vs the oracle's full recount (exactness of the incremental update)"""
+    sents = corpora["pan"][:300]
+    text, off = dev.pack_utf8([s.lower() for s in sents])
+    tr = dev.BpeTrainer.from_text(text, off)
+    orc = oracle.OracleBPETrainer(sents)
+    syms0, woff0, freq0 = orc.export()
+    ds, dw, df = tr.export()
+    assert np.array_equal(ds, syms0) and np.array_equal(dw, woff0) and np.array_equal(df, freq0)
+    from subword_tokenizers_amd.tokenizers import _SymbolTable
+
+    st = _SymbolTable()
+    for step in range(60):
+        left, right, count, tied, pos = tr.best()
+        orc.run(10 ** 9, 1)
+        ids, cnt = orc.merge_ids()
+        assert (left, right, count) == (int(ids[-1][0]), int(ids[-1][1]), int(cnt[-1])), step
+        merged = st.intern(st.string(left) + st.string(right))
+        assert merged == int(ids[-1][2])
+        tr.apply(left, right, merged)
+        if step % 10 == 9:
+            ds, dw, _ = tr.export()
+            os_, ow, _ = orc.export()
+            assert np.array_equal(ds, os_) and np.array_equal(dw, ow)
+            # histogram == full recount of the oracle's stream
+            keys, cnts = tr.histogram()
+            want = {}
+            for w in range(len(ow) - 1):
+                seq = os_[int(ow[w]):int(ow[w + 1])]
+                for a, b in zip(seq[:-1], seq[1:]):
+                    k = (int(a) << 32) | int(b)
+                    want[k] = want.get(k, 0) + int(freq0[w])
+            got = {int(k): int(c) for k, c in zip(keys, cnts)}
+            assert got == want
+
+
+def test_train_create_words_and_exhaustion(dev, oracle):
+    """from an explicit word list; training to exhaustion stops with count == 0 (bpe.py:98-99)"""
+    syms = np.array([ord(c) for c in "aaaabab"], dtype=np.uint32)
+    woff = np.array([0, 4, 7], dtype=np.uint64)
+    freq = np.array([3, 2], dtype=np.uint32)
+    tr = dev.BpeTrainer.from_words(syms, woff, freq)
+    assert tr.info()["n_base_symbols"] == 2
+    seen = []
+    nxt = 0x110000
+    while True:
+        l, r, c, tied, pos = tr.best()
+        if c == 0:
+            break
+        seen.append((l, r, c))
+        tr.apply(l, r, nxt)
+        nxt += 1
+    # 'aaaa'x3 + 'bab'x2: (a,a) counts 9 first; overlapping occurrences merge left to right
+    assert seen[0] == (ord("a"), ord("a"), 9)
+    ds, dw, _ = tr.export()
+    assert list(np.diff(dw)) == [1, 1]
+
+
+def test_sharded_training_two_handles(swt, oracle, dev, corpora):
+    """two shards on one GPU: local histograms exchanged once, delta lists after every merge, tie-break by
+    the smallest (pos_base + position) -- must reproduce the single-shard merges exactly"""
+    torch = pytest.importorskip("torch")
+    from subword_tokenizers_amd.distributed import LocalGroup, ShardedBpeTrainer
+
+    sents = corpora["pan"][:400]
+    ref = swt.NaiveBPE()
+    ref.train(list(sents), 400)
+    group = LocalGroup(2)
+    shards = [ShardedBpeTrainer.from_corpus(sents, rank=r, world=2, group=group) for r in range(2)]
+    merges = LocalGroup.run_lockstep(shards, max_vocab=400)
+    assert merges == ref.merges_list
