@@ -69,6 +69,10 @@ int swt_device_info(int *n_cu, char *name, size_t name_cap);
 int swt_profile_enable(int on);
 int swt_profile_read(double *ms_total, uint64_t *n_launches);
 
+/* Diagnostics only (ablation timing of kernel phases; results are wrong while a knob is set).  which = 0:
+ * bit mask of phases the encode kernels skip. */
+int swt_debug_knob(int which, int value);
+
 /* Code-point classes compiled into the library (fixture data probed from the wheel/interpreter the
  * reference runs on; tools/gen_unicode_tables.py).  bit0 pre-tokenizer whitespace, bit1 pre-tokenizer
  * punctuation (source/utils.py:27), bit2 str.isspace, bit3 str.isalnum (source/wordpiece.py:285-288). */

@@ -32,6 +32,7 @@ SIGNATURES = {
     "swt_init": (C.c_int, [C.c_int]),
     "swt_device_count": (C.c_int, []),
     "swt_device_info": (C.c_int, [C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    "swt_debug_knob": (C.c_int, [C.c_int, C.c_int]),
     "swt_profile_enable": (C.c_int, [C.c_int]),
     "swt_profile_read": (C.c_int, [C.POINTER(C.c_double), u64p]),
     "swt_class_of": (C.c_uint, [C.c_uint32]),

@@ -25,6 +25,7 @@ struct alignas(16) BpeSlot {
 
 constexpr uint8_t kClsWs = 1, kClsPunct = 2, kClsCont = 0x80;
 constexpr uint32_t kNoRank = 0xFFFFFFFFu, kDirtyRank = 0xFFFFFFFEu;
+constexpr int kClsLds = 1024;
 
 __device__ __forceinline__ bool slot_lookup(const BpeSlot *__restrict__ slots, uint32_t bits, uint32_t l, uint32_t r,
                                             uint32_t &rank, uint32_t &merged) {
@@ -97,16 +98,41 @@ __device__ GiantResult giant_word(const uint8_t *__restrict__ text, uint64_t pos
   return r;
 }
 
+// first probe of two independent lookups issued back to back (one L2 round trip for both); a probe that lands on
+// another key falls back to the ordinary probe loop (rare at load factor <= 1/2)
+__device__ __forceinline__ void slot_lookup2(const BpeSlot *__restrict__ slots, uint32_t bits, uint32_t l0, uint32_t r0,
+                                             uint32_t l1, uint32_t r1, bool second, uint32_t &v0, uint32_t &v1) {
+  const uint64_t k0 = pair_key(l0, r0), k1 = pair_key(l1, r1);
+  const uint32_t h0 = hash_slot(k0, bits), h1 = second ? hash_slot(k1, bits) : h0;
+  const uint4 a = *reinterpret_cast<const uint4 *>(&slots[h0]);
+  const uint4 b = *reinterpret_cast<const uint4 *>(&slots[h1]);
+  const uint64_t ka = ((uint64_t)a.y << 32) | a.x, kb = ((uint64_t)b.y << 32) | b.x;
+  uint32_t dummy;
+  if (ka == k0) v0 = a.z;
+  else if (ka == kEmptyKey) v0 = kNoRank;
+  else v0 = slot_lookup(slots, bits, l0, r0, v0, dummy) ? v0 : kNoRank;
+  if (second) {
+    if (kb == k1) v1 = b.z;
+    else if (kb == kEmptyKey) v1 = kNoRank;
+    else v1 = slot_lookup(slots, bits, l1, r1, v1, dummy) ? v1 : kNoRank;
+  }
+}
+
+// Packed = true: the cached value of a pair is (rank << 16 | merged - SWT_SYM_BASE), so a merge round needs no
+// table access to learn the merged symbol (tables of < 65535 merges); false: the value is the rank and the merged
+// symbol comes from merged_of_rank[].
+template <bool Packed>
 __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
     const uint8_t *__restrict__ text, uint64_t n_bytes, const uint64_t *__restrict__ sent_off,
     const uint64_t *__restrict__ plan, const uint8_t *__restrict__ cls_tab, const BpeSlot *__restrict__ slots,
     uint32_t bits, const uint32_t *__restrict__ merged_of_rank, uint32_t *__restrict__ scratch,
-    uint32_t *__restrict__ sent_local, uint32_t *__restrict__ tile_tok) {
+    uint32_t *__restrict__ sent_local, uint32_t *__restrict__ tile_tok, uint32_t dbg) {
   __shared__ TileLds L;
   __shared__ uint32_t rk[kCap];  // rank of the pair (symbol here, next symbol of the word); kNoRank when none
   __shared__ uint16_t wl[kCap];  // word starts, one list per wave (its quarter of the chunk)
   __shared__ uint32_t wnext[kWaves];
   __shared__ GiantResult s_giant;
+  __shared__ __attribute__((aligned(16))) uint8_t cls_lo[kClsLds];  // classes of U+0000..U+03FF: no global trip for Latin text
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;
@@ -115,6 +141,11 @@ __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
   if (s_lo == s_hi) {
     if (tid == 0) tile_tok[t] = 0;
     return;
+  }
+  if (tid < kClsLds / 16) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (cls_tab) v = reinterpret_cast<const uint4 *>(cls_tab)[tid];
+    reinterpret_cast<uint4 *>(cls_lo)[tid] = v;
   }
   const uint64_t span_base = sent_off[s_lo], span_end = sent_off[s_hi];
   uint32_t *const tile_out = scratch + span_base;
@@ -130,6 +161,7 @@ __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
     const uint32_t staged = last ? (uint32_t)avail : (uint32_t)kCap;
 
     tile_stage(L, text, n_bytes, abase, staged);
+    if (dbg & 1) { if (last) break; cb = abase + staged; continue; }  // ablation: staging only
 
     // ---- B. per byte: code point + pre-tokenizer class at every lead byte; sentence-start bits
     for (uint32_t p = tid; p < staged; p += kThreads) {
@@ -144,7 +176,9 @@ __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
           cp = b & (0xFF >> (len + 1));
           for (int i = 1; i < len; i++) cp = (cp << 6) | (L.txt[p + i] & 0x3F);
         }
-        const uint8_t c = (cls_tab && cp < kNumCodePoints) ? cls_tab[cp] : (uint8_t)0;
+        uint8_t c = 0;
+        if (cp < (uint32_t)kClsLds) c = cls_lo[cp];
+        else if (cls_tab && cp < kNumCodePoints) c = cls_tab[cp];
         cv = c & (kClsWs | kClsPunct);
         if (!(c & kClsWs)) sv = cp;
       }
@@ -192,38 +226,64 @@ __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
     }
 
     // ---- C. per byte position, all lanes busy: (1) word starts (utils.py:27 split) into per-wave lists,
-    // (2) the rank of the pair this symbol forms with the NEXT symbol of its word -- every lookup of the first
-    // merge round is issued here, one independent table probe per lane, instead of serially per word
+    // (2) the table value of the pair this symbol forms with the NEXT symbol of its word -- every lookup of the
+    // first merge round is issued here, four independent probes in flight per lane, instead of serially per word
     uint32_t nwords = 0;
     uint16_t *const mywl = wl + wave * kQuarter;
-    for (int r = 0; r < kQuarter / 64; r++) {
-      const uint32_t p = wave * kQuarter + r * 64 + lane;
-      bool is = false;
-      uint32_t rank = kNoRank;
-      if (p >= off0 && p < ce) {
-        const uint8_t c = L.cls[p];
-        if (!(c & (kClsCont | kClsWs))) {
-          if (c & kClsPunct) is = true;
-          else if (p == off0 || tile_sbit(L, p)) is = true;
-          else {
-            uint32_t q = p - 1;
-            while (q > off0 && (L.cls[q] & kClsCont)) q--;
-            is = (L.cls[q] & (kClsWs | kClsPunct | kClsCont)) != 0;
-          }
-          if (!(c & kClsPunct)) {
-            uint32_t q = p + utf8_len(L.txt[p]);
-            while (q < ce && (L.cls[q] & kClsCont)) q++;
-            if (q < ce && !tile_sbit(L, q) && !(L.cls[q] & (kClsWs | kClsPunct))) {
-              uint32_t rk_, mg_;
-              if (slot_lookup(slots, bits, L.sym[p], L.sym[q], rk_, mg_)) rank = rk_;
+    for (int r = 0; r < kQuarter / 64; r += 4) {
+      uint32_t pl[4], pr[4];
+      bool want[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t p = wave * kQuarter + (r + u) * 64 + lane;
+        bool is = false;
+        want[u] = false;
+        pl[u] = pr[u] = 0;
+        if (p >= off0 && p < ce) {
+          const uint8_t c = L.cls[p];
+          if (!(c & (kClsCont | kClsWs))) {
+            if (c & kClsPunct) is = true;
+            else if (p == off0 || tile_sbit(L, p)) is = true;
+            else {
+              uint32_t q = p - 1;
+              while (q > off0 && (L.cls[q] & kClsCont)) q--;
+              is = (L.cls[q] & (kClsWs | kClsPunct | kClsCont)) != 0;
+            }
+            if (!(c & kClsPunct)) {
+              uint32_t q = p + utf8_len(L.txt[p]);
+              while (q < ce && (L.cls[q] & kClsCont)) q++;
+              if (q < ce && !tile_sbit(L, q) && !(L.cls[q] & (kClsWs | kClsPunct)) && !(dbg & 4)) {
+                want[u] = true;
+                pl[u] = L.sym[p];
+                pr[u] = L.sym[q];
+              }
             }
           }
         }
+        const unsigned long long m = __ballot(is);
+        if (is) mywl[nwords + __popcll(m & lt)] = (uint16_t)p;
+        nwords += __popcll(m);
       }
-      if (p < kCap) rk[p] = rank;
-      const unsigned long long m = __ballot(is);
-      if (is) mywl[nwords + __popcll(m & lt)] = (uint16_t)p;
-      nwords += __popcll(m);
+      // four first probes back to back, then resolve
+      uint32_t hh[4];
+      uint4 raw[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) hh[u] = want[u] ? hash_slot(pair_key(pl[u], pr[u]), bits) : 0u;
+#pragma unroll
+      for (int u = 0; u < 4; u++) raw[u] = *reinterpret_cast<const uint4 *>(&slots[hh[u]]);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t p = wave * kQuarter + (r + u) * 64 + lane;
+        uint32_t val = kNoRank;
+        if (want[u]) {
+          const uint64_t key = pair_key(pl[u], pr[u]);
+          const uint64_t k = ((uint64_t)raw[u].y << 32) | raw[u].x;
+          uint32_t dummy;
+          if (k == key) val = raw[u].z;
+          else if (k != kEmptyKey && !slot_lookup(slots, bits, pl[u], pr[u], val, dummy)) val = kNoRank;
+        }
+        rk[p] = val;
+      }
     }
     if (lane == 0) wnext[wave] = 64;
     // (rk[] of a word is written by the lanes of this wave or the next one: a word may cross the quarter)
@@ -231,6 +291,7 @@ __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
 
     // ---- D. one lane per word, words handed out dynamically inside the wave: gather symbols + cached ranks,
     // merge loop (bpe.py:205-243) touching the table only for pairs a merge created, '##' flag, invalidate the tail
+    if (!(dbg & 16))
     for (uint32_t k = lane; k < nwords; k = atomicAdd(&wnext[wave], 1u)) {
       const uint32_t ws = mywl[k];
       uint32_t n = 0, p = ws;
@@ -252,12 +313,12 @@ __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
       if (p > ce) p = ce;
       uint32_t *const s = &L.sym[ws];
       uint32_t *const rr = &rk[ws];
-      while (n >= 2) {
+      while (n >= 2 && !(dbg & 8)) {
         uint32_t best = kNoRank;
         for (uint32_t i = 0; i + 1 < n; i++) best = min(best, rr[i]);
         if (best == kNoRank) break;
-        const uint32_t mg = merged_of_rank[best];
-        // replace every occurrence left to right (equal rank <=> equal pair); ranks next to a merge go stale
+        const uint32_t mg = Packed ? (SWT_SYM_BASE + (best & 0xFFFFu)) : merged_of_rank[best];
+        // replace every occurrence left to right (equal value <=> equal pair); values next to a merge go stale
         uint32_t i = 0, j = 0;
         while (i < n) {
           if (i + 1 < n && rr[i] == best) {
@@ -275,11 +336,21 @@ __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
         }
         n = j;
         rr[n - 1] = kNoRank;
-        for (uint32_t q = 0; q + 1 < n; q++) {
-          if (rr[q] == kDirtyRank) {
-            uint32_t rk_, mg_;
-            rr[q] = slot_lookup(slots, bits, s[q], s[q + 1], rk_, mg_) ? rk_ : kNoRank;
-          }
+        // refresh the stale values two at a time: both probes in flight together (one L2 round trip per round
+        // in the common case of a single occurrence)
+        uint32_t q = 0;
+        for (;;) {
+          while (q + 1 < n && rr[q] != kDirtyRank) q++;
+          if (q + 1 >= n) break;
+          const uint32_t a0 = q;
+          uint32_t b0 = q + 1;
+          while (b0 + 1 < n && rr[b0] != kDirtyRank) b0++;
+          const bool second = b0 + 1 < n;
+          uint32_t v0 = kNoRank, v1 = kNoRank;
+          slot_lookup2(slots, bits, s[a0], s[a0 + 1], second ? s[b0] : 0u, second ? s[b0 + 1] : 0u, second, v0, v1);
+          rr[a0] = v0;
+          if (second) rr[b0] = v1;
+          q = (second ? b0 : a0) + 1;
         }
       }
       for (uint32_t i = 1; i < n; i++) s[i] |= SWT_BPE_CONT;
@@ -288,6 +359,7 @@ __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
     __syncthreads();
 
     // ---- E, F
+    if (dbg & 32) { if (last) break; cb = abase + ce; continue; }
     const uint32_t total = tile_compact(L, off0, ce, tile_out + run);
     s_next += tile_record(L, sent_off, sent_local, s_next, s_hi, abase, ce, last, run, total);
     run += total;
@@ -304,6 +376,7 @@ using namespace swt;
 struct swt_bpe_table {
   std::vector<BpeSlot> h_slots;  // built on the host at create; uploaded on first encode
   std::vector<uint32_t> h_merged;  // merged symbol id by rank
+  bool packed = false;             // slot value = rank << 16 | (merged - SWT_SYM_BASE)
   BpeSlot *d_slots = nullptr;
   uint32_t *d_merged = nullptr;
   uint32_t bits = 0;
@@ -325,6 +398,14 @@ static int bpe_upload(swt_bpe_table *t) {
 }
 
 extern "C" {
+
+// diagnostics (not part of include/swt.h): resident workgroups per CU the runtime grants the encode kernel
+int swt_debug_occupancy(int which) {
+  int n = -1;
+  hipError_t e = which ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<false>, kThreads, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<true>, kThreads, 0);
+  return e == hipSuccess ? n : -(int)e;
+}
 
 int swt_bpe_table_create(const uint32_t *left, const uint32_t *right, const uint32_t *merged, uint32_t n_merges,
                          swt_bpe_table **out) {
@@ -352,6 +433,13 @@ int swt_bpe_table_create(const uint32_t *left, const uint32_t *right, const uint
     slots[h].merged = merged[i];
   }
   t->h_merged.assign(merged, merged + n_merges);
+  // packed values when every rank and every merged-symbol index fits 16 bits (any realistic table below 65k merges)
+  t->packed = n_merges < 0xFFFEu;
+  for (uint32_t i = 0; i < n_merges && t->packed; i++)
+    if (merged[i] < SWT_SYM_BASE || merged[i] - SWT_SYM_BASE >= 0xFFFFu) t->packed = false;
+  if (t->packed)
+    for (auto &sl : slots)
+      if (sl.key != kEmptyKey) sl.rank = (sl.rank << 16) | (sl.merged - SWT_SYM_BASE);
   *out = t;
   return SWT_OK;
 }
@@ -387,9 +475,14 @@ int swt_bpe_encode_dev(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes
   }
   launch_plan(d_sent_off, n_sent, n_tiles, t->ws.plan.as<uint64_t>(), st);
   prof_begin(st);
-  hipLaunchKernelGGL(bpe_encode_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, st, d_text, n_bytes, d_sent_off,
-                     t->ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, t->ws.scratch.as<uint32_t>(),
-                     t->ws.sent_local.as<uint32_t>(), t->ws.tile_tok.as<uint32_t>());
+  if (t->packed)
+    hipLaunchKernelGGL(bpe_encode_kernel<true>, dim3((unsigned)n_tiles), dim3(kThreads), 0, st, d_text, n_bytes, d_sent_off,
+                       t->ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, t->ws.scratch.as<uint32_t>(),
+                       t->ws.sent_local.as<uint32_t>(), t->ws.tile_tok.as<uint32_t>(), (uint32_t)debug_knob(0));
+  else
+    hipLaunchKernelGGL(bpe_encode_kernel<false>, dim3((unsigned)n_tiles), dim3(kThreads), 0, st, d_text, n_bytes, d_sent_off,
+                       t->ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, t->ws.scratch.as<uint32_t>(),
+                       t->ws.sent_local.as<uint32_t>(), t->ws.tile_tok.as<uint32_t>(), (uint32_t)debug_knob(0));
   prof_end(st);
   launch_scan_gather(d_sent_off, n_sent, n_tiles, t->ws, d_out_ids, d_out_off, d_n_tokens, st);
   SWT_HIP(hipGetLastError());

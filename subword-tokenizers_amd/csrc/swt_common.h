@@ -28,6 +28,8 @@ int fail(int code, const char *fmt, ...);
 int ensure_device();  // SWT_OK when a device is selected (selects 0 on first use)
 int device_cus();
 
+int debug_knob(int which);
+
 // ---- dominant-kernel timing (bench.py roofline) ---------------------------------------------------
 void prof_begin(hipStream_t st);
 void prof_end(hipStream_t st);

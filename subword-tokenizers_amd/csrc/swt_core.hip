@@ -76,6 +76,9 @@ void DevBuf::release() {
   cap = 0;
 }
 
+static int g_knobs[8] = {0};
+int debug_knob(int which) { return (which >= 0 && which < 8) ? g_knobs[which] : 0; }
+
 static bool g_prof_on = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pending, g_prof_pool;
 
@@ -158,6 +161,12 @@ int swt_device_info(int *n_cu, char *name, size_t name_cap) {
   if (name && name_cap) {
     snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
   }
+  return SWT_OK;
+}
+
+int swt_debug_knob(int which, int value) {
+  if (which < 0 || which >= 8) return swt::fail(SWT_ERR_INVALID, "no such knob");
+  swt::g_knobs[which] = value;
   return SWT_OK;
 }
 
