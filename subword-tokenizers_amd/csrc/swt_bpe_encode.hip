@@ -6,26 +6,38 @@
 //   FastBPE.encode_word / _pairs     /root/reference/source/bpe.py:202-243
 //   the rank dict                    /root/reference/source/bpe.py:200,257
 //
-// Runs on the tile/chunk skeleton of swt_tile.h.  Encoder-specific phases:
-//   B  per byte: decode the code point at every UTF-8 lead byte, look its pre-tokenizer class up
-//   C  per byte: word starts (whitespace removed, every punctuation code point its own word) -> per-wave lists
-//   D  one lane per word: gather the word's code points, run the lowest-rank merge loop against the
-//      device rank table (open-addressing hash, one 16-byte slot per probe), set the '##' flag
-// A span longer than kCap is cut at word boundaries; a single word longer than kCap falls to a one-lane
-// global-memory path (correct, slow, pathological inputs only).
+// One 64-lane wavefront per tile (workgroup = one wave, so every barrier is a wave-local fence):
+//   tile   = the sentences whose first byte lies in one kBpeTile-byte window of the text (whole sentences, no
+//            data-path atomics between workgroups, a tile's tokens are contiguous in the output)
+//   chunk  = up to kBpeCap bytes of the tile's span staged in LDS; longer spans are cut at word boundaries
+//   lane   = one BYTE POSITION in every phase -- including the merge loop:
+//     B/C  64 bytes per step: decode the code point at each UTF-8 lead byte, class from an LDS copy of the table,
+//          then everything structural (word starts, next symbol of the word, head of the word) comes from 64-bit
+//          ballot masks and scalar bit arithmetic; the table value of every adjacent pair is probed here, all
+//          lanes at once (this is the whole first merge round of bpe.py:211-219)
+//     D    merge rounds over the list of symbols that still belong to an unfinished word: per-word minimum by
+//          LDS atomicMin, the winners merge in place (symbols are linked by a next-pointer, nothing is shifted),
+//          and only symbols next to a merge probe the table again -- one L2 round trip per round for the wave
+//     E/F  order-preserving ballot compaction to the tile's output run, per-sentence offsets
+// A word longer than a chunk falls to a one-lane global-memory path (correct, slow, pathological inputs only).
 #include "swt_tile.h"
 
 namespace swt {
 
 struct alignas(16) BpeSlot {
   uint64_t key;     // left << 32 | right, kEmptyKey when free
-  uint32_t rank;    // index in merges_list (last duplicate wins)
+  uint32_t rank;    // table value: rank, or rank << 16 | (merged - SWT_SYM_BASE) in a packed table
   uint32_t merged;  // symbol id of left+right
 };
 
-constexpr uint8_t kClsWs = 1, kClsPunct = 2, kClsCont = 0x80;
-constexpr uint32_t kNoRank = 0xFFFFFFFFu, kDirtyRank = 0xFFFFFFFEu;
-constexpr int kClsLds = 1024;
+constexpr uint8_t kClsWs = 1, kClsPunct = 2;
+constexpr uint32_t kNoRank = 0xFFFFFFFFu;
+constexpr int kClsLds = 1024;    // code points whose class is served from LDS (64 lanes x 16 B)
+
+constexpr int kBpeTile = 256;   // bytes of sentence starts per tile
+constexpr int kBpeCap = 512;    // staged bytes per chunk
+constexpr int kBpeBlocks = kBpeCap / 64;
+constexpr uint32_t kNoPos = 0xFFFFu;
 
 __device__ __forceinline__ bool slot_lookup(const BpeSlot *__restrict__ slots, uint32_t bits, uint32_t l, uint32_t r,
                                             uint32_t &rank, uint32_t &merged) {
@@ -41,10 +53,14 @@ __device__ __forceinline__ bool slot_lookup(const BpeSlot *__restrict__ slots, u
   }
 }
 
-// FastBPE.encode_word on a symbol array (bpe.py:210-238): repeat { lowest-rank adjacent pair; replace all
-// of its occurrences left to right, non-overlapping }.  Returns the new length.
-template <class Ptr>
-__device__ __forceinline__ uint32_t merge_word(Ptr s, uint32_t n, const BpeSlot *__restrict__ slots, uint32_t bits) {
+__device__ __forceinline__ uint32_t slot_value(const BpeSlot *__restrict__ slots, uint32_t bits, uint32_t l, uint32_t r) {
+  uint32_t v, m;
+  return slot_lookup(slots, bits, l, r, v, m) ? v : kNoRank;
+}
+
+// FastBPE.encode_word on a symbol array (bpe.py:210-238), serial form for the one-lane fallback: repeat { lowest-rank
+// adjacent pair; replace all of its occurrences left to right, non-overlapping }.  Returns the new length.
+__device__ uint32_t merge_word(uint32_t *s, uint32_t n, const BpeSlot *__restrict__ slots, uint32_t bits) {
   while (n >= 2) {
     uint32_t best = 0xFFFFFFFFu, bm = 0, bl = 0, br = 0;
     uint32_t a = s[0];
@@ -98,275 +114,382 @@ __device__ GiantResult giant_word(const uint8_t *__restrict__ text, uint64_t pos
   return r;
 }
 
-// first probe of two independent lookups issued back to back (one L2 round trip for both); a probe that lands on
-// another key falls back to the ordinary probe loop (rare at load factor <= 1/2)
-__device__ __forceinline__ void slot_lookup2(const BpeSlot *__restrict__ slots, uint32_t bits, uint32_t l0, uint32_t r0,
-                                             uint32_t l1, uint32_t r1, bool second, uint32_t &v0, uint32_t &v1) {
-  const uint64_t k0 = pair_key(l0, r0), k1 = pair_key(l1, r1);
-  const uint32_t h0 = hash_slot(k0, bits), h1 = second ? hash_slot(k1, bits) : h0;
-  const uint4 a = *reinterpret_cast<const uint4 *>(&slots[h0]);
-  const uint4 b = *reinterpret_cast<const uint4 *>(&slots[h1]);
-  const uint64_t ka = ((uint64_t)a.y << 32) | a.x, kb = ((uint64_t)b.y << 32) | b.x;
-  uint32_t dummy;
-  if (ka == k0) v0 = a.z;
-  else if (ka == kEmptyKey) v0 = kNoRank;
-  else v0 = slot_lookup(slots, bits, l0, r0, v0, dummy) ? v0 : kNoRank;
-  if (second) {
-    if (kb == k1) v1 = b.z;
-    else if (kb == kEmptyKey) v1 = kNoRank;
-    else v1 = slot_lookup(slots, bits, l1, r1, v1, dummy) ? v1 : kNoRank;
-  }
-}
+struct BpeLds {
+  __attribute__((aligned(16))) uint8_t txt[kBpeCap + 16];
+  uint32_t sym[kBpeCap];           // per byte position: symbol id (token id at the end) or kInvalidTok
+  uint16_t nxt[kBpeCap];           // per byte position: next live symbol of the same word, kNoPos for the last one
+  uint32_t act[kBpeCap];           // symbols of unfinished words: position | head position << 16
+  uint32_t aval[kBpeCap];          // per list entry: table value of (this symbol, next symbol); kNoRank when none
+  uint32_t wm[2][kBpeCap / 2];     // per word (indexed by head >> 1): minimum table value, this round / next round
+  unsigned long long sbits[kBpeBlocks + 1];  // sentence-start bit per byte
+  unsigned long long mark[kBpeBlocks + 1];   // "my predecessor is a candidate of a twin pair (a,a)"
+  unsigned long long tk[kBpeBlocks + 1];     // taken: this symbol merges with its next one this round
+  unsigned long long dead[kBpeBlocks + 1];   // consumed by the symbol before it this round
+  unsigned long long vmask[kBpeBlocks + 1];  // phase E
+  uint32_t blkpre[kBpeBlocks + 1];
+  __attribute__((aligned(16))) uint8_t cls_lo[kClsLds];  // classes of U+0000..U+03FF
+  GiantResult giant;
+};
 
-// Packed = true: the cached value of a pair is (rank << 16 | merged - SWT_SYM_BASE), so a merge round needs no
-// table access to learn the merged symbol (tables of < 65535 merges); false: the value is the rank and the merged
-// symbol comes from merged_of_rank[].
+__device__ __forceinline__ bool bit_at(const unsigned long long *m, uint32_t p) { return (m[p >> 6] >> (p & 63)) & 1ull; }
+
+// Packed = true: the table value of a pair is rank << 16 | (merged - SWT_SYM_BASE), so a merge round learns the
+// merged symbol without touching memory (tables below 65,534 merges); false: the value is the rank and the merged
+// symbol is read from merged_of_rank[].
 template <bool Packed>
-__global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
+__global__ __launch_bounds__(64) void bpe_encode_kernel(
     const uint8_t *__restrict__ text, uint64_t n_bytes, const uint64_t *__restrict__ sent_off,
     const uint64_t *__restrict__ plan, const uint8_t *__restrict__ cls_tab, const BpeSlot *__restrict__ slots,
     uint32_t bits, const uint32_t *__restrict__ merged_of_rank, uint32_t *__restrict__ scratch,
     uint32_t *__restrict__ sent_local, uint32_t *__restrict__ tile_tok, uint32_t dbg) {
-  __shared__ TileLds L;
-  __shared__ uint32_t rk[kCap];  // rank of the pair (symbol here, next symbol of the word); kNoRank when none
-  __shared__ uint16_t wl[kCap];  // word starts, one list per wave (its quarter of the chunk)
-  __shared__ uint32_t wnext[kWaves];
-  __shared__ GiantResult s_giant;
-  __shared__ __attribute__((aligned(16))) uint8_t cls_lo[kClsLds];  // classes of U+0000..U+03FF: no global trip for Latin text
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned long long lt = (1ull << lane) - 1ull;
+  __shared__ BpeLds L;
+  const int lane = threadIdx.x;
+  const unsigned long long lt = (1ull << lane) - 1ull;  // lanes below me
+  const unsigned long long le = (2ull << lane) - 1ull;  // me and below
   const uint64_t t = blockIdx.x;
   const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
   if (s_lo == s_hi) {
-    if (tid == 0) tile_tok[t] = 0;
+    if (lane == 0) tile_tok[t] = 0;
     return;
   }
-  if (tid < kClsLds / 16) {
+  {
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (cls_tab) v = reinterpret_cast<const uint4 *>(cls_tab)[tid];
-    reinterpret_cast<uint4 *>(cls_lo)[tid] = v;
+    if (cls_tab) v = reinterpret_cast<const uint4 *>(cls_tab)[lane];
+    reinterpret_cast<uint4 *>(L.cls_lo)[lane] = v;
   }
   const uint64_t span_base = sent_off[s_lo], span_end = sent_off[s_hi];
   uint32_t *const tile_out = scratch + span_base;
-  uint32_t run = 0;        // tokens emitted by this tile so far (block-uniform)
-  uint64_t s_next = s_lo;  // first sentence whose local offset is not recorded yet (block-uniform)
+  uint32_t run = 0;        // tokens emitted by this tile so far
+  uint64_t s_next = s_lo;  // first sentence whose local offset is not recorded yet
   uint64_t cb = span_base;
 
   for (;;) {
     const uint64_t abase = cb & ~15ull;
     const uint32_t off0 = (uint32_t)(cb - abase);
     const uint64_t avail = span_end - abase;
-    const bool last = avail <= (uint64_t)kCap;
-    const uint32_t staged = last ? (uint32_t)avail : (uint32_t)kCap;
+    const bool last = avail <= (uint64_t)kBpeCap;
+    const uint32_t staged = last ? (uint32_t)avail : (uint32_t)kBpeCap;
+    const uint32_t nblk = (staged + 63) >> 6;
 
-    tile_stage(L, text, n_bytes, abase, staged);
+    // ---- A. stage [abase, abase+staged): one dwordx4 per lane
+    for (uint32_t c = lane * 16; c < staged; c += 64 * 16) {
+      const uint64_t g = abase + c;
+      if (g + 16 <= n_bytes && ((reinterpret_cast<uintptr_t>(text + g) & 15) == 0)) {
+        *reinterpret_cast<uint4 *>(&L.txt[c]) = *reinterpret_cast<const uint4 *>(text + g);
+      } else {
+        for (int i = 0; i < 16; i++) L.txt[c + i] = (g + i < n_bytes) ? text[g + i] : (uint8_t)' ';
+      }
+    }
+    if (lane <= kBpeBlocks) { L.sbits[lane] = 0ull; L.mark[lane] = 0ull; L.tk[lane] = 0ull; L.dead[lane] = 0ull; }
+    __syncthreads();
+    for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
+      const uint64_t o = sent_off[s];
+      if (o >= abase + staged) break;
+      if (o >= cb) atomicOr(&L.sbits[(o - abase) >> 6], 1ull << ((o - abase) & 63));
+    }
+    __syncthreads();
     if (dbg & 1) { if (last) break; cb = abase + staged; continue; }  // ablation: staging only
 
-    // ---- B. per byte: code point + pre-tokenizer class at every lead byte; sentence-start bits
-    for (uint32_t p = tid; p < staged; p += kThreads) {
-      const uint8_t b = L.txt[p];
-      uint32_t sv = kInvalidTok;
-      uint8_t cv = kClsCont;
-      if (!utf8_is_cont(b) && p >= off0) {
+    // ---- B/C. 64 bytes per step.  Scalars carried from block to block:
+    uint32_t na = 0;          // active-list length
+    bool prev_wb = true;      // the byte before this block belongs to a whitespace/punctuation char (or chunk start)
+    uint32_t pend = kNoPos;   // last symbol of the previous block whose word may continue, and its data
+    uint32_t pend_head = 0;
+    bool pend_listed = false;
+    int cut = -1;             // last word boundary (for a span longer than the chunk)
+    for (uint32_t blk = 0; blk < nblk; blk++) {
+      const uint32_t p = blk * 64 + lane;
+      const bool inr = p >= off0 && p < staged;
+      const uint8_t b = inr ? L.txt[p] : (uint8_t)' ';
+      const bool lead = !utf8_is_cont(b);
+      uint32_t cp = b;
+      if (b >= 0xC0) {
         int len = utf8_len(b);
         if (p + len > staged) len = (int)(staged - p);
-        uint32_t cp = b;
-        if (b >= 0x80 && len > 1) {
+        if (len > 1) {
           cp = b & (0xFF >> (len + 1));
           for (int i = 1; i < len; i++) cp = (cp << 6) | (L.txt[p + i] & 0x3F);
         }
-        uint8_t c = 0;
-        if (cp < (uint32_t)kClsLds) c = cls_lo[cp];
-        else if (cls_tab && cp < kNumCodePoints) c = cls_tab[cp];
-        cv = c & (kClsWs | kClsPunct);
-        if (!(c & kClsWs)) sv = cp;
       }
-      L.sym[p] = sv;
-      L.cls[p] = cv;
+      uint8_t c = kClsWs;  // bytes outside the chunk behave as whitespace
+      if (inr && lead) c = cp < (uint32_t)kClsLds ? L.cls_lo[cp] : ((cls_tab && cp < kNumCodePoints) ? cls_tab[cp] : (uint8_t)0);
+      const unsigned long long INR = __ballot(inr);
+      const unsigned long long LEAD = __ballot(lead);
+      const unsigned long long WSm = __ballot(lead && (c & kClsWs));
+      const unsigned long long PNm = __ballot(lead && (c & kClsPunct));
+      const unsigned long long CONT = ~LEAD;
+      // bytes that belong to a whitespace/punctuation char (continuation bytes inherit from their lead byte)
+      unsigned long long WB = WSm | PNm | ((prev_wb && (CONT & 1ull)) ? 1ull : 0ull);
+      WB |= (WB << 1) & CONT;
+      WB |= (WB << 1) & CONT;
+      WB |= (WB << 1) & CONT;
+      const unsigned long long SS = L.sbits[blk];
+      const unsigned long long first_bit = blk == 0 ? (1ull << off0) : 0ull;  // off0 < 16
+      const unsigned long long before = (WB << 1) | (prev_wb ? 1ull : 0ull) | SS | first_bit;
+      const unsigned long long SYM = LEAD & ~WSm & INR;
+      const unsigned long long WSTART = SYM & (PNm | before);
+      // chunk cut candidates: word boundaries strictly inside, with room for a whole UTF-8 char behind them
+      {
+        const unsigned long long CUT = LEAD & (WSm | PNm | SS) & __ballot(inr && p > off0 && p + 4 <= staged);
+        if (CUT) cut = (int)(blk * 64 + 63 - __builtin_clzll(CUT));
+      }
+      const bool is_sym = (SYM >> lane) & 1ull;
+      const bool wstart = (WSTART >> lane) & 1ull;
+      const unsigned long long hm = WSTART & le;
+      const uint32_t head = hm ? blk * 64 + 63 - __builtin_clzll(hm) : pend_head;
+      const unsigned long long after = SYM & ~le;
+      const uint32_t q = after ? (uint32_t)__builtin_ctzll(after) : 64u;
+      const bool hasnext = is_sym && q < 64 && !((WSTART >> (q & 63)) & 1ull);
+      // does the symbol left pending by the previous block continue into this one?
+      const uint32_t f = SYM ? (uint32_t)__builtin_ctzll(SYM) : 64u;
+      const bool joins = pend != kNoPos && f < 64 && !((WSTART >> (f & 63)) & 1ull);
+      const bool i_join = joins && lane == (int)f;
+      if (i_join) L.nxt[pend] = (uint16_t)p;
+      L.sym[p] = is_sym ? cp : kInvalidTok;
+      L.nxt[p] = hasnext ? (uint16_t)(blk * 64 + q) : (uint16_t)kNoPos;
+      // active list: symbols of words with at least two symbols (a lone word start waits for its successor)
+      const bool active = is_sym && (!wstart || hasnext);
+      const unsigned long long ACT = __ballot(active);
+      const uint32_t extra = (joins && !pend_listed) ? 1u : 0u;  // the pending word start now has a successor
+      if (i_join && extra) { L.act[na] = pend | (pend_head << 16); L.wm[0][pend_head >> 1] = kNoRank; }
+      if (active) {
+        L.act[na + extra + __popcll(ACT & lt)] = p | (head << 16);
+        if (p == head) L.wm[0][head >> 1] = kNoRank;
+      }
+      na += extra + __popcll(ACT);
+      // carries
+      if (SYM) {
+        const int li = 63 - __builtin_clzll(SYM);
+        const unsigned long long tail = li == 63 ? 0ull : ~((2ull << li) - 1ull);
+        const bool open = ((WSm | PNm | SS) & tail) == 0ull && !((PNm >> li) & 1ull);
+        pend = open ? blk * 64 + li : kNoPos;
+        pend_head = __shfl(head, li);
+        pend_listed = ((ACT >> li) & 1ull) != 0ull;
+      } else {
+        pend = kNoPos;  // a block without symbols holds whitespace: every word ended
+      }
+      prev_wb = (WB >> 63) & 1ull;
     }
-    tile_mark_sentences(L, sent_off, s_next, s_hi, cb, abase, staged);
     __syncthreads();
 
-    // ---- chunk end: the whole rest of the span, or the last word boundary that fits
+    // ---- chunk end
     uint32_t ce = staged;
     if (!last) {
-      int best = -1;
-      for (uint32_t p = tid; p + 4 <= staged; p += kThreads) {
-        if (p <= off0) continue;
-        const uint8_t c = L.cls[p];
-        if (c & kClsCont) continue;
-        if ((c & (kClsWs | kClsPunct)) || tile_sbit(L, p)) best = (int)p;
-      }
-      if (best >= 0) atomicMax(&L.cut, best);
-      __syncthreads();
-      if (L.cut < 0) {
+      if (cut < 0) {
         // a single word longer than the LDS chunk: one lane, global memory
-        if (tid == 0) {
+        if (lane == 0) {
           uint64_t s = s_next;
           while (s < s_hi && sent_off[s] <= cb) s++;
           const uint64_t send = sent_off[s];  // s <= s_hi and sent_off[s_hi] = span_end > cb
-          s_giant = giant_word(text, cb, send, cls_tab, slots, bits, tile_out + run);
+          L.giant = giant_word(text, cb, send, cls_tab, slots, bits, tile_out + run);
         }
         __syncthreads();
-        const GiantResult g = s_giant;
-        for (uint64_t s = s_next + tid; s < s_hi; s += kThreads) {
+        const GiantResult g = L.giant;
+        uint32_t mine = 0;
+        for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
           if (sent_off[s] >= g.end) break;
           sent_local[s] = run;
-          atomicAdd(&L.cnt, 1u);
+          mine++;
         }
-        __syncthreads();
-        s_next += L.cnt;
+        for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+        s_next += mine;
         run += g.ntok;
         cb = g.end;
         __syncthreads();
         continue;
       }
-      ce = (uint32_t)L.cut;
+      ce = (uint32_t)cut;
+      // drop list entries at or beyond the cut (the next chunk stages them again)
+      uint32_t keep = 0;
+      for (uint32_t k0 = 0; k0 < na; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        const uint32_t e = k < na ? L.act[k] : 0u;
+        const bool ok = k < na && (e & 0xFFFFu) < ce;
+        const unsigned long long M = __ballot(ok);
+        __syncthreads();
+        if (ok) L.act[keep + __popcll(M & lt)] = e;
+        keep += __popcll(M);
+        __syncthreads();
+      }
+      na = keep;
     }
 
-    // ---- C. per byte position, all lanes busy: (1) word starts (utils.py:27 split) into per-wave lists,
-    // (2) the table value of the pair this symbol forms with the NEXT symbol of its word -- every lookup of the
-    // first merge round is issued here, four independent probes in flight per lane, instead of serially per word
-    uint32_t nwords = 0;
-    uint16_t *const mywl = wl + wave * kQuarter;
-    for (int r = 0; r < kQuarter / 64; r += 4) {
-      uint32_t pl[4], pr[4];
+    // ---- C2. the table value of every adjacent pair of every listed symbol: the whole first merge round
+    // (bpe.py:211-219), four independent probes in flight per lane; each value also goes into its word's minimum
+    for (uint32_t k0 = 0; k0 < na; k0 += 256) {
+      uint32_t pl[4], pr[4], hh[4], hd[4];
       bool want[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const uint32_t p = wave * kQuarter + (r + u) * 64 + lane;
-        bool is = false;
-        want[u] = false;
-        pl[u] = pr[u] = 0;
-        if (p >= off0 && p < ce) {
-          const uint8_t c = L.cls[p];
-          if (!(c & (kClsCont | kClsWs))) {
-            if (c & kClsPunct) is = true;
-            else if (p == off0 || tile_sbit(L, p)) is = true;
-            else {
-              uint32_t q = p - 1;
-              while (q > off0 && (L.cls[q] & kClsCont)) q--;
-              is = (L.cls[q] & (kClsWs | kClsPunct | kClsCont)) != 0;
-            }
-            if (!(c & kClsPunct)) {
-              uint32_t q = p + utf8_len(L.txt[p]);
-              while (q < ce && (L.cls[q] & kClsCont)) q++;
-              if (q < ce && !tile_sbit(L, q) && !(L.cls[q] & (kClsWs | kClsPunct)) && !(dbg & 4)) {
-                want[u] = true;
-                pl[u] = L.sym[p];
-                pr[u] = L.sym[q];
-              }
-            }
-          }
-        }
-        const unsigned long long m = __ballot(is);
-        if (is) mywl[nwords + __popcll(m & lt)] = (uint16_t)p;
-        nwords += __popcll(m);
-      }
-      // four first probes back to back, then resolve
-      uint32_t hh[4];
       uint4 raw[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) hh[u] = want[u] ? hash_slot(pair_key(pl[u], pr[u]), bits) : 0u;
+      for (int u = 0; u < 4; u++) {
+        const uint32_t k = k0 + u * 64 + lane;
+        want[u] = false;
+        pl[u] = pr[u] = hd[u] = 0;
+        if (k < na && !(dbg & 4)) {
+          const uint32_t e = L.act[k];
+          const uint32_t p = e & 0xFFFFu;
+          const uint32_t qn = L.nxt[p];
+          hd[u] = e >> 17;
+          if (qn != kNoPos) {
+            want[u] = true;
+            pl[u] = L.sym[p];
+            pr[u] = L.sym[qn];
+          }
+        }
+        hh[u] = want[u] ? hash_slot(pair_key(pl[u], pr[u]), bits) : 0u;
+      }
 #pragma unroll
       for (int u = 0; u < 4; u++) raw[u] = *reinterpret_cast<const uint4 *>(&slots[hh[u]]);
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const uint32_t p = wave * kQuarter + (r + u) * 64 + lane;
-        uint32_t val = kNoRank;
+        const uint32_t k = k0 + u * 64 + lane;
+        uint32_t v = kNoRank;
         if (want[u]) {
           const uint64_t key = pair_key(pl[u], pr[u]);
-          const uint64_t k = ((uint64_t)raw[u].y << 32) | raw[u].x;
-          uint32_t dummy;
-          if (k == key) val = raw[u].z;
-          else if (k != kEmptyKey && !slot_lookup(slots, bits, pl[u], pr[u], val, dummy)) val = kNoRank;
+          const uint64_t kk = ((uint64_t)raw[u].y << 32) | raw[u].x;
+          if (kk == key) v = raw[u].z;
+          else if (kk != kEmptyKey) v = slot_value(slots, bits, pl[u], pr[u]);
+          if (v != kNoRank && !(dbg & 8)) atomicMin(&L.wm[0][hd[u]], v);
         }
-        rk[p] = val;
+        if (k < na) L.aval[k] = v;
       }
     }
-    if (lane == 0) wnext[wave] = 64;
-    // (rk[] of a word is written by the lanes of this wave or the next one: a word may cross the quarter)
     __syncthreads();
 
-    // ---- D. one lane per word, words handed out dynamically inside the wave: gather symbols + cached ranks,
-    // merge loop (bpe.py:205-243) touching the table only for pairs a merge created, '##' flag, invalidate the tail
-    if (!(dbg & 16))
-    for (uint32_t k = lane; k < nwords; k = atomicAdd(&wnext[wave], 1u)) {
-      const uint32_t ws = mywl[k];
-      uint32_t n = 0, p = ws;
-      if (L.cls[ws] & kClsPunct) {
-        n = 1;
-        p = ws + utf8_len(L.txt[ws]);
-      } else {
-        for (;;) {
-          L.sym[ws + n] = L.sym[p];
-          rk[ws + n] = rk[p];
-          n++;
-          p += utf8_len(L.txt[p]);
-          while (p < ce && (L.cls[p] & kClsCont)) p++;
-          if (p >= ce) break;
-          if (tile_sbit(L, p)) break;
-          if (L.cls[p] & (kClsWs | kClsPunct)) break;
-        }
-      }
-      if (p > ce) p = ce;
-      uint32_t *const s = &L.sym[ws];
-      uint32_t *const rr = &rk[ws];
-      while (n >= 2 && !(dbg & 8)) {
-        uint32_t best = kNoRank;
-        for (uint32_t i = 0; i + 1 < n; i++) best = min(best, rr[i]);
-        if (best == kNoRank) break;
-        const uint32_t mg = Packed ? (SWT_SYM_BASE + (best & 0xFFFFu)) : merged_of_rank[best];
-        // replace every occurrence left to right (equal value <=> equal pair); values next to a merge go stale
-        uint32_t i = 0, j = 0;
-        while (i < n) {
-          if (i + 1 < n && rr[i] == best) {
-            s[j] = mg;
-            rr[j] = kDirtyRank;
-            i += 2;
+    // ---- D. merge rounds (bpe.py:210-238), all lanes on the symbols of unfinished words.  Two passes per round:
+    //   X  candidates = left symbols of their word's best pair; they publish "taken" (tk) and "consumed" (dead) bits.
+    //      A pair of two different symbols cannot overlap itself, so such a candidate always merges; a twin pair
+    //      (a,a) in a run like "aaaa" merges left to right, non-overlapping (bpe.py:225-235): every second member,
+    //      decided by the run's first member.
+    //   Y  every listed symbol updates itself from those bits (merged symbol, next pointer), re-probes the table only
+    //      if its pair changed, feeds the next round's per-word minimum, and the list is compacted.
+    uint32_t cur = 0, round_no = 0;
+    while (na > 0 && !(dbg & 16)) {
+      round_no++;
+      const bool stop_now = (dbg >> 8) && round_no > (dbg >> 8);  // ablation: bounded rounds
+      bool twin = false;
+      for (uint32_t k = lane; k < na; k += 64) {
+        const uint32_t e = L.act[k];
+        const uint32_t v = L.aval[k];
+        const uint32_t p = e & 0xFFFFu, w = e >> 17;
+        const uint32_t m = stop_now ? kNoRank : L.wm[cur][w];
+        if (p == (e >> 16)) L.wm[cur ^ 1][w] = kNoRank;
+        if (m != kNoRank && v == m) {
+          const uint32_t qn = L.nxt[p];
+          if (L.sym[p] == L.sym[qn]) {
+            atomicOr(&L.mark[qn >> 6], 1ull << (qn & 63));
+            twin = true;
           } else {
-            const bool next_taken = (i + 2 < n) && rr[i + 1] == best;
-            const uint32_t keep = rr[i];
-            s[j] = s[i];
-            rr[j] = next_taken ? kDirtyRank : keep;
-            i += 1;
+            atomicOr(&L.tk[p >> 6], 1ull << (p & 63));
+            atomicOr(&L.dead[qn >> 6], 1ull << (qn & 63));
           }
-          j++;
-        }
-        n = j;
-        rr[n - 1] = kNoRank;
-        // refresh the stale values two at a time: both probes in flight together (one L2 round trip per round
-        // in the common case of a single occurrence)
-        uint32_t q = 0;
-        for (;;) {
-          while (q + 1 < n && rr[q] != kDirtyRank) q++;
-          if (q + 1 >= n) break;
-          const uint32_t a0 = q;
-          uint32_t b0 = q + 1;
-          while (b0 + 1 < n && rr[b0] != kDirtyRank) b0++;
-          const bool second = b0 + 1 < n;
-          uint32_t v0 = kNoRank, v1 = kNoRank;
-          slot_lookup2(slots, bits, s[a0], s[a0 + 1], second ? s[b0] : 0u, second ? s[b0 + 1] : 0u, second, v0, v1);
-          rr[a0] = v0;
-          if (second) rr[b0] = v1;
-          q = (second ? b0 : a0) + 1;
         }
       }
-      for (uint32_t i = 1; i < n; i++) s[i] |= SWT_BPE_CONT;
-      for (uint32_t q = ws + n; q < p; q++) L.sym[q] = kInvalidTok;
+      twin = __any(twin);
+      __syncthreads();
+      if (twin) {
+        for (uint32_t k = lane; k < na; k += 64) {
+          const uint32_t e = L.act[k];
+          uint32_t p = e & 0xFFFFu;
+          const uint32_t m = L.wm[cur][e >> 17];
+          if (m != kNoRank && L.aval[k] == m && L.sym[p] == L.sym[L.nxt[p]] && !bit_at(L.mark, p)) {
+            // first member of a run of twins: take, skip, take, ...  (a member's pair value equals m iff the symbol
+            // after it is the same symbol again)
+            const uint32_t a = L.sym[p];
+            for (;;) {
+              const uint32_t qn = L.nxt[p];
+              if (qn == kNoPos || L.sym[qn] != a) break;
+              atomicOr(&L.tk[p >> 6], 1ull << (p & 63));
+              atomicOr(&L.dead[qn >> 6], 1ull << (qn & 63));
+              p = L.nxt[qn];
+              if (p == kNoPos || L.sym[p] != a) break;
+            }
+          }
+        }
+        __syncthreads();
+      }
+      uint32_t keep = 0;
+      for (uint32_t k0 = 0; k0 < na; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        uint32_t e = 0, v = kNoRank;
+        bool stay = false;
+        if (k < na) {
+          e = L.act[k];
+          v = L.aval[k];
+          const uint32_t p = e & 0xFFFFu, h = e >> 16;
+          const uint32_t m = stop_now ? kNoRank : L.wm[cur][h >> 1];
+          if (bit_at(L.dead, p)) {
+            L.sym[p] = kInvalidTok;  // consumed by the symbol before it; nobody reads a consumed symbol again
+          } else {
+            uint32_t sp = L.sym[p];
+            if (m == kNoRank) {
+              if (p != h) L.sym[p] = sp | SWT_BPE_CONT;  // word finished: '##' on all but its first token (bpe.py:240-241)
+            } else {
+              stay = true;
+              const uint32_t mg = Packed ? (SWT_SYM_BASE + (m & 0xFFFFu)) : merged_of_rank[m];
+              uint32_t nq = L.nxt[p];
+              bool dirty;
+              if (bit_at(L.tk, p)) {
+                nq = L.nxt[nq];  // my partner is consumed; its successor becomes mine
+                sp = mg;
+                L.sym[p] = mg;
+                L.nxt[p] = (uint16_t)nq;
+                dirty = true;
+              } else {
+                dirty = nq != kNoPos && bit_at(L.tk, nq);
+              }
+              if (nq == kNoPos) v = kNoRank;
+              else if (dirty) v = slot_value(slots, bits, sp, bit_at(L.tk, nq) ? mg : L.sym[nq]);
+              if (v != kNoRank) atomicMin(&L.wm[cur ^ 1][h >> 1], v);
+            }
+          }
+        }
+        const unsigned long long M = __ballot(stay);
+        __syncthreads();
+        if (stay) {
+          const uint32_t d = keep + __popcll(M & lt);
+          L.act[d] = e;
+          L.aval[d] = v;
+        }
+        keep += __popcll(M);
+        __syncthreads();
+      }
+      na = keep;
+      if (lane <= kBpeBlocks) { L.tk[lane] = 0ull; L.mark[lane] = 0ull; L.dead[lane] = 0ull; }
+      cur ^= 1;
+      __syncthreads();
+    }
+
+    // ---- E. order-preserving compaction of the valid positions into the tile's output run
+    if (dbg & 32) { if (last) break; cb = abase + ce; continue; }
+    uint32_t total = 0;
+    for (uint32_t blk = 0; blk < nblk; blk++) {
+      const uint32_t p = blk * 64 + lane;
+      const uint32_t sv = (p >= off0 && p < ce) ? L.sym[p] : kInvalidTok;
+      const unsigned long long m = __ballot(sv != kInvalidTok);
+      if (lane == 0) { L.vmask[blk] = m; L.blkpre[blk] = total; }
+      if (sv != kInvalidTok) tile_out[run + total + __popcll(m & lt)] = sv;
+      total += __popcll(m);
     }
     __syncthreads();
-
-    // ---- E, F
-    if (dbg & 32) { if (last) break; cb = abase + ce; continue; }
-    const uint32_t total = tile_compact(L, off0, ce, tile_out + run);
-    s_next += tile_record(L, sent_off, sent_local, s_next, s_hi, abase, ce, last, run, total);
+    // ---- F. tile-local token offset of every sentence starting in [cb, ce) (and == ce on the last chunk)
+    uint32_t mine = 0;
+    for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
+      const uint64_t rel = sent_off[s] - abase;
+      if (rel > ce || (rel == ce && !last)) break;
+      uint32_t e = total;
+      if (rel < ce && (rel >> 6) < nblk) e = L.blkpre[rel >> 6] + __popcll(L.vmask[rel >> 6] & ((1ull << (rel & 63)) - 1ull));
+      sent_local[s] = run + e;
+      mine++;
+    }
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    s_next += mine;
     run += total;
     if (last) break;
     cb = abase + ce;
+    __syncthreads();
   }
-  if (tid == 0) tile_tok[t] = run;
+  if (lane == 0) tile_tok[t] = run;
 }
 
 }  // namespace swt
@@ -374,7 +497,7 @@ __global__ __launch_bounds__(kThreads) void bpe_encode_kernel(
 using namespace swt;
 
 struct swt_bpe_table {
-  std::vector<BpeSlot> h_slots;  // built on the host at create; uploaded on first encode
+  std::vector<BpeSlot> h_slots;    // built on the host at create; uploaded on first encode
   std::vector<uint32_t> h_merged;  // merged symbol id by rank
   bool packed = false;             // slot value = rank << 16 | (merged - SWT_SYM_BASE)
   BpeSlot *d_slots = nullptr;
@@ -402,8 +525,8 @@ extern "C" {
 // diagnostics (not part of include/swt.h): resident workgroups per CU the runtime grants the encode kernel
 int swt_debug_occupancy(int which) {
   int n = -1;
-  hipError_t e = which ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<false>, kThreads, 0)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<true>, kThreads, 0);
+  hipError_t e = which ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<false>, 64, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<true>, 64, 0);
   return e == hipSuccess ? n : -(int)e;
 }
 
@@ -464,7 +587,7 @@ int swt_bpe_encode_dev(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes
   const uint8_t *d_cls = nullptr;
   if ((rc = device_class_table(&d_cls))) return rc;
   if (flags & SWT_BPE_RAW_WORDS) d_cls = nullptr;  // no classes: nothing splits, nothing is dropped
-  const uint64_t n_tiles = tile_count(n_bytes);
+  const uint64_t n_tiles = tile_count(n_bytes, kBpeTile);
   if (n_tiles > 0x7FFFFFFFull)
     return fail(SWT_ERR_UNSUPPORTED, "text too large for one call (%llu bytes)", (unsigned long long)n_bytes);
   if ((rc = t->ws.reserve(n_bytes, n_sent, n_tiles))) return rc;
@@ -473,14 +596,14 @@ int swt_bpe_encode_dev(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes
     SWT_HIP(hipMemsetAsync(d_n_tokens, 0, 8, st));
     return SWT_OK;
   }
-  launch_plan(d_sent_off, n_sent, n_tiles, t->ws.plan.as<uint64_t>(), st);
+  launch_plan(d_sent_off, n_sent, n_tiles, kBpeTile, t->ws.plan.as<uint64_t>(), st);
   prof_begin(st);
   if (t->packed)
-    hipLaunchKernelGGL(bpe_encode_kernel<true>, dim3((unsigned)n_tiles), dim3(kThreads), 0, st, d_text, n_bytes, d_sent_off,
+    hipLaunchKernelGGL(bpe_encode_kernel<true>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
                        t->ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, t->ws.scratch.as<uint32_t>(),
                        t->ws.sent_local.as<uint32_t>(), t->ws.tile_tok.as<uint32_t>(), (uint32_t)debug_knob(0));
   else
-    hipLaunchKernelGGL(bpe_encode_kernel<false>, dim3((unsigned)n_tiles), dim3(kThreads), 0, st, d_text, n_bytes, d_sent_off,
+    hipLaunchKernelGGL(bpe_encode_kernel<false>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
                        t->ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, t->ws.scratch.as<uint32_t>(),
                        t->ws.sent_local.as<uint32_t>(), t->ws.tile_tok.as<uint32_t>(), (uint32_t)debug_knob(0));
   prof_end(st);

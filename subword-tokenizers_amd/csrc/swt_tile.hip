@@ -3,13 +3,13 @@
 
 namespace swt {
 
-// plan[t] = first sentence whose first byte is >= t * kTile  (lower bound; plan[n_tiles] = n_sent)
-__global__ void plan_kernel(const uint64_t *__restrict__ sent_off, uint64_t n_sent, uint64_t n_tiles,
+// plan[t] = first sentence whose first byte is >= t * tile  (lower bound; plan[n_tiles] = n_sent)
+__global__ void plan_kernel(const uint64_t *__restrict__ sent_off, uint64_t n_sent, uint64_t n_tiles, uint32_t tile,
                             uint64_t *__restrict__ plan) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t > n_tiles) return;
   if (t == n_tiles) { plan[t] = n_sent; return; }
-  const uint64_t target = t * (uint64_t)kTile;
+  const uint64_t target = t * (uint64_t)tile;
   uint64_t lo = 0, hi = n_sent;
   while (lo < hi) {
     const uint64_t mid = (lo + hi) >> 1;
@@ -81,8 +81,8 @@ void TileWorkspace::release() {
   plan.release(); scratch.release(); sent_local.release(); tile_tok.release(); tile_base.release();
 }
 
-void launch_plan(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, uint64_t *d_plan, hipStream_t st) {
-  hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n_tiles + 1 + 255) / 256)), dim3(256), 0, st, d_sent_off, n_sent, n_tiles, d_plan);
+void launch_plan(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, uint32_t tile, uint64_t *d_plan, hipStream_t st) {
+  hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n_tiles + 1 + 255) / 256)), dim3(256), 0, st, d_sent_off, n_sent, n_tiles, tile, d_plan);
 }
 
 void launch_scan_gather(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, const TileWorkspace &ws,

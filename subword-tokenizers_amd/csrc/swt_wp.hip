@@ -522,7 +522,7 @@ int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, c
   T.corner_nonterm = t->H.corner_nonterm ? 1u : 0u;
   T.empty_status = t->H.child(t->H.root, ' ') >= 0 ? SWT_WP_INDEXERROR : SWT_WP_OK;
   T.corner_id = t->H.corner.size() == 1 ? t->H.corner[0] : t->H.n_vocab + 2;
-  launch_plan(d_sent_off, n_sent, n_tiles, t->ws.plan.as<uint64_t>(), st);
+  launch_plan(d_sent_off, n_sent, n_tiles, kTile, t->ws.plan.as<uint64_t>(), st);
   prof_begin(st);
   hipLaunchKernelGGL(wp_encode_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, st, d_text, n_bytes, d_sent_off,
                      t->ws.plan.as<uint64_t>(), d_cls, T, t->ws.scratch.as<uint32_t>(), t->ws.sent_local.as<uint32_t>(),

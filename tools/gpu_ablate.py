@@ -29,4 +29,6 @@ for name, k in [("full", 0), ("stage only", 1), ("no class table", 2), ("no firs
                 ("no word phase D", 16), ("no compaction/record", 32), ("no D, no lookups", 20), ("no D/lookups/cls", 22),
                 ("B only (no C-lookups, D, E)", 52)]:
     print("%-32s knob=%2d  %8.1f us" % (name, k, run(k)), flush=True)
+for r in (1, 2, 3, 4, 6, 8, 10, 12, 16, 24):
+    print("max rounds %2d   knob=%5d  %8.1f us" % (r, r << 8, run(r << 8)), flush=True)
 N.lib().swt_debug_knob(0, 0)
