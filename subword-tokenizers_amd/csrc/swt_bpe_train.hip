@@ -25,6 +25,7 @@
 namespace swt {
 
 constexpr int kTrainThreads = 256;
+constexpr int kArgBlocks = 512;
 
 struct TrainResult {
   unsigned long long max_count;
@@ -99,37 +100,72 @@ __global__ __launch_bounds__(kTrainThreads) void hist_build_kernel(const uint32_
   }
 }
 
-__global__ void result_reset_kernel(TrainResult *res) {
-  res->max_count = 0;
-  res->n_tied = 0;
-  res->best_pos = kEmptyKey;
-  res->best_key = kEmptyKey;
-  res->win_key = kEmptyKey;
+struct ArgPart {
+  unsigned long long mx, cnt, key;
+};
+
+__device__ __forceinline__ void arg_combine(unsigned long long &m, unsigned long long &c, unsigned long long &k,
+                                            unsigned long long m2, unsigned long long c2, unsigned long long k2) {
+  if (m2 > m) { m = m2; c = c2; k = k2; }
+  else if (m2 == m) { c += c2; k = k2 < k ? k2 : k; }
 }
 
-__global__ __launch_bounds__(256) void argmax_max_kernel(const long long *__restrict__ cnt, uint64_t cap, TrainResult *res) {
-  long long m = 0;
+// bpe.py:98-102 in one launch: maximum count, how many pairs hold it, and the smallest such key.  Every workgroup
+// reduces its share of the table and publishes a partial; the last one to arrive (ticket) combines the partials
+// and resets the tie-break fields of the result.
+__global__ __launch_bounds__(256) void argmax_kernel(const unsigned long long *__restrict__ keys, const long long *__restrict__ cnt,
+                                                     uint64_t cap, ArgPart *__restrict__ parts, unsigned int *__restrict__ ticket,
+                                                     TrainResult *res) {
+  __shared__ unsigned long long sm[4], sc[4], sk[4];
+  __shared__ bool is_last;
+  unsigned long long m = 0, c = 0, k = kEmptyKey;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
-    const long long c = cnt[i];
-    m = c > m ? c : m;
+    const long long v = cnt[i];
+    if (v > 0 && (unsigned long long)v >= m) {
+      const unsigned long long key = keys[i];
+      if (key != kEmptyKey) arg_combine(m, c, k, (unsigned long long)v, 1ull, key);
+    }
   }
   for (int d = 32; d >= 1; d >>= 1) {
-    const long long o = __shfl_xor(m, d);
-    m = o > m ? o : m;
+    const unsigned long long m2 = __shfl_xor(m, d), c2 = __shfl_xor(c, d), k2 = __shfl_xor(k, d);
+    arg_combine(m, c, k, m2, c2, k2);
   }
-  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&res->max_count, (unsigned long long)m);
-}
-
-// census of the slots that hold the maximum; best_key = the smallest such key (deterministic)
-__global__ __launch_bounds__(256) void argmax_tie_kernel(const unsigned long long *__restrict__ keys, const long long *__restrict__ cnt,
-                                                         uint64_t cap, TrainResult *res) {
-  const unsigned long long mx = res->max_count;
-  if (mx == 0) return;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
-    if ((unsigned long long)cnt[i] == mx && keys[i] != kEmptyKey) {
-      atomicAdd(&res->n_tied, 1ull);
-      atomicMin(&res->best_key, keys[i]);
-    }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sm[wave] = m; sc[wave] = c; sk[wave] = k; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) arg_combine(m, c, k, sm[w], sc[w], sk[w]);
+    parts[blockIdx.x].mx = m;
+    parts[blockIdx.x].cnt = c;
+    parts[blockIdx.x].key = k;
+    __threadfence();  // agent-scope release before the ticket
+    is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();  // agent-scope acquire
+  m = 0; c = 0; k = kEmptyKey;
+  for (uint32_t j = threadIdx.x; j < gridDim.x; j += blockDim.x) {
+    const unsigned long long m2 = __hip_atomic_load(&parts[j].mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long c2 = __hip_atomic_load(&parts[j].cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long k2 = __hip_atomic_load(&parts[j].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (m2 > 0) arg_combine(m, c, k, m2, c2, k2);
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long m2 = __shfl_xor(m, d), c2 = __shfl_xor(c, d), k2 = __shfl_xor(k, d);
+    arg_combine(m, c, k, m2, c2, k2);
+  }
+  __syncthreads();
+  if (lane == 0) { sm[wave] = m; sc[wave] = c; sk[wave] = k; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) arg_combine(m, c, k, sm[w], sc[w], sk[w]);
+    res->max_count = m;
+    res->n_tied = m ? c : 0;
+    res->best_key = k;
+    res->best_pos = kEmptyKey;
+    res->win_key = kEmptyKey;
+    *ticket = 0;
   }
 }
 
@@ -261,6 +297,7 @@ struct swt_bpe_trainer {
   uint32_t *d_freq = nullptr;
   PairTable T{nullptr, nullptr, 0};
   TrainResult *d_res = nullptr;
+  ArgPart *d_parts = nullptr;     // per-workgroup argmax partials + the ticket behind them
   TrainResult h_res{};
   uint64_t pos_base = 0;
   bool hist_ready = false;
@@ -352,6 +389,8 @@ static int trainer_upload(swt_bpe_trainer *t, const uint32_t *syms, const uint64
   SWT_HIP(hipMalloc((void **)&t->d_freq, (n_words + 1) * 4));
   SWT_HIP(hipMalloc((void **)&t->d_res, sizeof(TrainResult)));
   SWT_HIP(hipMemset(t->d_res, 0, sizeof(TrainResult)));
+  SWT_HIP(hipMalloc((void **)&t->d_parts, (kArgBlocks + 1) * sizeof(ArgPart)));
+  SWT_HIP(hipMemset(t->d_parts, 0, (kArgBlocks + 1) * sizeof(ArgPart)));
   if (n_syms) SWT_HIP(hipMemcpy(t->d_sym, syms, n_syms * 4, hipMemcpyHostToDevice));
   SWT_HIP(hipMemcpy(t->d_woff, word_off, (n_words + 1) * 8, hipMemcpyHostToDevice));
   if (n_words) {
@@ -432,7 +471,7 @@ int swt_bpe_train_create_text(const uint8_t *text, const uint64_t *sent_off, uin
 
 void swt_bpe_train_destroy(swt_bpe_trainer *t) {
   if (!t) return;
-  for (void *p : {(void *)t->d_sym, (void *)t->d_woff, (void *)t->d_wlen, (void *)t->d_freq, (void *)t->d_res,
+  for (void *p : {(void *)t->d_sym, (void *)t->d_woff, (void *)t->d_wlen, (void *)t->d_freq, (void *)t->d_res, (void *)t->d_parts,
                   (void *)t->d_log_keys, (void *)t->d_log_vals})
     if (p) (void)hipFree(p);
   table_free(t->T);
@@ -470,16 +509,17 @@ int swt_bpe_train_best(swt_bpe_trainer *t, uint32_t *left, uint32_t *right, uint
   int rc = ensure_device();
   if (rc) return rc;
   const uint64_t cap = 1ull << t->T.bits;
-  const unsigned g = grid_for(cap, 256 * 4, 2048);
-  hipLaunchKernelGGL(result_reset_kernel, dim3(1), dim3(1), 0, 0, t->d_res);
-  hipLaunchKernelGGL(argmax_max_kernel, dim3(g), dim3(256), 0, 0, t->T.cnt, cap, t->d_res);
-  hipLaunchKernelGGL(argmax_tie_kernel, dim3(g), dim3(256), 0, 0, t->T.keys, t->T.cnt, cap, t->d_res);
-  if (t->n_words) {
+  const unsigned g = grid_for(cap, 256 * 8, kArgBlocks);
+  unsigned int *ticket = reinterpret_cast<unsigned int *>(t->d_parts + kArgBlocks);
+  hipLaunchKernelGGL(argmax_kernel, dim3(g), dim3(256), 0, 0, t->T.keys, t->T.cnt, cap, t->d_parts, ticket, t->d_res);
+  if ((rc = sync_result(t))) return rc;
+  if (t->h_res.n_tied >= 2 && t->n_words) {
+    // bpe.py:102: only a tied maximum needs the scan for the earliest (word, position)
     hipLaunchKernelGGL(first_pos_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff,
                        t->d_wlen, t->n_words, t->T, t->d_res);
     hipLaunchKernelGGL(winner_kernel, dim3(1), dim3(1), 0, 0, t->d_sym, t->d_res);
+    if ((rc = sync_result(t))) return rc;
   }
-  if ((rc = sync_result(t))) return rc;
   const TrainResult &r = t->h_res;
   *count = r.max_count;
   if (n_tied) *n_tied = r.n_tied;

@@ -117,7 +117,7 @@ __device__ __forceinline__ uint32_t tile_record(TileLds &L, const uint64_t *__re
 
 // Per-call workspaces shared by both encoders (grow-only).
 struct TileWorkspace {
-  DevBuf plan, scratch, sent_local, tile_tok, tile_base;
+  DevBuf plan, scratch, sent_local, tile_tok, tile_base, blk;
   int reserve(uint64_t n_bytes, uint64_t n_sent, uint64_t n_tiles);
   void release();
 };

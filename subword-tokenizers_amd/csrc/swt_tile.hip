@@ -18,35 +18,59 @@ __global__ void plan_kernel(const uint64_t *__restrict__ sent_off, uint64_t n_se
   plan[t] = lo;
 }
 
-// Exclusive scan of the tile totals (one workgroup; n_tiles is small next to the text).
+// Exclusive scan of the tile totals, one launch: every workgroup scans its 1024 tiles locally and publishes its total;
+// the last one to arrive (ticket) scans the workgroup totals.  Global base of tile t = blk_base[t >> 10] + tile_base[t].
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t *__restrict__ tile_tok, uint64_t n_tiles,
-                                                         uint64_t *__restrict__ tile_base, uint64_t *__restrict__ n_tokens) {
+                                                         uint32_t *__restrict__ tile_base, unsigned long long *__restrict__ blk_tot,
+                                                         unsigned long long *__restrict__ blk_base, unsigned int *__restrict__ ticket,
+                                                         uint64_t *__restrict__ n_tokens) {
   __shared__ unsigned long long wsum[16];
   __shared__ unsigned long long carry_s;
+  __shared__ bool is_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t i = (uint64_t)blockIdx.x * 1024 + tid;
+  const unsigned long long v = i < n_tiles ? tile_tok[i] : 0;
+  unsigned long long x = v;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long y = __shfl_up(x, d);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  unsigned long long wb = 0;
+  for (int w = 0; w < wave; w++) wb += wsum[w];
+  if (i < n_tiles) tile_base[i] = (uint32_t)(wb + x - v);
+  if (tid == 1023) {
+    blk_tot[blockIdx.x] = wb + x;
+    __threadfence();  // agent-scope release of blk_tot before the ticket
+    is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();  // agent-scope acquire: every other workgroup's total is visible
   if (tid == 0) carry_s = 0;
   __syncthreads();
-  for (uint64_t base = 0; base < n_tiles; base += 1024) {
-    const uint64_t i = base + tid;
-    const unsigned long long v = i < n_tiles ? tile_tok[i] : 0;
-    unsigned long long x = v;
+  for (uint32_t base = 0; base < gridDim.x; base += 1024) {
+    const uint32_t j = base + tid;
+    const unsigned long long u = j < gridDim.x ? __hip_atomic_load(&blk_tot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    unsigned long long z = u;
     for (int d = 1; d < 64; d <<= 1) {
-      const unsigned long long y = __shfl_up(x, d);
-      if (lane >= d) x += y;
+      const unsigned long long y = __shfl_up(z, d);
+      if (lane >= d) z += y;
     }
-    if (lane == 63) wsum[wave] = x;
+    if (lane == 63) wsum[wave] = z;
     __syncthreads();
-    unsigned long long wb = 0;
-    for (int w = 0; w < wave; w++) wb += wsum[w];
+    unsigned long long wb2 = 0;
+    for (int w = 0; w < wave; w++) wb2 += wsum[w];
     const unsigned long long carry = carry_s;
-    if (i < n_tiles) tile_base[i] = carry + wb + x - v;
+    if (j < gridDim.x) blk_base[j] = carry + wb2 + z - u;
     __syncthreads();
-    if (tid == 1023) carry_s = carry + wb + x;
+    if (tid == 1023) carry_s = carry + wb2 + z;
     __syncthreads();
   }
   if (tid == 0) {
-    tile_base[n_tiles] = carry_s;
     *n_tokens = carry_s;
+    *ticket = 0;  // ready for the next call
   }
 }
 
@@ -54,13 +78,14 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t *__restr
 __global__ __launch_bounds__(kThreads) void gather_kernel(const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
                                                           uint64_t n_tiles, uint64_t n_sent, const uint32_t *__restrict__ scratch,
                                                           const uint32_t *__restrict__ sent_local, const uint32_t *__restrict__ tile_tok,
-                                                          const uint64_t *__restrict__ tile_base, uint32_t *__restrict__ out_ids,
+                                                          const uint32_t *__restrict__ tile_base, const unsigned long long *__restrict__ blk_base,
+                                                          const uint64_t *__restrict__ n_tokens, uint32_t *__restrict__ out_ids,
                                                           uint64_t *__restrict__ out_off) {
   const uint64_t t = blockIdx.x;
   const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
-  if (t == n_tiles - 1 && threadIdx.x == 0) out_off[n_sent] = tile_base[n_tiles];
+  if (t == n_tiles - 1 && threadIdx.x == 0) out_off[n_sent] = *n_tokens;
   if (s_lo == s_hi) return;
-  const uint64_t base = tile_base[t];
+  const uint64_t base = blk_base[t >> 10] + tile_base[t];
   const uint32_t n = tile_tok[t];
   const uint32_t *src = scratch + sent_off[s_lo];
   for (uint32_t i = threadIdx.x; i < n; i += kThreads) out_ids[base + i] = src[i];
@@ -73,12 +98,16 @@ int TileWorkspace::reserve(uint64_t n_bytes, uint64_t n_sent, uint64_t n_tiles) 
   if ((rc = scratch.reserve((n_bytes + 64) * 4))) return rc;
   if ((rc = sent_local.reserve((n_sent + 1) * 4))) return rc;
   if ((rc = tile_tok.reserve((n_tiles + 1) * 4))) return rc;
-  if ((rc = tile_base.reserve((n_tiles + 2) * 8))) return rc;
+  if ((rc = tile_base.reserve((n_tiles + 2) * 4))) return rc;
+  const uint64_t nb = (n_tiles + 1023) / 1024;
+  const bool fresh = blk.p == nullptr;
+  if ((rc = blk.reserve((2 * nb + 4) * 8))) return rc;
+  if (fresh) SWT_HIP(hipMemset(blk.p, 0, 8));  // the ticket (reset by the scan kernel itself afterwards)
   return SWT_OK;
 }
 
 void TileWorkspace::release() {
-  plan.release(); scratch.release(); sent_local.release(); tile_tok.release(); tile_base.release();
+  plan.release(); scratch.release(); sent_local.release(); tile_tok.release(); tile_base.release(); blk.release();
 }
 
 void launch_plan(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, uint32_t tile, uint64_t *d_plan, hipStream_t st) {
@@ -87,11 +116,16 @@ void launch_plan(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, 
 
 void launch_scan_gather(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, const TileWorkspace &ws,
                         uint32_t *d_out_ids, uint64_t *d_out_off, uint64_t *d_n_tokens, hipStream_t st) {
-  hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, ws.tile_tok.as<uint32_t>(), n_tiles,
-                     ws.tile_base.as<uint64_t>(), d_n_tokens);
+  const uint64_t nb = (n_tiles + 1023) / 1024;
+  // blk layout: [0] ticket (8 bytes), then blk_tot[nb], then blk_base[nb]
+  unsigned long long *b = ws.blk.as<unsigned long long>();
+  unsigned int *ticket = reinterpret_cast<unsigned int *>(b);
+  unsigned long long *blk_tot = b + 1, *blk_base = b + 1 + nb;
+  hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)nb), dim3(1024), 0, st, ws.tile_tok.as<uint32_t>(), n_tiles,
+                     ws.tile_base.as<uint32_t>(), blk_tot, blk_base, ticket, d_n_tokens);
   hipLaunchKernelGGL(gather_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, st, d_sent_off, ws.plan.as<uint64_t>(), n_tiles,
                      n_sent, ws.scratch.as<uint32_t>(), ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(),
-                     ws.tile_base.as<uint64_t>(), d_out_ids, d_out_off);
+                     ws.tile_base.as<uint32_t>(), blk_base, d_n_tokens, d_out_ids, d_out_off);
 }
 
 }  // namespace swt

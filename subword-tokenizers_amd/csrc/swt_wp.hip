@@ -27,7 +27,7 @@ struct alignas(16) WpNode {
 constexpr uint32_t kWpRoot = 0, kWpRootP = 1;
 constexpr uint32_t kNodeBits = 21, kMaxNodes = (1u << kNodeBits) - 2;
 constexpr uint64_t kEdgeEmpty = ~0ull;
-constexpr uint8_t kPySpace = 1, kPyAlnum = 2, kWpCont = 0x80;
+constexpr uint8_t kPySpace = 1, kPyAlnum = 2;
 
 __host__ __device__ inline uint64_t edge_key(uint32_t node, uint32_t cp) { return ((uint64_t)node << 21) | cp; }
 
@@ -55,110 +55,154 @@ __device__ __forceinline__ int32_t edge_lookup(const WpDev &T, uint32_t node, ui
   }
 }
 
-// Character sources for the sentence walker: LDS-staged chunk, or global memory (sentences longer than a chunk).
-struct LdsSrc {
-  const TileLds *L;
-  __device__ __forceinline__ void load(uint64_t p, uint64_t e, uint32_t &cp, uint32_t &cc, uint32_t &len) const {
-    cp = L->sym[p];
-    cc = L->cls[p];
-    uint32_t q = (uint32_t)p + 1;
-    while (q < e && (L->cls[q] & kWpCont)) q++;
-    len = q - (uint32_t)p;
-  }
-};
-struct GlobalSrc {
-  const uint8_t *text;
+// Character source of the walkers: UTF-8 bytes (LDS-staged chunk or global memory), decoded on the fly; classes of
+// U+0000..U+03FF from the LDS copy when there is one.  [b, e) is the sentence; positions are byte offsets.
+struct TxtSrc {
+  const uint8_t *txt;
+  const uint8_t *cls_lo;   // may be null
   const uint8_t *cls_tab;
   __device__ __forceinline__ void load(uint64_t p, uint64_t e, uint32_t &cp, uint32_t &cc, uint32_t &len) const {
-    const uint8_t b = text[p];
+    const uint8_t b = txt[p];
     int n = utf8_len(b);
     if (p + n > e) n = (int)(e - p);
     cp = b;
     if (b >= 0x80 && n > 1) {
       cp = b & (0xFF >> (n + 1));
-      for (int i = 1; i < n; i++) cp = (cp << 6) | (text[p + i] & 0x3F);
+      for (int i = 1; i < n; i++) cp = (cp << 6) | (txt[p + i] & 0x3F);
     }
-    const uint8_t c = cp < kNumCodePoints ? cls_tab[cp] : (uint8_t)0;
+    const uint8_t c = (cls_lo && cp < 1024u) ? cls_lo[cp] : (cp < kNumCodePoints ? cls_tab[cp] : (uint8_t)0);
     cc = (c >> 2) & 3;
     uint64_t q = p + n;
-    while (q < e && utf8_is_cont(text[q])) q++;  // stray continuation bytes ride with the previous char
+    while (q < e && utf8_is_cont(txt[q])) q++;  // stray continuation bytes ride with the previous char
     len = (uint32_t)(q - p);
   }
 };
 
-// FastWP.tokenize on one sentence occupying bytes [b, e); `out` receives the ids (out[k] for the k-th).
-// Returns the token count (0 when status != OK).  wordpiece.py:248-270 with s = text + " ".
-template <class Src, class Out>
-__device__ __forceinline__ uint32_t wp_sentence(const Src &src, uint64_t b, uint64_t e, Out out, const WpDev &T, int &status) {
-  uint64_t i = b;  // i == e: the appended space (wordpiece.py:248); i > e: i == len(s)
-  uint32_t cp = ' ', cc = kPySpace, len = 1;
-  if (i < e) src.load(i, e, cp, cc, len);
-  bool prev_punc = false;  // ispunc(s[i-1]) -- never across a sentence start
-  uint32_t nt = 0;
-  status = SWT_WP_OK;
-#define WP_ADV()                                   \
-  do {                                             \
-    prev_punc = (cc & (kPySpace | kPyAlnum)) == 0; \
-    if (i < e) { i += len; if (i > e) i = e; }     \
-    else i = e + 1;                                \
-    if (i < e) src.load(i, e, cp, cc, len);        \
-    else { cp = ' '; cc = kPySpace; len = 1; }     \
-  } while (0)
-#define WP_BNDRY() (prev_punc || (cc & kPySpace) || (cc & (kPySpace | kPyAlnum)) == 0) /* wordpiece.py:285 */
-  while (i <= e) {  // wordpiece.py:251
+// State of a walk through one sentence occupying bytes [b, e): i == e is the appended space (wordpiece.py:248),
+// i == e + 1 is len(s).
+template <class Src>
+struct WpWalk {
+  const Src &src;
+  const WpDev &T;
+  uint64_t e, i;
+  uint32_t cp, cc, len;
+  bool prev_punc;  // ispunc(s[i-1]); never across a sentence start
+  __device__ __forceinline__ WpWalk(const Src &s, const WpDev &t, uint64_t start, uint64_t end, bool pp)
+      : src(s), T(t), e(end), i(start), cp(' '), cc(kPySpace), len(1), prev_punc(pp) {
+    if (i < e) src.load(i, e, cp, cc, len);
+  }
+  __device__ __forceinline__ void adv() {
+    prev_punc = (cc & (kPySpace | kPyAlnum)) == 0;
+    if (i < e) { i += len; if (i > e) i = e; }
+    else i = e + 1;
+    if (i < e) src.load(i, e, cp, cc, len);
+    else { cp = ' '; cc = kPySpace; len = 1; }
+  }
+  __device__ __forceinline__ bool bndry() const {  // wordpiece.py:285
+    return prev_punc || (cc & kPySpace) || (cc & (kPySpace | kPyAlnum)) == 0;
+  }
+  // One iteration of the loop at wordpiece.py:251-269: match a segment from i, emit its tokens to out[0..) (at most
+  // `room` are stored), move i to the start of the next segment.  Returns the token count; status != OK aborts.
+  template <class Out>
+  __device__ __forceinline__ uint32_t segment(Out out, uint32_t room, int &status) {
     const uint64_t seg_i = i;
-    const uint32_t seg_nt = nt;
+    uint32_t nt = 0;
     uint32_t node = kWpRoot;
-    // matchloop, wordpiece.py:291-316
     bool stop = false;
-    while (i <= e) {
+    while (i <= e) {  // matchloop, wordpiece.py:291-316
       int32_t child = edge_lookup(T, node, cp);
       while (child < 0) {
         const WpNode nd = T.nodes[node];
         if (nd.link < 0) { stop = true; break; }
-        for (uint32_t k = 0; k < nd.pop_cnt; k++) out[nt++] = T.pops[nd.pop_off + k];
+        for (uint32_t k = 0; k < nd.pop_cnt; k++) {
+          if (nt < room) out[nt] = T.pops[nd.pop_off + k];
+          nt++;
+        }
         node = (uint32_t)nd.link;
         child = edge_lookup(T, node, cp);
       }
       if (stop) break;
       node = (uint32_t)child;
-      WP_ADV();
+      adv();
     }
     if (i > e) { status = SWT_WP_INDEXERROR; return 0; }  // iswdbndry indexes seq[len(seq)] (wordpiece.py:285)
     const bool root_like = node == kWpRoot || node == T.root_sharp || node == kWpRootP;
-    if (!WP_BNDRY() || !root_like) {  // wordpiece.py:255-257
-      nt = seg_nt;
-      out[nt++] = T.unk_id;
-    } else if (node == T.root_sharp && nt == seg_nt) {  // wordpiece.py:260-261
+    if (!bndry() || !root_like) {  // wordpiece.py:255-257: the segment's tokens are replaced by the one literal
+      for (uint32_t k = 1; k < nt && k < room; k++) out[k] = kInvalidTok;
+      if (room) out[0] = T.unk_id;
+      nt = 1;
+    } else if (node == T.root_sharp && nt == 0) {  // wordpiece.py:260-261
       if (T.corner_nonterm) { status = SWT_WP_NONTERMINATING; return 0; }
-      out[nt++] = T.corner_id;
+      if (room) out[0] = T.corner_id;
+      nt = 1;
     }
-    while (i <= e && !WP_BNDRY()) WP_ADV();        // wordpiece.py:265-266
-    while (i <= e && (cc & kPySpace)) WP_ADV();    // wordpiece.py:268-269
+    while (i <= e && !bndry()) adv();          // wordpiece.py:265-266
+    while (i <= e && (cc & kPySpace)) adv();   // wordpiece.py:268-269
     if (i == seg_i) { status = SWT_WP_NONTERMINATING; return 0; }  // same state again: the reference spins
+    return nt;
   }
-#undef WP_ADV
-#undef WP_BNDRY
+};
+
+// FastWP.tokenize on one whole sentence, segment after segment (the sequential form: sentences the parallel form
+// cannot certify, and sentences longer than a chunk).  out[k] receives the k-th id.  Returns the token count
+// (0 when status != OK).  wordpiece.py:248-270.
+template <class Src, class Out>
+__device__ uint32_t wp_sentence(const Src &src, uint64_t b, uint64_t e, Out out, const WpDev &T, int &status) {
+  WpWalk<Src> w(src, T, b, e, false);
+  uint32_t nt = 0;
+  status = SWT_WP_OK;
+  while (w.i <= e) {  // wordpiece.py:251
+    nt += w.segment(out + nt, 0xFFFFFFFFu, status);
+    if (status != SWT_WP_OK) return 0;
+  }
   return nt;
 }
 
-struct WpGiant { uint64_t end; uint32_t ntok; };
+constexpr int kWpTile = 512;    // bytes of sentence starts per tile
+constexpr int kWpCap = 1024;    // staged bytes per chunk
+constexpr int kWpBlocks = kWpCap / 64;
+constexpr int kWpClsLds = 1024;
 
-__global__ __launch_bounds__(kThreads) void wp_encode_kernel(
+struct WpGiant { uint64_t end; uint32_t ntok; uint32_t nsent; };
+
+struct WpLds {
+  __attribute__((aligned(16))) uint8_t txt[kWpCap + 16];
+  uint32_t tok[kWpCap];                      // per byte position: a token id or kInvalidTok
+  uint16_t cand[kWpCap];                     // segment-start candidates, in position order
+  unsigned long long sbits[kWpBlocks + 1];   // sentence-start bit per byte
+  unsigned long long ppunc[kWpBlocks + 1];   // the char before this byte (same sentence) is punctuation-class
+  unsigned long long irr[kWpBlocks + 1];     // per sentence-start position: needs the sequential walk
+  unsigned long long vmask[kWpBlocks + 1];
+  uint32_t blkpre[kWpBlocks + 1];
+  __attribute__((aligned(16))) uint8_t cls_lo[kWpClsLds];
+  WpGiant giant;
+};
+
+__device__ __forceinline__ bool wbit(const unsigned long long *m, uint32_t p) { return (m[p >> 6] >> (p & 63)) & 1ull; }
+
+// One 64-lane wavefront per tile (workgroup = one wave).  Segments of a sentence depend on each other only through
+// where the previous one ended (wordpiece.py:265-269), and that is almost always the next static boundary.  So:
+//   B  64 bytes per step: classes (str.isspace / str.isalnum) -> ballot masks -> the positions where a segment CAN
+//      start (sentence start; a non-space char after a space; either side of a punctuation-class char)
+//   C  one lane per candidate walks the trie from there (matchloop + validity + skip), writing its tokens into its own
+//      territory [candidate, next candidate); it certifies itself when it ended exactly at the next candidate
+//   D  a sentence with an uncertified candidate (a vocabulary entry spanning a boundary, a non-terminating or raising
+//      input) is redone by one lane with the sequential walker -- exactness never rests on the speculation
+//   E/F  ballot compaction to the tile's output run, per-sentence offsets and statuses
+__global__ __launch_bounds__(64) void wp_encode_kernel(
     const uint8_t *__restrict__ text, uint64_t n_bytes, const uint64_t *__restrict__ sent_off,
     const uint64_t *__restrict__ plan, const uint8_t *__restrict__ cls_tab, WpDev T, uint32_t *__restrict__ scratch,
     uint32_t *__restrict__ sent_local, uint32_t *__restrict__ tile_tok, uint8_t *__restrict__ status) {
-  __shared__ TileLds L;
-  __shared__ WpGiant s_giant;
-  __shared__ uint32_t s_nsent;
-
-  const int tid = threadIdx.x;
+  __shared__ WpLds L;
+  const int lane = threadIdx.x;
+  const unsigned long long lt = (1ull << lane) - 1ull;
   const uint64_t t = blockIdx.x;
   const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
   if (s_lo == s_hi) {
-    if (tid == 0) tile_tok[t] = 0;
+    if (lane == 0) tile_tok[t] = 0;
     return;
   }
+  reinterpret_cast<uint4 *>(L.cls_lo)[lane] = reinterpret_cast<const uint4 *>(cls_tab)[lane];
   const uint64_t span_base = sent_off[s_lo], span_end = sent_off[s_hi];
   uint32_t *const tile_out = scratch + span_base;
   uint32_t run = 0;
@@ -169,100 +213,192 @@ __global__ __launch_bounds__(kThreads) void wp_encode_kernel(
     const uint64_t abase = cb & ~15ull;
     const uint32_t off0 = (uint32_t)(cb - abase);
     const uint64_t avail = span_end - abase;
-    const bool last = avail <= (uint64_t)kCap;
-    const uint32_t staged = last ? (uint32_t)avail : (uint32_t)kCap;
+    const bool last = avail <= (uint64_t)kWpCap;
+    const uint32_t staged = last ? (uint32_t)avail : (uint32_t)kWpCap;
+    const uint32_t nblk = (staged + 63) >> 6;
 
-    tile_stage(L, text, n_bytes, abase, staged);
-    if (tid == 0) s_nsent = 0;
-
-    // ---- B. per byte: code point + str.isspace / str.isalnum bits at every lead byte
-    for (uint32_t p = tid; p < staged; p += kThreads) {
-      const uint8_t b = L.txt[p];
-      uint32_t sv = kInvalidTok;
-      uint8_t cv = kWpCont;
-      if (!utf8_is_cont(b) && p >= off0) {
-        int len = utf8_len(b);
-        if (p + len > staged) len = (int)(staged - p);
-        uint32_t cp = b;
-        if (b >= 0x80 && len > 1) {
-          cp = b & (0xFF >> (len + 1));
-          for (int i = 1; i < len; i++) cp = (cp << 6) | (L.txt[p + i] & 0x3F);
-        }
-        const uint8_t c = cp < kNumCodePoints ? cls_tab[cp] : (uint8_t)0;
-        cv = (c >> 2) & 3;
-        sv = cp;
+    // ---- A. stage
+    for (uint32_t c = lane * 16; c < staged; c += 64 * 16) {
+      const uint64_t g = abase + c;
+      if (g + 16 <= n_bytes && ((reinterpret_cast<uintptr_t>(text + g) & 15) == 0)) {
+        *reinterpret_cast<uint4 *>(&L.txt[c]) = *reinterpret_cast<const uint4 *>(text + g);
+      } else {
+        for (int i = 0; i < 16; i++) L.txt[c + i] = (g + i < n_bytes) ? text[g + i] : (uint8_t)' ';
       }
-      L.sym[p] = sv;
-      L.cls[p] = cv;
     }
-    // chunk end: whole sentences only -- the last sentence start that fits (or the end of the span)
-    uint32_t ce = staged;
-    if (!last) {
-      int best = -1;
-      for (uint64_t s = s_next + tid; s < s_hi; s += kThreads) {
-        const uint64_t o = sent_off[s];
-        if (o > abase + staged) break;
-        if (o > cb) best = (int)(o - abase);
-      }
-      if (best >= 0) atomicMax(&L.cut, best);
+    if (lane <= kWpBlocks) { L.sbits[lane] = 0ull; L.irr[lane] = 0ull; }
+    __syncthreads();
+    // sentence starts inside the staged bytes; the chunk ends at the last one that leaves its predecessor whole
+    int cut = -1;
+    uint32_t n_in = 0;  // sentences starting in [cb, abase + staged)
+    for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
+      const uint64_t o = sent_off[s];
+      if (o >= abase + staged) break;
+      atomicOr(&L.sbits[(o - abase) >> 6], 1ull << ((o - abase) & 63));
+      if (o > cb) cut = (int)(o - abase);
+      n_in++;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+      cut = max(cut, __shfl_xor(cut, d));
+      n_in += __shfl_xor(n_in, d);
     }
     __syncthreads();
+
+    uint32_t ce = staged;
     if (!last) {
-      if (L.cut < 0) {
+      // does a sentence start exactly at the end of the staged bytes?  then everything staged is whole
+      uint64_t s_after = s_next + n_in;
+      const bool whole = s_after < s_hi && sent_off[s_after] == abase + staged;
+      if (whole) ce = staged;
+      else if (cut >= 0) ce = (uint32_t)cut;
+      else {
         // one sentence longer than the LDS chunk: one lane walks it in global memory
-        if (tid == 0) {
+        if (lane == 0) {
           uint64_t s = s_next;
           while (s + 1 < s_hi && sent_off[s + 1] <= cb) s++;  // the last sentence that starts at cb
           int stt;
-          GlobalSrc src{text, cls_tab};
+          TxtSrc src{text, nullptr, cls_tab};
           const uint64_t e = sent_off[s + 1];
           const uint32_t n = wp_sentence(src, cb, e, tile_out + run, T, stt);
           // empty sentences that also start at cb come first and get no tokens
           for (uint64_t z = s_next; z <= s; z++) { sent_local[z] = run; status[z] = (uint8_t)T.empty_status; }
           status[s] = (uint8_t)stt;
-          s_giant.end = e;
-          s_giant.ntok = n;
-          s_nsent = (uint32_t)(s - s_next + 1);
+          L.giant.end = e;
+          L.giant.ntok = n;
+          L.giant.nsent = (uint32_t)(s - s_next + 1);
         }
         __syncthreads();
-        s_next += s_nsent;
-        run += s_giant.ntok;
-        cb = s_giant.end;
+        s_next += L.giant.nsent;
+        run += L.giant.ntok;
+        cb = L.giant.end;
         __syncthreads();
         if (cb >= span_end) {
           // trailing empty sentences at the very end of the span
-          for (uint64_t z = s_next + tid; z < s_hi; z += kThreads) { sent_local[z] = run; status[z] = (uint8_t)T.empty_status; }
+          for (uint64_t z = s_next + lane; z < s_hi; z += 64) { sent_local[z] = run; status[z] = (uint8_t)T.empty_status; }
           break;
         }
         continue;
       }
-      ce = (uint32_t)L.cut;
     }
 
-    // ---- D (v1). one lane per sentence: the reference's state machine over the staged chunk; tokens
-    // overwrite the sentence's own bytes in sym[] (a sentence never yields more tokens than bytes)
-    for (uint64_t s = s_next + tid; s < s_hi; s += kThreads) {
+    // ---- B. classes -> masks -> candidates
+    uint32_t nc = 0;
+    bool prev_sp = true, prev_pu = false;  // class of the char owning the byte before this block
+    for (uint32_t blk = 0; blk < nblk; blk++) {
+      const uint32_t p = blk * 64 + lane;
+      const bool inr = p >= off0 && p < ce;
+      const uint8_t b = inr ? L.txt[p] : (uint8_t)' ';
+      const bool lead = !utf8_is_cont(b);
+      uint32_t cp = b;
+      if (b >= 0xC0) {
+        int len = utf8_len(b);
+        if (p + len > ce) len = (int)(ce - p);
+        if (len > 1) {
+          cp = b & (0xFF >> (len + 1));
+          for (int i = 1; i < len; i++) cp = (cp << 6) | (L.txt[p + i] & 0x3F);
+        }
+      }
+      uint8_t c = SWT_CLS_PY_SPACE;  // bytes outside the chunk behave as spaces
+      if (inr && lead) c = cp < (uint32_t)kWpClsLds ? L.cls_lo[cp] : (cp < kNumCodePoints ? cls_tab[cp] : (uint8_t)0);
+      const unsigned long long INR = __ballot(inr);
+      const unsigned long long LEAD = __ballot(lead);
+      const unsigned long long SPm = __ballot(lead && (c & SWT_CLS_PY_SPACE));
+      const unsigned long long ANm = __ballot(lead && (c & SWT_CLS_PY_ALNUM));
+      const unsigned long long PUm = LEAD & ~SPm & ~ANm;
+      const unsigned long long CONT = ~LEAD;
+      unsigned long long SPb = SPm | ((prev_sp && (CONT & 1ull)) ? 1ull : 0ull);
+      unsigned long long PUb = PUm | ((prev_pu && (CONT & 1ull)) ? 1ull : 0ull);
+      SPb |= (SPb << 1) & CONT; SPb |= (SPb << 1) & CONT; SPb |= (SPb << 1) & CONT;
+      PUb |= (PUb << 1) & CONT; PUb |= (PUb << 1) & CONT; PUb |= (PUb << 1) & CONT;
+      const unsigned long long SS = L.sbits[blk] & INR;
+      const unsigned long long before_sp = ((SPb << 1) | (prev_sp ? 1ull : 0ull)) & ~SS;  // no context across a sentence start
+      const unsigned long long before_pu = ((PUb << 1) | (prev_pu ? 1ull : 0ull)) & ~SS;
+      const unsigned long long CAND = INR & (SS | (LEAD & ~SPm & (before_sp | before_pu | PUm)));
+      if (lane == 0) L.ppunc[blk] = before_pu;
+      if ((CAND >> lane) & 1ull) L.cand[nc + __popcll(CAND & lt)] = (uint16_t)p;
+      nc += __popcll(CAND);
+      L.tok[p] = kInvalidTok;
+      prev_sp = (SPb >> 63) & 1ull;
+      prev_pu = (PUb >> 63) & 1ull;
+    }
+    __syncthreads();
+
+    // ---- C. one lane per candidate
+    for (uint32_t k = lane; k < nc; k += 64) {
+      const uint32_t p0 = L.cand[k];
+      // the sentence around p0: [s0, e)
+      uint32_t s0, e;
+      {
+        int w = (int)(p0 >> 6);
+        unsigned long long m = L.sbits[w] & ((2ull << (p0 & 63)) - 1ull);
+        while (!m && w > 0) m = L.sbits[--w];
+        s0 = m ? (uint32_t)(w * 64 + 63 - __builtin_clzll(m)) : off0;
+        w = (int)(p0 >> 6);
+        m = (p0 & 63) == 63 ? 0ull : (L.sbits[w] & ~((2ull << (p0 & 63)) - 1ull));
+        while (!m && w + 1 < (int)nblk) m = L.sbits[++w];
+        e = m ? (uint32_t)(w * 64 + __builtin_ctzll(m)) : ce;
+        if (e > ce) e = ce;
+      }
+      const bool has_succ = k + 1 < nc && L.cand[k + 1] < e;
+      const uint32_t terr_end = has_succ ? L.cand[k + 1] : e;
+      const uint64_t want_next = has_succ ? L.cand[k + 1] : (uint64_t)e + 1;
+      TxtSrc src{L.txt, L.cls_lo, cls_tab};
+      WpWalk<TxtSrc> w(src, T, p0, e, p0 != s0 && wbit(L.ppunc, p0));
+      int stt = SWT_WP_OK;
+      const uint32_t n = w.segment(&L.tok[p0], terr_end - p0, stt);
+      if (stt != SWT_WP_OK || w.i != want_next || n > terr_end - p0) atomicOr(&L.irr[s0 >> 6], 1ull << (s0 & 63));
+    }
+    __syncthreads();
+
+    // ---- D. per sentence: status; the sequential walk where the speculation was not certified
+    for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
       const uint64_t o = sent_off[s];
       const uint64_t rel = o - abase;
       if (rel > ce || (rel == ce && !last)) break;
       const uint64_t e = sent_off[s + 1] - abase;  // <= ce: chunks end at sentence starts
-      int stt = SWT_WP_OK;
-      // an empty sentence still runs: s = " " (wordpiece.py:248); it yields no token but may raise (a vocabulary
-      // with a " " edge at the root) -- it never writes to out
-      LdsSrc src{&L};
-      const uint32_t n = wp_sentence(src, rel, e, &L.sym[rel < kCap ? rel : 0], T, stt);
-      for (uint64_t q = rel + n; q < e; q++) L.sym[q] = kInvalidTok;
+      int stt = T.empty_status;
+      if (rel < e) {
+        stt = SWT_WP_OK;
+        if (wbit(L.irr, (uint32_t)rel)) {
+          TxtSrc src{L.txt, L.cls_lo, cls_tab};
+          // tokens are staged in the global output run first (the territory array still feeds no one, but the walker
+          // must not overwrite text it has not read: it only reads L.txt, so L.tok is free to take them)
+          const uint32_t n = wp_sentence(src, rel, e, &L.tok[rel], T, stt);
+          for (uint64_t q = rel + n; q < e; q++) L.tok[q] = kInvalidTok;
+        }
+      }
       status[s] = (uint8_t)stt;
     }
     __syncthreads();
 
-    const uint32_t total = tile_compact(L, off0, ce, tile_out + run);
-    s_next += tile_record(L, sent_off, sent_local, s_next, s_hi, abase, ce, last, run, total);
+    // ---- E. compaction, F. sentence offsets
+    uint32_t total = 0;
+    for (uint32_t blk = 0; blk < nblk; blk++) {
+      const uint32_t p = blk * 64 + lane;
+      const uint32_t sv = (p >= off0 && p < ce) ? L.tok[p] : kInvalidTok;
+      const unsigned long long m = __ballot(sv != kInvalidTok);
+      if (lane == 0) { L.vmask[blk] = m; L.blkpre[blk] = total; }
+      if (sv != kInvalidTok) tile_out[run + total + __popcll(m & lt)] = sv;
+      total += __popcll(m);
+    }
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
+      const uint64_t rel = sent_off[s] - abase;
+      if (rel > ce || (rel == ce && !last)) break;
+      uint32_t ex = total;
+      if (rel < ce && (rel >> 6) < nblk) ex = L.blkpre[rel >> 6] + __popcll(L.vmask[rel >> 6] & ((1ull << (rel & 63)) - 1ull));
+      sent_local[s] = run + ex;
+      mine++;
+    }
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    s_next += mine;
     run += total;
     if (last) break;
     cb = abase + ce;
+    __syncthreads();
   }
-  if (tid == 0) tile_tok[t] = run;
+  if (lane == 0) tile_tok[t] = run;
 }
 
 // ---- host: trie build (utils.py:75-139) and flattening -------------------------------------------
@@ -503,7 +639,7 @@ int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, c
   hipStream_t st = (hipStream_t)stream;
   const uint8_t *d_cls = nullptr;
   if ((rc = device_class_table(&d_cls))) return rc;
-  const uint64_t n_tiles = tile_count(n_bytes);
+  const uint64_t n_tiles = tile_count(n_bytes, kWpTile);
   if (n_tiles > 0x7FFFFFFFull)
     return fail(SWT_ERR_UNSUPPORTED, "text too large for one call (%llu bytes)", (unsigned long long)n_bytes);
   if ((rc = t->ws.reserve(n_bytes, n_sent, n_tiles))) return rc;
@@ -522,9 +658,9 @@ int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, c
   T.corner_nonterm = t->H.corner_nonterm ? 1u : 0u;
   T.empty_status = t->H.child(t->H.root, ' ') >= 0 ? SWT_WP_INDEXERROR : SWT_WP_OK;
   T.corner_id = t->H.corner.size() == 1 ? t->H.corner[0] : t->H.n_vocab + 2;
-  launch_plan(d_sent_off, n_sent, n_tiles, kTile, t->ws.plan.as<uint64_t>(), st);
+  launch_plan(d_sent_off, n_sent, n_tiles, kWpTile, t->ws.plan.as<uint64_t>(), st);
   prof_begin(st);
-  hipLaunchKernelGGL(wp_encode_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, st, d_text, n_bytes, d_sent_off,
+  hipLaunchKernelGGL(wp_encode_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
                      t->ws.plan.as<uint64_t>(), d_cls, T, t->ws.scratch.as<uint32_t>(), t->ws.sent_local.as<uint32_t>(),
                      t->ws.tile_tok.as<uint32_t>(), d_status);
   prof_end(st);

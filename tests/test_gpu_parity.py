@@ -137,6 +137,24 @@ def test_bpe_duplicate_and_unreachable_merges(swt, oracle, dev):
         assert tok.tokenize(w) == orc.tokenize(w), w
 
 
+def test_bpe_wide_table_unpacked_path(swt, oracle, dev, bpe, corpora):
+    """more than 65,534 merges: the kernel variant whose cached pair value is the bare rank (merged_of_rank[] path)"""
+    extra = [(chr(0xE000 + 2 * i), chr(0xE001 + 2 * i)) for i in range(3000)]          # private-use pairs, never in text
+    extra += [(chr(0x4E00 + (i % 20000)), chr(0x3400 + (i // 20000))) for i in range(48000)]
+    merges = list(bpe.merges_list) + extra
+    assert len(merges) > 65534
+    tok = swt.FastBPE()
+    tok.merges_list = merges
+    tok._build_table()
+    orc = oracle.OracleBPE(merges)
+    texts = corpora["pan"][:300] + ["\ue000\ue001 x", "\u4e00\u3400\u4e01\u3400", "zażółć " * 50]
+    same_bpe(tok, orc, texts)
+    # same ids as the packed table on ordinary text (the extra merges never fire there)
+    a, ao = tok.encode_ids_batch(corpora["pan"][:300])
+    b, bo = bpe.encode_ids_batch(corpora["pan"][:300])
+    assert np.array_equal(ao, bo) and [tok.decode_ids(a)] == [bpe.decode_ids(b)]
+
+
 def test_bpe_s85k_full_size_properties(swt, oracle, dev):
     """config 2 at full size: bit-exact vs the oracle on ALL of S85k, plus size-independent properties"""
     from subword_tokenizers_amd import synth

@@ -1,0 +1,23 @@
+# rocprofv3 summaries for profiles/: kernel-trace stats per workload, then PMC passes (separate runs, no trace domains mixed in)
+export TMPDIR=/tmp
+cd /tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_r01
+rm -rf $O; mkdir -p $O
+for w in bpe_encode wp_encode bpe_train; do
+  extra=""; [ $w = bpe_encode ] && extra="--steps 50 --warmup 5"; [ $w = wp_encode ] && extra="--steps 5 --warmup 1"; [ $w = bpe_train ] && extra="--steps 1 --warmup 0"
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$w -- python3 $R/bench.py --workload $w $extra > $O/$w.json 2> $O/$w.err; echo "$w trace exit=$?"
+  f=$(find $O/$w -name "*kernel_stats.csv" | head -1); cp "$f" $O/${w}_kernel_stats.csv; cut -d, -f1-4 "$f" | cut -c1-110 | head -8
+done
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --workload bpe_encode --steps 5 --warmup 1 > $O/pmc_$c.json 2> $O/pmc_$c.err; echo "pmc $c exit=$?"
+  f=$(find $O/pmc_$c -name "*counter_collection.csv" | head -1); echo $f; head -1 "$f"; grep bpe_encode_kernel "$f" | head -3
+  python3 - "$f" $c <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "bpe_encode_kernel" in r.get("Kernel_Name", "")]
+vals = [float(r["Counter_Value"]) for r in rows if r.get("Counter_Name") == sys.argv[2]]
+print(sys.argv[2], "launches", len(vals), "mean", sum(vals) / max(len(vals), 1))
+PY
+done
+rm -rf $O/bpe_encode $O/wp_encode $O/bpe_train
+ls -la $O
