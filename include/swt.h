@@ -174,6 +174,12 @@ int swt_bpe_train_best(swt_bpe_trainer *t, uint32_t *left, uint32_t *right, uint
 /* Replace every L->R non-overlapping occurrence of (left,right) by merged (source/bpe.py:25-48,
  * 108-111) and update the histogram. */
 int swt_bpe_train_apply(swt_bpe_trainer *t, uint32_t left, uint32_t right, uint32_t merged);
+/* Device-driven training: up to max_steps iterations of {best, apply} enqueued back to back with no host round trip
+ * per merge.  Step i merges into symbol id first_merged + i -- valid while every merged STRING is new, which the caller
+ * checks afterwards from (left, right) (symbols are identified by their string; on the never-observed collision the
+ * caller replays with swt_bpe_train_apply).  Stops early when no pair is left; *n_done = merges performed. */
+int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_merged, uint32_t *left, uint32_t *right,
+                      uint64_t *count, uint32_t *n_done);
 /* Copies the current stream back (parity checks, corpus_as_symbols): syms[n_symbols], word_off[n_words+1],
  * freq[n_words] (freq may be NULL). */
 int swt_bpe_train_export(swt_bpe_trainer *t, uint32_t *syms, uint64_t syms_cap, uint64_t *word_off, uint32_t *freq);

@@ -58,6 +58,7 @@ SIGNATURES = {
     "swt_bpe_train_base_symbols": (C.c_int, [C.c_void_p, u32p, C.c_uint32]),
     "swt_bpe_train_best": (C.c_int, [C.c_void_p, u32p, u32p, u64p, u64p, u64p]),
     "swt_bpe_train_apply": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "swt_bpe_train_run": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u32p, u32p, u64p, u32p]),
     "swt_bpe_train_export": (C.c_int, [C.c_void_p, u32p, C.c_uint64, u64p, u32p]),
     "swt_bpe_train_histogram": (C.c_int, [C.c_void_p, u64p, u64p, C.c_uint64, u64p]),
     "swt_bpe_train_take_deltas": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, u64p, C.c_void_p]),
@@ -324,6 +325,16 @@ class BpeTrainer:
 
     def apply(self, left, right, merged):
         check(lib().swt_bpe_train_apply(self._h, left, right, merged))
+
+    def run(self, max_steps, first_merged):
+        """device-driven steps -> (left uint32[n], right uint32[n], count uint64[n]); n < max_steps: no pair was left"""
+        left = np.zeros(max(max_steps, 1), dtype=np.uint32)
+        right = np.zeros(max(max_steps, 1), dtype=np.uint32)
+        count = np.zeros(max(max_steps, 1), dtype=np.uint64)
+        n = C.c_uint32()
+        check(lib().swt_bpe_train_run(self._h, max_steps, first_merged, ptr(left, u32p), ptr(right, u32p), ptr(count, u64p),
+                                      C.byref(n)))
+        return left[:n.value], right[:n.value], count[:n.value]
 
     def export(self):
         inf = self.info()

@@ -26,6 +26,7 @@ namespace swt {
 
 constexpr int kTrainThreads = 256;
 constexpr int kArgBlocks = 512;
+constexpr uint32_t kMaxRunSteps = 512;
 
 struct TrainResult {
   unsigned long long max_count;
@@ -36,6 +37,14 @@ struct TrainResult {
   unsigned long long n_log;      // delta-log entries of the last apply
   unsigned long long n_syms;     // live symbols after the last apply
   unsigned long long win_key;    // pair at best_pos (tie winner)
+};
+
+struct StepCmd {
+  uint32_t l, r, m, valid;
+};
+struct StepLog {
+  uint32_t l, r;
+  unsigned long long count;
 };
 
 struct PairTable {
@@ -198,6 +207,22 @@ __global__ void winner_kernel(const uint32_t *__restrict__ sym, TrainResult *res
   res->win_key = pair_key(sym[res->best_pos], sym[res->best_pos + 1]);
 }
 
+// device-driven steps (swt_bpe_train_run): turn the argmax / tie-break result into the merge command of this step
+__global__ void decide_kernel(const uint32_t *__restrict__ sym, TrainResult *res, StepCmd *cmd, StepLog *log, uint32_t step,
+                              uint32_t merged) {
+  const unsigned long long mx = res->max_count;
+  unsigned long long key = res->best_key;
+  if (res->n_tied >= 2) key = res->best_pos != kEmptyKey ? pair_key(sym[res->best_pos], sym[res->best_pos + 1]) : kEmptyKey;
+  const bool valid = mx > 0 && key != kEmptyKey;
+  cmd->l = (uint32_t)(key >> 32);
+  cmd->r = (uint32_t)key;
+  cmd->m = merged;
+  cmd->valid = valid ? 1u : 0u;
+  log[step].l = cmd->l;
+  log[step].r = cmd->r;
+  log[step].count = valid ? mx : 0ull;
+}
+
 // bpe.py:108-111 + _replace_pair (bpe.py:25-48), with the histogram kept exact:
 //   an old pair (x[i],x[i+1]) disappears iff x[i] or x[i+1] is consumed by an occurrence;
 //   a new pair (y[j],y[j+1]) appears iff y[j] or y[j+1] is a freshly merged symbol.
@@ -205,9 +230,14 @@ __global__ __launch_bounds__(kTrainThreads) void apply_kernel(uint32_t *__restri
                                                               uint32_t *__restrict__ wlen, const uint32_t *__restrict__ freq,
                                                               uint64_t n_words, uint32_t l, uint32_t r, uint32_t m, PairTable T,
                                                               TrainResult *res, unsigned long long *__restrict__ log_keys,
-                                                              long long *__restrict__ log_vals, uint64_t log_cap) {
+                                                              long long *__restrict__ log_vals, uint64_t log_cap,
+                                                              const StepCmd *__restrict__ cmd) {
   const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n_words) return;
+  if (cmd) {  // device-driven step: the pair comes from decide_kernel
+    if (!cmd->valid) return;
+    l = cmd->l; r = cmd->r; m = cmd->m;
+  }
   const uint32_t n = wlen[w];
   if (n < 2) return;
   uint32_t *s = sym + woff[w];
@@ -298,6 +328,8 @@ struct swt_bpe_trainer {
   PairTable T{nullptr, nullptr, 0};
   TrainResult *d_res = nullptr;
   ArgPart *d_parts = nullptr;     // per-workgroup argmax partials + the ticket behind them
+  StepCmd *d_cmd = nullptr;       // device-driven steps
+  StepLog *d_steplog = nullptr;
   TrainResult h_res{};
   uint64_t pos_base = 0;
   bool hist_ready = false;
@@ -389,6 +421,8 @@ static int trainer_upload(swt_bpe_trainer *t, const uint32_t *syms, const uint64
   SWT_HIP(hipMalloc((void **)&t->d_freq, (n_words + 1) * 4));
   SWT_HIP(hipMalloc((void **)&t->d_res, sizeof(TrainResult)));
   SWT_HIP(hipMemset(t->d_res, 0, sizeof(TrainResult)));
+  SWT_HIP(hipMalloc((void **)&t->d_cmd, sizeof(StepCmd)));
+  SWT_HIP(hipMalloc((void **)&t->d_steplog, kMaxRunSteps * sizeof(StepLog)));
   SWT_HIP(hipMalloc((void **)&t->d_parts, (kArgBlocks + 1) * sizeof(ArgPart)));
   SWT_HIP(hipMemset(t->d_parts, 0, (kArgBlocks + 1) * sizeof(ArgPart)));
   if (n_syms) SWT_HIP(hipMemcpy(t->d_sym, syms, n_syms * 4, hipMemcpyHostToDevice));
@@ -471,7 +505,7 @@ int swt_bpe_train_create_text(const uint8_t *text, const uint64_t *sent_off, uin
 
 void swt_bpe_train_destroy(swt_bpe_trainer *t) {
   if (!t) return;
-  for (void *p : {(void *)t->d_sym, (void *)t->d_woff, (void *)t->d_wlen, (void *)t->d_freq, (void *)t->d_res, (void *)t->d_parts,
+  for (void *p : {(void *)t->d_sym, (void *)t->d_woff, (void *)t->d_wlen, (void *)t->d_freq, (void *)t->d_res, (void *)t->d_parts, (void *)t->d_cmd, (void *)t->d_steplog,
                   (void *)t->d_log_keys, (void *)t->d_log_vals})
     if (p) (void)hipFree(p);
   table_free(t->T);
@@ -555,11 +589,88 @@ int swt_bpe_train_apply(swt_bpe_trainer *t, uint32_t left, uint32_t right, uint3
   if (t->n_words)
     hipLaunchKernelGGL(apply_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff,
                        t->d_wlen, t->d_freq, t->n_words, left, right, merged, t->T, t->d_res,
-                       t->logging ? t->d_log_keys : nullptr, t->logging ? t->d_log_vals : nullptr, t->log_cap);
+                       t->logging ? t->d_log_keys : nullptr, t->logging ? t->d_log_vals : nullptr, t->log_cap,
+                       (const StepCmd *)nullptr);
   prof_end(0);
   SWT_HIP(hipGetLastError());
   // n_used may have grown; the next best() refreshes h_res.  Be conservative until then.
   t->h_res.n_used += 2 * occ;
+  return SWT_OK;
+}
+
+// Up to max_steps iterations of {argmax, tie-break, apply} enqueued back to back: the pair of step i stays on the device
+// (decide_kernel -> apply_kernel), only the log comes back.  Step i merges into symbol first_merged + i.
+int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_merged, uint32_t *left, uint32_t *right,
+                      uint64_t *count, uint32_t *n_done) {
+  if (!t || !left || !right || !count || !n_done) return fail(SWT_ERR_INVALID, "null argument");
+  if (t->logging) return fail(SWT_ERR_STATE, "swt_bpe_train_run is for unsharded training (deltas are exchanged per step)");
+  int rc = ensure_device();
+  if (rc) return rc;
+  *n_done = 0;
+  std::vector<StepLog> hlog(kMaxRunSteps);
+  uint32_t done = 0;
+  bool exhausted = false;
+  unsigned int *ticket = reinterpret_cast<unsigned int *>(t->d_parts + kArgBlocks);
+  while (done < max_steps && !exhausted) {
+    // Batch size: the maximum count never increases, so every step creates at most 2*C new pairs (C = the count of the
+    // last finished step); keep the table below load 1/2 for the whole batch.  The first batch is one step (no C yet).
+    uint64_t cap = 1ull << t->T.bits;
+    uint32_t k = 1;
+    if (t->h_res.max_count > 0) {
+      const uint64_t c0 = t->h_res.max_count < t->h_res.n_syms ? t->h_res.max_count : t->h_res.n_syms;
+      const uint64_t per = 2 * c0 + 1;
+      if (2 * (t->h_res.n_used + per + 64) > cap) {
+        uint32_t bits = t->T.bits;
+        while ((1ull << bits) < 4 * (t->h_res.n_used + 8 * per + 64)) bits++;
+        if (bits > 32) return fail(SWT_ERR_UNSUPPORTED, "pair table would exceed 2^32 slots");
+        if ((rc = table_resize(t, bits))) return rc;
+        if ((rc = sync_result(t))) return rc;
+        cap = 1ull << t->T.bits;
+      }
+      const uint64_t room = cap / 2 - t->h_res.n_used - 64;
+      const uint64_t fit = room / per;
+      k = (uint32_t)(fit < 1 ? 1 : (fit > kMaxRunSteps ? kMaxRunSteps : fit));
+    } else {
+      // no count known yet (fresh handle): one step.  A merge creates at most two new pairs per distinct symbol, and
+      // there are at most n_used + 1 distinct symbols.
+      const uint64_t per = 2 * t->h_res.n_used + 2;
+      if (2 * (t->h_res.n_used + per + 64) > cap) {
+        uint32_t bits = t->T.bits;
+        while ((1ull << bits) < 4 * (t->h_res.n_used + per + 64)) bits++;
+        if (bits > 32) return fail(SWT_ERR_UNSUPPORTED, "pair table would exceed 2^32 slots");
+        if ((rc = table_resize(t, bits))) return rc;
+        if ((rc = sync_result(t))) return rc;
+        cap = 1ull << t->T.bits;
+      }
+    }
+    if (k > max_steps - done) k = max_steps - done;
+    const unsigned g = grid_for(cap, 256 * 8, kArgBlocks);
+    for (uint32_t i = 0; i < k; i++) {
+      hipLaunchKernelGGL(argmax_kernel, dim3(g), dim3(256), 0, 0, t->T.keys, t->T.cnt, cap, t->d_parts, ticket, t->d_res);
+      if (t->n_words)
+        hipLaunchKernelGGL(first_pos_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym,
+                           t->d_woff, t->d_wlen, t->n_words, t->T, t->d_res);
+      hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(1), 0, 0, t->d_sym, t->d_res, t->d_cmd, t->d_steplog, i, first_merged + done + i);
+      prof_begin(0);
+      if (t->n_words)
+        hipLaunchKernelGGL(apply_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff,
+                           t->d_wlen, t->d_freq, t->n_words, 0u, 0u, 0u, t->T, t->d_res, (unsigned long long *)nullptr,
+                           (long long *)nullptr, (uint64_t)0, (const StepCmd *)t->d_cmd);
+      prof_end(0);
+    }
+    SWT_HIP(hipGetLastError());
+    SWT_HIP(hipMemcpy(hlog.data(), t->d_steplog, k * sizeof(StepLog), hipMemcpyDeviceToHost));
+    if ((rc = sync_result(t))) return rc;
+    for (uint32_t i = 0; i < k; i++) {
+      if (hlog[i].count == 0) { exhausted = true; break; }
+      left[done] = hlog[i].l;
+      right[done] = hlog[i].r;
+      count[done] = hlog[i].count;
+      done++;
+    }
+    if (!exhausted) t->h_res.max_count = hlog[k - 1].count;  // bound for the next batch (res holds the last argmax)
+  }
+  *n_done = done;
   return SWT_OK;
 }
 

@@ -147,18 +147,36 @@ class NaiveBPE(SubwordTokenizer):
         trainer = N.BpeTrainer.from_text(text, off)  # bpe.py:70-81 (split, Counter, symbolise)
         syms = _SymbolTable()
         self.vocab.update(chr(int(c)) for c in trainer.base_symbols())  # bpe.py:75
+        applied: List[Tuple[int, int, int]] = []  # (left, right, merged) ids in order, for the collision replay
         done = set()
-        while len(self.vocab) < max_vocab:  # bpe.py:88
-            left, right, count, _tied, _pos = trainer.best()  # bpe.py:90-102
-            if count == 0:  # bpe.py:98-99
-                break
-            if (left, right) in done:  # symbols only ever merge: a merged pair cannot come back
-                raise RuntimeError("pair histogram inconsistent: %r selected twice" % ((left, right),))
-            done.add((left, right))
-            ls, rs = syms.string(left), syms.string(right)
-            self.vocab.add(ls + rs)  # bpe.py:103
-            self.merges_list.append((ls, rs))  # bpe.py:104
-            trainer.apply(left, right, syms.intern(ls + rs))  # bpe.py:108-111
+        exhausted = False
+        while len(self.vocab) < max_vocab and not exhausted:  # bpe.py:88
+            # The device runs `want` iterations of bpe.py:90-111 back to back; it names the merged symbol of step i
+            # SYM_BASE + (strings so far) + i, which is right as long as every merged string is new (bpe.py:103).
+            want = max_vocab - len(self.vocab)
+            first = N.SYM_BASE + len(syms.strings)
+            lefts, rights, counts = trainer.run(want, first)
+            if len(lefts) < want:
+                exhausted = True  # bpe.py:98-99: no pair left
+            for i in range(len(lefts)):
+                left, right = int(lefts[i]), int(rights[i])
+                if (left, right) in done:  # symbols only ever merge: a merged pair cannot come back
+                    raise RuntimeError("pair histogram inconsistent: %r selected twice" % ((left, right),))
+                done.add((left, right))
+                ls, rs = syms.string(left), syms.string(right)
+                merged = syms.intern(ls + rs)
+                self.vocab.add(ls + rs)  # bpe.py:103
+                self.merges_list.append((ls, rs))  # bpe.py:104
+                applied.append((left, right, merged))
+                if merged != first + i:
+                    # two different merges spelled the same string (never observed).  The device
+                    # continued with a fresh id; rebuild the state with the right one and carry on from here.
+                    trainer.close()
+                    trainer = N.BpeTrainer.from_text(text, off)
+                    for l_, r_, m_ in applied:
+                        trainer.apply(l_, r_, m_)
+                    exhausted = False
+                    break
         self._trainer, self._train_syms, self._corpus_cache = trainer, syms, None
 
     @property

@@ -374,6 +374,34 @@ def test_train_state_matches_oracle_stepwise(swt, oracle, dev, corpora):
             assert got == want
 
 
+def test_train_device_driven_run_equals_stepwise(dev, oracle, corpora):
+    """swt_bpe_train_run (K merges per host round trip) == best/apply one at a time == the oracle"""
+    sents = corpora["t5k"][:1500]
+    text, off = dev.pack_utf8([s.lower() for s in sents])
+    a = dev.BpeTrainer.from_text(text, off)
+    b = dev.BpeTrainer.from_text(text, off)
+    orc = oracle.OracleBPETrainer(sents)
+    orc.run(10 ** 9, 300)
+    want, cnt = orc.merge_ids()
+    la, ra, ca = a.run(300, 0x110000)
+    assert len(la) == 300
+    got = np.stack([la, ra, 0x110000 + np.arange(300, dtype=np.uint32)], axis=1)
+    assert np.array_equal(got, want) and np.array_equal(ca, cnt)
+    for i in range(300):
+        l, r, c, tied, pos = b.best()
+        assert (l, r, c) == (int(la[i]), int(ra[i]), int(ca[i]))
+        b.apply(l, r, 0x110000 + i)
+    sa, wa, _ = a.export()
+    sb, wb, _ = b.export()
+    so, wo, _ = orc.export()
+    assert np.array_equal(sa, sb) and np.array_equal(wa, wb) and np.array_equal(sa, so) and np.array_equal(wa, wo)
+    # run() past exhaustion returns fewer steps than asked
+    t = dev.BpeTrainer.from_words(np.array([97, 98, 97, 98], dtype=np.uint32), np.array([0, 2, 4], dtype=np.uint64),
+                                  np.array([1, 1], dtype=np.uint32))
+    l, r, c = t.run(10, 0x110000)
+    assert list(zip(l.tolist(), r.tolist(), c.tolist())) == [(97, 98, 2)]
+
+
 def test_train_create_words_and_exhaustion(dev, oracle):
     """from an explicit word list; training to exhaustion stops with count == 0 (bpe.py:98-99)"""
     syms = np.array([ord(c) for c in "aaaabab"], dtype=np.uint32)
