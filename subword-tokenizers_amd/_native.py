@@ -186,9 +186,9 @@ class BpeTable:
         self._h = h
 
     def close(self):
-        if getattr(self, "_h", None):
-            lib().swt_bpe_table_destroy(self._h)
-            self._h = None
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.swt_bpe_table_destroy(self._h)
+        self._h = None
 
     __del__ = close
 
@@ -219,9 +219,9 @@ class WpTrie:
         self._h = h
 
     def close(self):
-        if getattr(self, "_h", None):
-            lib().swt_wp_trie_destroy(self._h)
-            self._h = None
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.swt_wp_trie_destroy(self._h)
+        self._h = None
 
     __del__ = close
 
@@ -296,9 +296,9 @@ class BpeTrainer:
         return cls(h)
 
     def close(self):
-        if getattr(self, "_h", None):
-            lib().swt_bpe_train_destroy(self._h)
-            self._h = None
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.swt_bpe_train_destroy(self._h)
+        self._h = None
 
     __del__ = close
 

@@ -27,6 +27,7 @@ namespace swt {
 constexpr int kTrainThreads = 256;
 constexpr int kArgBlocks = 512;
 constexpr uint32_t kMaxRunSteps = 512;
+constexpr uint32_t kRunBatch = 256;
 
 struct TrainResult {
   unsigned long long max_count;
@@ -45,6 +46,7 @@ struct StepCmd {
 struct StepLog {
   uint32_t l, r;
   unsigned long long count;
+  unsigned long long flag;  // 0 merged, 1 tied maximum (the host breaks the tie), 2 no pair left
 };
 
 struct PairTable {
@@ -178,49 +180,68 @@ __global__ __launch_bounds__(256) void argmax_kernel(const unsigned long long *_
   }
 }
 
-// bpe.py:102 tie-break: the earliest (word, position) whose pair holds the maximum count
+// bpe.py:102 tie-break: the earliest (word, position) whose pair holds the maximum count.  Grid-stride over the
+// words, so an untied step costs a handful of workgroups that return at once.
+// Device-driven mode (cmd != null, swt_bpe_train_run): this kernel also turns the result into the step's merge command
+// for apply_kernel and logs it -- workgroup 0 when the maximum is unique, the last workgroup of the scan when tied.
+__device__ __forceinline__ void write_cmd(unsigned long long key, unsigned long long mx, StepCmd *cmd, StepLog *log, uint32_t step,
+                                          uint32_t merged) {
+  const bool ok = mx > 0 && key != kEmptyKey;
+  cmd->l = (uint32_t)(key >> 32);
+  cmd->r = (uint32_t)key;
+  cmd->m = merged;
+  cmd->valid = ok ? 1u : 0u;
+  log[step].l = cmd->l;
+  log[step].r = cmd->r;
+  log[step].count = mx;
+  log[step].flag = ok ? 0ull : 2ull;
+}
+
 __global__ __launch_bounds__(kTrainThreads) void first_pos_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
                                                                   const uint32_t *__restrict__ wlen, uint64_t n_words, PairTable T,
-                                                                  TrainResult *res) {
-  if (res->n_tied < 2) return;
-  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= n_words) return;
-  const uint32_t n = wlen[w];
-  if (n < 2) return;
-  const uint64_t base = woff[w];
-  if (base >= res->best_pos) return;  // an earlier word already holds a candidate
-  const long long mx = (long long)res->max_count;
-  const uint32_t *s = sym + base;
-  uint32_t a = s[0];
-  for (uint32_t i = 1; i < n; i++) {
-    const uint32_t b = s[i];
-    if (table_get(T, pair_key(a, b)) == mx) {
-      atomicMin(&res->best_pos, (unsigned long long)(base + i - 1));
-      return;
-    }
-    a = b;
+                                                                  TrainResult *res, StepCmd *cmd, StepLog *log, uint32_t step,
+                                                                  uint32_t merged, unsigned int *ticket) {
+  __shared__ bool is_last;
+  if (res->n_tied < 2) {
+    if (cmd && blockIdx.x == 0 && threadIdx.x == 0) write_cmd(res->best_key, res->max_count, cmd, log, step, merged);
+    return;
   }
+  const long long mx = (long long)res->max_count;
+  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t n = wlen[w];
+    if (n < 2) continue;
+    const uint64_t base = woff[w];
+    if (base >= __hip_atomic_load(&res->best_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;  // words only get later
+    const uint32_t *s = sym + base;
+    uint32_t a = s[0];
+    for (uint32_t i = 1; i < n; i++) {
+      const uint32_t b = s[i];
+      if (table_get(T, pair_key(a, b)) == mx) {
+        atomicMin(&res->best_pos, (unsigned long long)(base + i - 1));
+        break;
+      }
+      a = b;
+    }
+  }
+  if (!cmd) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last || threadIdx.x != 0) return;
+  __threadfence();
+  const unsigned long long pos = __hip_atomic_load(&res->best_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long key = pos != kEmptyKey ? pair_key(sym[pos], sym[pos + 1]) : kEmptyKey;
+  res->win_key = key;
+  write_cmd(key, res->max_count, cmd, log, step, merged);
+  *ticket = 0;
 }
 
 __global__ void winner_kernel(const uint32_t *__restrict__ sym, TrainResult *res) {
   if (res->n_tied < 2 || res->best_pos == kEmptyKey) return;
   res->win_key = pair_key(sym[res->best_pos], sym[res->best_pos + 1]);
-}
-
-// device-driven steps (swt_bpe_train_run): turn the argmax / tie-break result into the merge command of this step
-__global__ void decide_kernel(const uint32_t *__restrict__ sym, TrainResult *res, StepCmd *cmd, StepLog *log, uint32_t step,
-                              uint32_t merged) {
-  const unsigned long long mx = res->max_count;
-  unsigned long long key = res->best_key;
-  if (res->n_tied >= 2) key = res->best_pos != kEmptyKey ? pair_key(sym[res->best_pos], sym[res->best_pos + 1]) : kEmptyKey;
-  const bool valid = mx > 0 && key != kEmptyKey;
-  cmd->l = (uint32_t)(key >> 32);
-  cmd->r = (uint32_t)key;
-  cmd->m = merged;
-  cmd->valid = valid ? 1u : 0u;
-  log[step].l = cmd->l;
-  log[step].r = cmd->r;
-  log[step].count = valid ? mx : 0ull;
 }
 
 // bpe.py:108-111 + _replace_pair (bpe.py:25-48), with the histogram kept exact:
@@ -330,6 +351,8 @@ struct swt_bpe_trainer {
   ArgPart *d_parts = nullptr;     // per-workgroup argmax partials + the ticket behind them
   StepCmd *d_cmd = nullptr;       // device-driven steps
   StepLog *d_steplog = nullptr;
+  unsigned int *d_halt = nullptr;  // ticket of the tie-break scan
+  uint64_t n_applied = 0;         // merges applied so far (bounds the number of distinct symbols)
   TrainResult h_res{};
   uint64_t pos_base = 0;
   bool hist_ready = false;
@@ -423,6 +446,7 @@ static int trainer_upload(swt_bpe_trainer *t, const uint32_t *syms, const uint64
   SWT_HIP(hipMemset(t->d_res, 0, sizeof(TrainResult)));
   SWT_HIP(hipMalloc((void **)&t->d_cmd, sizeof(StepCmd)));
   SWT_HIP(hipMalloc((void **)&t->d_steplog, kMaxRunSteps * sizeof(StepLog)));
+  SWT_HIP(hipMalloc((void **)&t->d_halt, 8));
   SWT_HIP(hipMalloc((void **)&t->d_parts, (kArgBlocks + 1) * sizeof(ArgPart)));
   SWT_HIP(hipMemset(t->d_parts, 0, (kArgBlocks + 1) * sizeof(ArgPart)));
   if (n_syms) SWT_HIP(hipMemcpy(t->d_sym, syms, n_syms * 4, hipMemcpyHostToDevice));
@@ -505,7 +529,7 @@ int swt_bpe_train_create_text(const uint8_t *text, const uint64_t *sent_off, uin
 
 void swt_bpe_train_destroy(swt_bpe_trainer *t) {
   if (!t) return;
-  for (void *p : {(void *)t->d_sym, (void *)t->d_woff, (void *)t->d_wlen, (void *)t->d_freq, (void *)t->d_res, (void *)t->d_parts, (void *)t->d_cmd, (void *)t->d_steplog,
+  for (void *p : {(void *)t->d_sym, (void *)t->d_woff, (void *)t->d_wlen, (void *)t->d_freq, (void *)t->d_res, (void *)t->d_parts, (void *)t->d_cmd, (void *)t->d_steplog, (void *)t->d_halt,
                   (void *)t->d_log_keys, (void *)t->d_log_vals})
     if (p) (void)hipFree(p);
   table_free(t->T);
@@ -549,8 +573,9 @@ int swt_bpe_train_best(swt_bpe_trainer *t, uint32_t *left, uint32_t *right, uint
   if ((rc = sync_result(t))) return rc;
   if (t->h_res.n_tied >= 2 && t->n_words) {
     // bpe.py:102: only a tied maximum needs the scan for the earliest (word, position)
-    hipLaunchKernelGGL(first_pos_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff,
-                       t->d_wlen, t->n_words, t->T, t->d_res);
+    hipLaunchKernelGGL(first_pos_kernel, dim3(grid_for(t->n_words, kTrainThreads, 1024)), dim3(kTrainThreads), 0, 0, t->d_sym,
+                       t->d_woff, t->d_wlen, t->n_words, t->T, t->d_res, (StepCmd *)nullptr, (StepLog *)nullptr, 0u, 0u,
+                       (unsigned int *)nullptr);
     hipLaunchKernelGGL(winner_kernel, dim3(1), dim3(1), 0, 0, t->d_sym, t->d_res);
     if ((rc = sync_result(t))) return rc;
   }
@@ -570,20 +595,33 @@ int swt_bpe_train_best(swt_bpe_trainer *t, uint32_t *left, uint32_t *right, uint
   return SWT_OK;
 }
 
+// New pairs one merge can create: two per occurrence (occurrences <= the pair's count, counts never grow), and never
+// more than (x, m) / (m, y) over the distinct symbols x, y plus (m, m).
+static uint64_t new_pairs_bound(const swt_bpe_trainer *t, uint64_t count_bound) {
+  const uint64_t by_symbols = 2 * (t->n_base + t->n_applied + 1) + 1;
+  uint64_t by_count = count_bound ? 2 * count_bound : by_symbols;
+  if (t->h_res.n_syms && 2 * t->h_res.n_syms < by_count) by_count = 2 * t->h_res.n_syms;
+  return by_symbols < by_count ? by_symbols : by_count;
+}
+
+static int ensure_room(swt_bpe_trainer *t, uint64_t extra) {
+  const uint64_t cap = 1ull << t->T.bits;
+  if (2 * (t->h_res.n_used + extra + 64) <= cap) return SWT_OK;
+  uint32_t bits = t->T.bits;
+  while ((1ull << bits) < 4 * (t->h_res.n_used + extra + 64)) bits++;
+  if (bits > 32) return fail(SWT_ERR_UNSUPPORTED, "pair table would exceed 2^32 slots");
+  int rc = table_resize(t, bits);
+  if (rc) return rc;
+  return sync_result(t);
+}
+
 int swt_bpe_train_apply(swt_bpe_trainer *t, uint32_t left, uint32_t right, uint32_t merged) {
   if (!t) return fail(SWT_ERR_INVALID, "null trainer");
   int rc = ensure_device();
   if (rc) return rc;
-  // keep the load factor below 1/2 even if every occurrence creates two new pairs
-  const uint64_t cap = 1ull << t->T.bits;
-  uint64_t occ = t->h_res.max_count < t->h_res.n_syms ? t->h_res.max_count : t->h_res.n_syms;
-  if (occ == 0) occ = t->n_syms0;
-  if (2 * (t->h_res.n_used + 2 * occ + 64) > cap) {
-    uint32_t bits = t->T.bits;
-    while ((1ull << bits) < 4 * (t->h_res.n_used + 2 * occ + 64)) bits++;
-    if (bits > 32) return fail(SWT_ERR_UNSUPPORTED, "pair table would exceed 2^32 slots");
-    if ((rc = table_resize(t, bits))) return rc;
-  }
+  // keep the load factor below 1/2 whatever this merge creates
+  const uint64_t occ = new_pairs_bound(t, t->h_res.max_count);
+  if ((rc = ensure_room(t, occ))) return rc;
   if (t->logging) SWT_HIP(hipMemsetAsync(&t->d_res->n_log, 0, 8, 0));
   prof_begin(0);
   if (t->n_words)
@@ -594,7 +632,8 @@ int swt_bpe_train_apply(swt_bpe_trainer *t, uint32_t left, uint32_t right, uint3
   prof_end(0);
   SWT_HIP(hipGetLastError());
   // n_used may have grown; the next best() refreshes h_res.  Be conservative until then.
-  t->h_res.n_used += 2 * occ;
+  t->h_res.n_used += occ;
+  t->n_applied++;
   return SWT_OK;
 }
 
@@ -609,48 +648,25 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
   *n_done = 0;
   std::vector<StepLog> hlog(kMaxRunSteps);
   uint32_t done = 0;
-  bool exhausted = false;
   unsigned int *ticket = reinterpret_cast<unsigned int *>(t->d_parts + kArgBlocks);
+  unsigned int *ticket2 = reinterpret_cast<unsigned int *>(t->d_halt);
+  bool exhausted = false;
   while (done < max_steps && !exhausted) {
-    // Batch size: the maximum count never increases, so every step creates at most 2*C new pairs (C = the count of the
-    // last finished step); keep the table below load 1/2 for the whole batch.  The first batch is one step (no C yet).
-    uint64_t cap = 1ull << t->T.bits;
-    uint32_t k = 1;
-    if (t->h_res.max_count > 0) {
-      const uint64_t c0 = t->h_res.max_count < t->h_res.n_syms ? t->h_res.max_count : t->h_res.n_syms;
-      const uint64_t per = 2 * c0 + 1;
-      if (2 * (t->h_res.n_used + per + 64) > cap) {
-        uint32_t bits = t->T.bits;
-        while ((1ull << bits) < 4 * (t->h_res.n_used + 8 * per + 64)) bits++;
-        if (bits > 32) return fail(SWT_ERR_UNSUPPORTED, "pair table would exceed 2^32 slots");
-        if ((rc = table_resize(t, bits))) return rc;
-        if ((rc = sync_result(t))) return rc;
-        cap = 1ull << t->T.bits;
-      }
-      const uint64_t room = cap / 2 - t->h_res.n_used - 64;
-      const uint64_t fit = room / per;
-      k = (uint32_t)(fit < 1 ? 1 : (fit > kMaxRunSteps ? kMaxRunSteps : fit));
-    } else {
-      // no count known yet (fresh handle): one step.  A merge creates at most two new pairs per distinct symbol, and
-      // there are at most n_used + 1 distinct symbols.
-      const uint64_t per = 2 * t->h_res.n_used + 2;
-      if (2 * (t->h_res.n_used + per + 64) > cap) {
-        uint32_t bits = t->T.bits;
-        while ((1ull << bits) < 4 * (t->h_res.n_used + per + 64)) bits++;
-        if (bits > 32) return fail(SWT_ERR_UNSUPPORTED, "pair table would exceed 2^32 slots");
-        if ((rc = table_resize(t, bits))) return rc;
-        if ((rc = sync_result(t))) return rc;
-        cap = 1ull << t->T.bits;
-      }
-    }
-    if (k > max_steps - done) k = max_steps - done;
+    uint32_t k = max_steps - done;
+    if (k > kRunBatch) k = kRunBatch;
+    // room for the whole batch (the symbol count grows by one per step, counts never grow)
+    const uint64_t by_sym = 2 * (t->n_base + t->n_applied + k + 1) + 1;
+    uint64_t per = new_pairs_bound(t, t->h_res.max_count);
+    if (t->h_res.max_count == 0 || by_sym < per) per = by_sym;
+    if ((rc = ensure_room(t, per * k))) return rc;
+    const uint64_t cap = 1ull << t->T.bits;
     const unsigned g = grid_for(cap, 256 * 8, kArgBlocks);
+    const unsigned gw = grid_for(t->n_words ? t->n_words : 1, kTrainThreads * 8, 256);
+    SWT_HIP(hipMemsetAsync(t->d_halt, 0, 8, 0));
     for (uint32_t i = 0; i < k; i++) {
       hipLaunchKernelGGL(argmax_kernel, dim3(g), dim3(256), 0, 0, t->T.keys, t->T.cnt, cap, t->d_parts, ticket, t->d_res);
-      if (t->n_words)
-        hipLaunchKernelGGL(first_pos_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym,
-                           t->d_woff, t->d_wlen, t->n_words, t->T, t->d_res);
-      hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(1), 0, 0, t->d_sym, t->d_res, t->d_cmd, t->d_steplog, i, first_merged + done + i);
+      hipLaunchKernelGGL(first_pos_kernel, dim3(gw), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff, t->d_wlen, t->n_words, t->T,
+                         t->d_res, t->d_cmd, t->d_steplog, i, first_merged + done + i, ticket2);
       prof_begin(0);
       if (t->n_words)
         hipLaunchKernelGGL(apply_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff,
@@ -661,14 +677,17 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
     SWT_HIP(hipGetLastError());
     SWT_HIP(hipMemcpy(hlog.data(), t->d_steplog, k * sizeof(StepLog), hipMemcpyDeviceToHost));
     if ((rc = sync_result(t))) return rc;
-    for (uint32_t i = 0; i < k; i++) {
-      if (hlog[i].count == 0) { exhausted = true; break; }
-      left[done] = hlog[i].l;
-      right[done] = hlog[i].r;
-      count[done] = hlog[i].count;
+    uint32_t good = 0;
+    while (good < k && hlog[good].flag == 0) {
+      left[done] = hlog[good].l;
+      right[done] = hlog[good].r;
+      count[done] = hlog[good].count;
       done++;
+      good++;
     }
-    if (!exhausted) t->h_res.max_count = hlog[k - 1].count;  // bound for the next batch (res holds the last argmax)
+    t->n_applied += good;
+    if (good) t->h_res.max_count = hlog[good - 1].count;  // counts never grow: bound for the next batch
+    if (good < k) exhausted = true;  // bpe.py:98-99: no pair left (later steps of the batch were no-ops)
   }
   *n_done = done;
   return SWT_OK;
