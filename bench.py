@@ -245,33 +245,44 @@ def bench_bpe_train(args, torch, dist, rank, world, local):
     from subword_tokenizers_amd import _native as N
     from subword_tokenizers_amd import synth, tokenizers
 
-    if world > 1:
-        raise SystemExit("bpe_train bench is single-GPU in this round (sharded training: tests + DESIGN.md)")
     N.init(local)
     sents = synth.s85k()
     max_vocab = args.max_vocab or 8000
     times = []
     n_merges = 0
     kernel_ms = launches = 0
+    info = {}
+    merges = []
     for it in range(args.warmup + args.steps):
-        tok = tokenizers.FastBPE()
         if it == args.warmup:
             N.profile_enable(True)
             N.profile_read()
-        torch.cuda.synchronize()
+        barrier_sync(torch, dist)
         t0 = time.perf_counter()
-        tok.train(sents, max_vocab)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        if world == 1:
+            tok = tokenizers.FastBPE()
+            tok.train(sents, max_vocab)
+            merges = list(tok.merges_list)
+            info = tok._trainer.info()
+            tok.reset()
+        else:
+            # corpus-sharded: contiguous sentence ranges, pair-histogram deltas all-gathered over RCCL every merge
+            from subword_tokenizers_amd.distributed import ShardedBpeTrainer, TorchGroup
+
+            tr = ShardedBpeTrainer.from_corpus(sents, rank, world, TorchGroup(dist, "cuda"))
+            merges = [tuple(m) for m in tr.train(max_vocab)]
+            info = tr.engine.t.info()
+            tr.engine.t.close()
+        barrier_sync(torch, dist)
+        dt = max_over_ranks(torch, dist, time.perf_counter() - t0)
         if it >= args.warmup:
             times.append(dt)
-        n_merges = len(tok.merges_list)
-        info = tok._trainer.info()
-        merges = list(tok.merges_list)
-        tok.reset()
+        n_merges = len(merges)
     kernel_ms, launches = N.profile_read()
     N.profile_enable(False)
     elapsed = sum(times)
+    if rank != 0:
+        return {"metric": "", "value": 0, "unit": "", "ms_per_step": 0, "dtype": "u32", "config": {}}
     from oracle import oracle as O
 
     sample = 200
@@ -291,7 +302,9 @@ def bench_bpe_train(args, torch, dist, rank, world, local):
         "metric": "BPE train seconds per 1k merges", "value": round(sec_per_1k, 4), "unit": "s/1k-merges", "higher_is_better": False,
         "ms_per_step": round(elapsed / len(times) * 1e3, 3), "dtype": "u32",
         "config": {"workload": "FastBPE.train on S85k (stand-in for train-85k) to max_vocab=%d: %d merges, %d unique words, "
-                               "%d symbols" % (max_vocab, n_merges, w0, n0), "parallelism": "single GPU"},
+                               "%d symbols" % (max_vocab, n_merges, w0, n0),
+                   "parallelism": "single GPU" if world == 1 else "corpus-sharded x%d, per-merge delta all-gather (RCCL)" % world},
+        "scaling": "strong",
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_from_profile("bpe_train"),
                      "kernel": "apply_kernel", "kernel_us": round(per_launch_s * 1e6, 2),
@@ -324,7 +337,7 @@ def main():
     res = fn(args, torch, dist, rank, world, local)
     line = {"metric": res.pop("metric"), "value": res.pop("value"), "unit": res.pop("unit"), "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"),
-            "higher_is_better": res.pop("higher_is_better", True), "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": res.pop("higher_is_better", True), "scaling": res.pop("scaling", "weak"), "vs_baseline": None,
             "dtype": res.pop("dtype"), "data": "synthetic", "config": res.pop("config")}
     line.update(res)
     if rank == 0:

@@ -458,11 +458,21 @@ static int trainer_upload(swt_bpe_trainer *t, const uint32_t *syms, const uint64
   unsigned long long ns = n_syms;
   SWT_HIP(hipMemcpy(&t->d_res->n_syms, &ns, 8, hipMemcpyHostToDevice));
   // distinct code points (the initial vocab, bpe.py:75)
-  std::vector<uint32_t> b(syms, syms + n_syms);
-  std::sort(b.begin(), b.end());
-  b.erase(std::unique(b.begin(), b.end()), b.end());
-  t->base_syms = b;
-  t->n_base = (uint32_t)b.size();
+  {
+    std::vector<uint8_t> seen(kNumCodePoints, 0);
+    std::vector<uint32_t> other;  // ids that are not code points (a caller-supplied stream may already hold merged symbols)
+    for (uint64_t i = 0; i < n_syms; i++) {
+      if (syms[i] < kNumCodePoints) seen[syms[i]] = 1;
+      else other.push_back(syms[i]);
+    }
+    std::vector<uint32_t> b;
+    for (uint32_t c = 0; c < kNumCodePoints; c++) if (seen[c]) b.push_back(c);
+    std::sort(other.begin(), other.end());
+    other.erase(std::unique(other.begin(), other.end()), other.end());
+    b.insert(b.end(), other.begin(), other.end());
+    t->base_syms = b;
+    t->n_base = (uint32_t)b.size();
+  }
   return build_histogram(t);
 }
 
@@ -483,10 +493,24 @@ int swt_bpe_train_create_words(const uint32_t *syms, const uint64_t *word_off, c
 int swt_bpe_train_create_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, swt_bpe_trainer **out) {
   if (!out || !sent_off || (n_sent && sent_off[n_sent] && !text)) return fail(SWT_ERR_INVALID, "null argument");
   const uint8_t *cls = host_class_table();
-  std::unordered_map<std::string, uint32_t> index;
+  // Counter(words) in first-occurrence order: open addressing over (hash, first occurrence) -- no per-word allocation
+  struct Slot { uint64_t hash; const uint8_t *p; uint32_t len; uint32_t index; };
+  size_t cap = 1 << 16;
+  std::vector<Slot> table(cap, Slot{0, nullptr, 0, 0});
   std::vector<uint32_t> syms, freq;
   std::vector<uint64_t> woff{0};
   std::vector<uint32_t> cps;
+  auto grow = [&]() {
+    std::vector<Slot> nt(cap * 2, Slot{0, nullptr, 0, 0});
+    for (const Slot &sl : table)
+      if (sl.p) {
+        size_t h = sl.hash & (cap * 2 - 1);
+        while (nt[h].p) h = (h + 1) & (cap * 2 - 1);
+        nt[h] = sl;
+      }
+    table.swap(nt);
+    cap *= 2;
+  };
   for (uint64_t s = 0; s < n_sent; s++) {
     const uint8_t *p = text + sent_off[s], *end = text + sent_off[s + 1];
     while (p < end) {
@@ -507,16 +531,23 @@ int swt_bpe_train_create_text(const uint8_t *text, const uint64_t *sent_off, uin
           p += len;
         }
       }
-      std::string key(reinterpret_cast<const char *>(w0), (size_t)(p - w0));
-      auto it = index.find(key);
-      if (it == index.end()) {
-        index.emplace(std::move(key), (uint32_t)freq.size());
+      const uint32_t wl = (uint32_t)(p - w0);
+      uint64_t h = 0xcbf29ce484222325ull;
+      for (uint32_t i = 0; i < wl; i++) { h ^= w0[i]; h *= 0x100000001b3ull; }
+      h ^= h >> 29; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 32;
+      size_t slot = h & (cap - 1);
+      while (table[slot].p && !(table[slot].hash == h && table[slot].len == wl && memcmp(table[slot].p, w0, wl) == 0))
+        slot = (slot + 1) & (cap - 1);
+      if (!table[slot].p) {
+        table[slot] = Slot{h, w0, wl, (uint32_t)freq.size()};
         freq.push_back(1);
         syms.insert(syms.end(), cps.begin(), cps.end());
         woff.push_back(syms.size());
+        if (freq.size() * 2 > cap) grow();
       } else {
-        if (freq[it->second] == 0xFFFFFFFFu) return fail(SWT_ERR_UNSUPPORTED, "word frequency overflows 32 bits");
-        freq[it->second]++;
+        uint32_t &f = freq[table[slot].index];
+        if (f == 0xFFFFFFFFu) return fail(SWT_ERR_UNSUPPORTED, "word frequency overflows 32 bits");
+        f++;
       }
     }
   }
