@@ -21,6 +21,7 @@
 #include <unordered_map>
 
 #include "swt_common.h"
+#include "swt_words.h"
 
 namespace swt {
 
@@ -426,6 +427,36 @@ static int build_histogram(swt_bpe_trainer *t) {
   return SWT_OK;
 }
 
+__global__ void wlen_kernel(const uint64_t *__restrict__ woff, uint32_t *__restrict__ wlen, uint64_t n_words) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < n_words) wlen[w] = (uint32_t)(woff[w + 1] - woff[w]);
+}
+
+// take ownership of a unique-word stream that is already on the device (swt_words.hip)
+static int trainer_adopt(swt_bpe_trainer *t, DeviceWords &dw) {
+  t->n_words = dw.n_words;
+  t->n_syms0 = dw.n_syms;
+  t->d_sym = dw.d_sym;
+  t->d_woff = dw.d_woff;
+  t->d_freq = dw.d_freq;
+  dw.d_sym = nullptr; dw.d_woff = nullptr; dw.d_freq = nullptr;
+  SWT_HIP(hipMalloc((void **)&t->d_wlen, (t->n_words + 1) * 4));
+  SWT_HIP(hipMalloc((void **)&t->d_res, sizeof(TrainResult)));
+  SWT_HIP(hipMemset(t->d_res, 0, sizeof(TrainResult)));
+  SWT_HIP(hipMalloc((void **)&t->d_cmd, sizeof(StepCmd)));
+  SWT_HIP(hipMalloc((void **)&t->d_steplog, kMaxRunSteps * sizeof(StepLog)));
+  SWT_HIP(hipMalloc((void **)&t->d_halt, 8));
+  SWT_HIP(hipMalloc((void **)&t->d_parts, (kArgBlocks + 1) * sizeof(ArgPart)));
+  SWT_HIP(hipMemset(t->d_parts, 0, (kArgBlocks + 1) * sizeof(ArgPart)));
+  if (t->n_words)
+    hipLaunchKernelGGL(wlen_kernel, dim3(grid_for(t->n_words, 256)), dim3(256), 0, 0, t->d_woff, t->d_wlen, t->n_words);
+  unsigned long long ns = t->n_syms0;
+  SWT_HIP(hipMemcpy(&t->d_res->n_syms, &ns, 8, hipMemcpyHostToDevice));
+  t->base_syms = dw.base_syms;
+  t->n_base = (uint32_t)t->base_syms.size();
+  return build_histogram(t);
+}
+
 static int trainer_upload(swt_bpe_trainer *t, const uint32_t *syms, const uint64_t *word_off, const uint32_t *freq, uint64_t n_words) {
   int rc = ensure_device();
   if (rc) return rc;
@@ -489,70 +520,26 @@ int swt_bpe_train_create_words(const uint32_t *syms, const uint64_t *word_off, c
   return SWT_OK;
 }
 
-// bpe.py:70-81 on the host: pre-tokenize (utils.py:27 split), Counter(words) in first-occurrence order, symbolise.
+// bpe.py:70-81 on the device (swt_words.hip): split (utils.py:27), Counter(words) in first-occurrence order, symbolise.
 int swt_bpe_train_create_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, swt_bpe_trainer **out) {
   if (!out || !sent_off || (n_sent && sent_off[n_sent] && !text)) return fail(SWT_ERR_INVALID, "null argument");
-  const uint8_t *cls = host_class_table();
-  // Counter(words) in first-occurrence order: open addressing over (hash, first occurrence) -- no per-word allocation
-  struct Slot { uint64_t hash; const uint8_t *p; uint32_t len; uint32_t index; };
-  size_t cap = 1 << 16;
-  std::vector<Slot> table(cap, Slot{0, nullptr, 0, 0});
-  std::vector<uint32_t> syms, freq;
-  std::vector<uint64_t> woff{0};
-  std::vector<uint32_t> cps;
-  auto grow = [&]() {
-    std::vector<Slot> nt(cap * 2, Slot{0, nullptr, 0, 0});
-    for (const Slot &sl : table)
-      if (sl.p) {
-        size_t h = sl.hash & (cap * 2 - 1);
-        while (nt[h].p) h = (h + 1) & (cap * 2 - 1);
-        nt[h] = sl;
-      }
-    table.swap(nt);
-    cap *= 2;
-  };
-  for (uint64_t s = 0; s < n_sent; s++) {
-    const uint8_t *p = text + sent_off[s], *end = text + sent_off[s + 1];
-    while (p < end) {
-      int len;
-      uint32_t cp = utf8_decode_host(p, end, &len);
-      const uint8_t c = cp < kNumCodePoints ? cls[cp] : 0;
-      if (c & SWT_CLS_BERT_WS) { p += len; continue; }
-      const uint8_t *w0 = p;
-      cps.clear();
-      cps.push_back(cp);
-      p += len;
-      if (!(c & SWT_CLS_BERT_PUNCT)) {
-        while (p < end) {
-          cp = utf8_decode_host(p, end, &len);
-          const uint8_t c2 = cp < kNumCodePoints ? cls[cp] : 0;
-          if (c2 & (SWT_CLS_BERT_WS | SWT_CLS_BERT_PUNCT)) break;
-          cps.push_back(cp);
-          p += len;
-        }
-      }
-      const uint32_t wl = (uint32_t)(p - w0);
-      uint64_t h = 0xcbf29ce484222325ull;
-      for (uint32_t i = 0; i < wl; i++) { h ^= w0[i]; h *= 0x100000001b3ull; }
-      h ^= h >> 29; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 32;
-      size_t slot = h & (cap - 1);
-      while (table[slot].p && !(table[slot].hash == h && table[slot].len == wl && memcmp(table[slot].p, w0, wl) == 0))
-        slot = (slot + 1) & (cap - 1);
-      if (!table[slot].p) {
-        table[slot] = Slot{h, w0, wl, (uint32_t)freq.size()};
-        freq.push_back(1);
-        syms.insert(syms.end(), cps.begin(), cps.end());
-        woff.push_back(syms.size());
-        if (freq.size() * 2 > cap) grow();
-      } else {
-        uint32_t &f = freq[table[slot].index];
-        if (f == 0xFFFFFFFFu) return fail(SWT_ERR_UNSUPPORTED, "word frequency overflows 32 bits");
-        f++;
-      }
-    }
-  }
+  if (sent_off[0] != 0) return fail(SWT_ERR_INVALID, "sent_off[0] must be 0");
+  for (uint64_t s = 0; s < n_sent; s++)
+    if (sent_off[s] > sent_off[s + 1]) return fail(SWT_ERR_INVALID, "sentence offsets must be non-decreasing");
+  int rc = ensure_device();
+  if (rc) return rc;
+  const uint64_t n_bytes = sent_off[n_sent];
+  DevBuf d_text, d_off;
+  if ((rc = d_text.reserve(n_bytes + 64)) || (rc = d_off.reserve((n_sent + 1) * 8))) return rc;
+  if (n_bytes) SWT_HIP(hipMemcpy(d_text.p, text, n_bytes, hipMemcpyHostToDevice));
+  SWT_HIP(hipMemcpy(d_off.p, sent_off, (n_sent + 1) * 8, hipMemcpyHostToDevice));
+  DeviceWords dw;
+  rc = device_words_from_text(d_text.as<uint8_t>(), n_bytes, d_off.as<uint64_t>(), n_sent, &dw);
+  d_text.release();
+  d_off.release();
+  if (rc) return rc;
   auto *t = new swt_bpe_trainer();
-  int rc = trainer_upload(t, syms.data(), woff.data(), freq.data(), freq.size());
+  rc = trainer_adopt(t, dw);
   if (rc) { swt_bpe_train_destroy(t); return rc; }
   *out = t;
   return SWT_OK;

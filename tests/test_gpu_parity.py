@@ -402,6 +402,33 @@ def test_train_device_driven_run_equals_stepwise(dev, oracle, corpora):
     assert list(zip(l.tolist(), r.tolist(), c.tolist())) == [(97, 98, 2)]
 
 
+def test_train_device_word_census_edge_shapes(swt, oracle, dev, corpora):
+    """a1/a2 on the device (swt_words.hip): sentences longer than a chunk, words longer than a chunk, words of 255+ bytes
+    (never deduplicated: same merges), punctuation runs, multi-byte text, empty sentences"""
+    cases = [
+        (["słowo " * 400 + "koniec", "", "x", "słowo słowo"], 60),
+        (["ab" * 200 + " " + "ab" * 200 + " cd cd", "ab" * 200], 40),                 # 400-byte words, repeated
+        (["q" * 3000 + " q q", "q" * 3000], 12),                                      # one word longer than a chunk, twice
+        (["!!!???...,,, a,b;c", "(a)(b)(c)", "a-b-c-d " * 50], 30),
+        (["zażółć gęślą jaźń " * 60, "ŻÓŁĆ żółć", "中文 中文 字 字"], 50),
+        (corpora["pan"][:150] + ["", " ", "\t"], 200),
+    ]
+    for corpus, max_vocab in cases:
+        tok = swt.NaiveBPE()
+        tok.train(list(corpus), max_vocab)
+        orc = oracle.OracleBPETrainer(corpus)
+        orc.run(max_vocab)
+        assert tok.merges_list == orc.merges_list, corpus[0][:40]
+        assert len(tok.vocab) == orc.vocab_size
+    # the unique-word stream itself (first-occurrence order, frequencies, symbols) on ordinary text
+    sents = corpora["t5k"][:800]
+    text, off = dev.pack_utf8([s.lower() for s in sents])
+    tr = dev.BpeTrainer.from_text(text, off)
+    ds, dw, df = tr.export()
+    os_, ow, of = oracle.OracleBPETrainer(sents).export()
+    assert np.array_equal(ds, os_) and np.array_equal(dw, ow) and np.array_equal(df, of)
+
+
 def test_train_create_words_and_exhaustion(dev, oracle):
     """from an explicit word list; training to exhaustion stops with count == 0 (bpe.py:98-99)"""
     syms = np.array([ord(c) for c in "aaaabab"], dtype=np.uint32)
