@@ -13,6 +13,7 @@ from . import _build
 SYM_BASE = 0x110000
 BPE_CONT = 0x80000000
 BPE_RAW_WORDS = 1
+BPE_NO_DEDUP = 2
 WP_OK, WP_NONTERMINATING, WP_INDEXERROR = 0, 1, 2
 ERR_NO_DEVICE, ERR_INVALID, ERR_CAPACITY, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = -1, -2, -3, -4, -5, -6
 CLS_BERT_WS, CLS_BERT_PUNCT, CLS_PY_SPACE, CLS_PY_ALNUM = 1, 2, 4, 8
@@ -128,6 +129,10 @@ def device_count():
 
 def init(device=0):
     check(lib().swt_init(device))
+
+
+def debug_knob(which, value):
+    check(lib().swt_debug_knob(which, value))
 
 
 def profile_enable(on=True):

@@ -492,6 +492,452 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
   if (lane == 0) tile_tok[t] = run;
 }
 
+
+// ================================================================================================
+// Word-level dedup inside one call.  Natural text repeats its words (S85k: 1.5 M words, 83 k distinct), and
+// FastBPE.encode_word is a pure function of the word, so each distinct word is encoded once:
+//   wordref   one wave per tile: the word split of phase B/C, then one lane per word -- a single-symbol word is its own
+//             token; any other word is found or inserted in a global table (hash, then EXACT byte compare with the
+//             slot's representative occurrence; the inserter appends the word to a "unique words" text).  Every word
+//             start gets a 32-bit record (token, or table slot).
+//   encode    bpe_encode_kernel in raw-word mode over the unique words (each one is a "sentence")
+//   count / write   per tile: records -> token counts -> scan -> tokens copied from the unique words' results
+// Slots carry an 8-bit epoch, so the table is never cleared between calls.
+constexpr int kDTile = 1024;
+constexpr int kDCap = 2048;
+constexpr int kDBlocks = kDCap / 64;
+constexpr uint64_t kDedupMinBytes = 1u << 18;
+constexpr unsigned long long kDOffMask = (1ull << 40) - 1ull;
+constexpr uint32_t kRefSlot = 0x80000000u;
+
+typedef uint64_t u64u __attribute__((aligned(1)));  // unaligned 8-byte access (one global_load / ds_read on gfx950)
+
+struct DedupTab {
+  unsigned long long *slot;      // epoch:8 | tag:8 | byte length:8 | representative offset:40
+  unsigned long long *rec;       // per slot, filled after the unique words are encoded: token offset:40 | count:24
+  uint32_t *uslot;               // per unique word: its slot
+  uint64_t n_bytes;              // size of the text (wide compares stay inside it)
+  uint32_t count_cas;            // diagnostics: tally CAS successes / failures behind `overflow`
+  uint32_t bits;
+  uint32_t epoch;
+  unsigned long long *ucounter;  // unique words:28 | unique bytes:36, advanced by one atomicAdd per new word
+  uint8_t *utext;                // the unique words, concatenated
+  uint64_t *uoff;                // their offsets (monotone in uid because of the packed counter)
+  uint64_t utext_cap;
+  uint32_t max_uniq;
+  unsigned int *overflow;
+};
+
+// the same function as the wide form in dd_find_or_insert_lds, byte by byte (words in global memory)
+__device__ __forceinline__ unsigned long long dd_pack8(const uint8_t *p, uint32_t n) {
+  unsigned long long w = 0;
+  for (uint32_t i = 0; i < n && i < 8; i++) w |= (unsigned long long)p[i] << (8 * i);
+  return w;
+}
+__device__ __forceinline__ unsigned long long dd_hash(const uint8_t *p, uint32_t n) {
+  const unsigned long long w0 = dd_pack8(p, n), w1 = n > 8 ? dd_pack8(p + 8, n - 8) : 0ull;
+  unsigned long long h = (w0 ^ 0x9E3779B97F4A7C15ull) * 0xff51afd7ed558ccdull;
+  h ^= h >> 32;
+  h = (h ^ w1 ^ ((unsigned long long)n << 56)) * 0xc4ceb9fe1a85ec53ull;
+  for (uint32_t i = 16; i < n; i += 8) {
+    h ^= h >> 29;
+    h = (h ^ dd_pack8(p + i, n - i)) * 0x9E3779B97F4A7C15ull;
+  }
+  h ^= h >> 29; h *= 0x94d049bb133111ebull; h ^= h >> 32;
+  return h;
+}
+
+__device__ uint32_t dd_find_or_insert(const DedupTab &D, const uint8_t *__restrict__ text, const uint8_t *mine, uint32_t len,
+                                      uint64_t gpos) {
+  const unsigned long long h = dd_hash(mine, len);
+  const uint32_t mask = (1u << D.bits) - 1u;
+  const uint32_t lf = len < 255u ? len : 255u;
+  const unsigned long long head = ((unsigned long long)D.epoch << 56) | (((h >> 40) & 0xFFull) << 48) | ((unsigned long long)lf << 40);
+  uint32_t idx = (uint32_t)h & mask;
+  for (;;) {
+    unsigned long long v = __hip_atomic_load(&D.slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(v >> 56) != D.epoch) {  // free in this call (never used, or left over from an earlier call)
+      const unsigned long long prev = atomicCAS(&D.slot[idx], v, head | gpos);
+      if (prev == v) {
+        const unsigned long long old = atomicAdd(D.ucounter, (1ull << 36) | (unsigned long long)len);
+        const uint64_t u = old >> 36, boff = old & ((1ull << 36) - 1ull);
+        if (u < D.max_uniq && boff + len <= D.utext_cap) {
+          D.uoff[u] = boff;
+          D.uslot[u] = idx;
+          for (uint32_t i = 0; i < len; i++) D.utext[boff + i] = mine[i];
+        } else {
+          __hip_atomic_store(D.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return idx;
+      }
+      v = prev;
+      if ((uint32_t)(v >> 56) != D.epoch) continue;  // changed to another stale value?  look again
+    }
+    if (lf != 255u && (v & ~kDOffMask) == head) {
+      const uint8_t *rep = text + (v & kDOffMask);
+      bool same = true;
+      for (uint32_t i = 0; i < len; i++)
+        if (rep[i] != mine[i]) { same = false; break; }
+      if (same) return idx;
+    }
+    idx = (idx + 1) & mask;
+  }
+}
+
+// The common case: the word sits in LDS.  Its first 16 bytes are taken with two unaligned 8-byte reads, hashed as two
+// words, and compared with the representative's bytes by two unaligned global loads (one L2 trip), not byte by byte.
+__device__ __forceinline__ uint32_t dd_find_or_insert_lds(const DedupTab &D, const uint8_t *__restrict__ text, const uint8_t *mine,
+                                                          uint32_t len, uint64_t gpos, bool &is_new) {
+  is_new = false;
+  unsigned long long w0 = *reinterpret_cast<const u64u *>(mine), w1 = *reinterpret_cast<const u64u *>(mine + 8);
+  if (len < 8) { w0 &= (1ull << (8 * len)) - 1ull; w1 = 0; }
+  else if (len < 16) w1 &= (1ull << (8 * (len - 8))) - 1ull;
+  unsigned long long h = (w0 ^ 0x9E3779B97F4A7C15ull) * 0xff51afd7ed558ccdull;
+  h ^= h >> 32;
+  h = (h ^ w1 ^ ((unsigned long long)len << 56)) * 0xc4ceb9fe1a85ec53ull;
+  for (uint32_t i = 16; i < len; i += 8) {
+    unsigned long long wk = *reinterpret_cast<const u64u *>(mine + i);  // txt[] has 16 bytes of slack behind the chunk
+    if (len - i < 8) wk &= (1ull << (8 * (len - i))) - 1ull;
+    h ^= h >> 29;
+    h = (h ^ wk) * 0x9E3779B97F4A7C15ull;
+  }
+  h ^= h >> 29; h *= 0x94d049bb133111ebull; h ^= h >> 32;
+  const uint32_t mask = (1u << D.bits) - 1u;
+  const uint32_t lf = len < 255u ? len : 255u;
+  const unsigned long long head = ((unsigned long long)D.epoch << 56) | (((h >> 40) & 0xFFull) << 48) | ((unsigned long long)lf << 40);
+  uint32_t idx = (uint32_t)h & mask;
+  for (;;) {
+    unsigned long long v = __hip_atomic_load(&D.slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(v >> 56) != D.epoch) {  // free in this call (never used, or left over from an earlier call)
+      const unsigned long long prev = atomicCAS(&D.slot[idx], v, head | gpos);
+      if (D.count_cas) atomicAdd(&D.overflow[prev == v ? 1 : 2], 1u);
+      if (prev == v) {
+        is_new = true;  // registered by the caller, one atomic per wave (dd_register_wave)
+        return idx;
+      }
+      v = prev;
+      if ((uint32_t)(v >> 56) != D.epoch) continue;
+    }
+    if (lf != 255u && (v & ~kDOffMask) == head) {
+      const uint64_t ro = v & kDOffMask;
+      const uint8_t *rep = text + ro;
+      bool same;
+      if (ro + 16 <= D.n_bytes) {
+        unsigned long long r0 = *reinterpret_cast<const u64u *>(rep), r1 = *reinterpret_cast<const u64u *>(rep + 8);
+        if (len < 8) { r0 &= (1ull << (8 * len)) - 1ull; r1 = 0; }
+        else if (len < 16) r1 &= (1ull << (8 * (len - 8))) - 1ull;
+        same = r0 == w0 && r1 == w1;
+        for (uint32_t i = 16; i < len && same; i++) same = rep[i] == mine[i];
+      } else {
+        same = true;
+        for (uint32_t i = 0; i < len; i++)
+          if (rep[i] != mine[i]) { same = false; break; }
+      }
+      if (same) return idx;
+    }
+    idx = (idx + 1) & mask;
+  }
+}
+
+// The lanes of a wave that inserted a new word reserve their places in the unique-word list together: ONE returning
+// atomic per wave step on the packed counter (a single hot word serialises every returning atomic of the chip).
+// Must be called by all 64 lanes.
+__device__ __forceinline__ void dd_register_wave(const DedupTab &D, bool is_new, uint32_t idx, const uint8_t *mine, uint32_t len) {
+  const unsigned long long M = __ballot(is_new);
+  if (!M) return;
+  const int lane = threadIdx.x & 63;
+  uint32_t x = is_new ? len : 0u;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = __shfl_up(x, d);
+    if (lane >= d) x += y;
+  }
+  const uint32_t tot_len = __shfl(x, 63);
+  const uint32_t n_new = (uint32_t)__popcll(M);
+  unsigned long long old = 0;
+  if (lane == 0) old = atomicAdd(D.ucounter, ((unsigned long long)n_new << 36) | (unsigned long long)tot_len);
+  old = __shfl(old, 0);
+  if (is_new) {
+    const uint64_t u = (old >> 36) + __popcll(M & ((1ull << lane) - 1ull));
+    const uint64_t boff = (old & ((1ull << 36) - 1ull)) + (x - len);
+    if (u < D.max_uniq && boff + len <= D.utext_cap) {
+      D.uoff[u] = boff;
+      D.uslot[u] = idx;
+      for (uint32_t i = 0; i < len; i++) D.utext[boff + i] = mine[i];
+    } else {
+      __hip_atomic_store(D.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+struct WordrefLds {
+  __attribute__((aligned(16))) uint8_t txt[kDCap + 16];
+  uint16_t wl[kDCap];
+  unsigned long long sbits[kDBlocks + 1];
+  unsigned long long endm[kDBlocks + 1];
+  __attribute__((aligned(16))) uint8_t cls_lo[kClsLds];
+  uint64_t giant_end;
+};
+
+__global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restrict__ text, uint64_t n_bytes,
+                                                         const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
+                                                         const uint8_t *__restrict__ cls_tab, DedupTab D, uint32_t *__restrict__ wref,
+                                                         uint32_t dbg) {
+  __shared__ WordrefLds L;
+  const int lane = threadIdx.x;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const uint64_t t = blockIdx.x;
+  const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
+  if (s_lo == s_hi) return;
+  reinterpret_cast<uint4 *>(L.cls_lo)[lane] = reinterpret_cast<const uint4 *>(cls_tab)[lane];
+  const uint64_t span_base = sent_off[s_lo], span_end = sent_off[s_hi];
+  uint64_t s_next = s_lo;
+  uint64_t cb = span_base;
+  for (;;) {
+    const uint64_t abase = cb & ~15ull;
+    const uint32_t off0 = (uint32_t)(cb - abase);
+    const uint64_t avail = span_end - abase;
+    const bool last = avail <= (uint64_t)kDCap;
+    const uint32_t staged = last ? (uint32_t)avail : (uint32_t)kDCap;
+    const uint32_t nblk = (staged + 63) >> 6;
+    for (uint32_t c = lane * 16; c < staged; c += 64 * 16) {
+      const uint64_t g = abase + c;
+      if (g + 16 <= n_bytes && ((reinterpret_cast<uintptr_t>(text + g) & 15) == 0)) {
+        *reinterpret_cast<uint4 *>(&L.txt[c]) = *reinterpret_cast<const uint4 *>(text + g);
+      } else {
+        for (int i = 0; i < 16; i++) L.txt[c + i] = (g + i < n_bytes) ? text[g + i] : (uint8_t)' ';
+      }
+    }
+    if (lane <= kDBlocks) L.sbits[lane] = 0ull;
+    __syncthreads();
+    for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
+      const uint64_t o = sent_off[s];
+      if (o >= abase + staged) break;
+      if (o >= cb) atomicOr(&L.sbits[(o - abase) >> 6], 1ull << ((o - abase) & 63));
+    }
+    __syncthreads();
+    uint32_t nw = 0;
+    bool prev_wb = true;
+    int cut = -1;
+    for (uint32_t blk = 0; blk < nblk; blk++) {
+      const uint32_t p = blk * 64 + lane;
+      const bool inr = p >= off0 && p < staged;
+      const uint8_t b = inr ? L.txt[p] : (uint8_t)' ';
+      const bool lead = !utf8_is_cont(b);
+      uint32_t cp = b;
+      if (b >= 0xC0) {
+        int len = utf8_len(b);
+        if (p + len > staged) len = (int)(staged - p);
+        if (len > 1) {
+          cp = b & (0xFF >> (len + 1));
+          for (int i = 1; i < len; i++) cp = (cp << 6) | (L.txt[p + i] & 0x3F);
+        }
+      }
+      uint8_t c = kClsWs;
+      if (inr && lead) c = cp < (uint32_t)kClsLds ? L.cls_lo[cp] : (cp < kNumCodePoints ? cls_tab[cp] : (uint8_t)0);
+      const unsigned long long INR = __ballot(inr);
+      const unsigned long long LEAD = __ballot(lead);
+      const unsigned long long WSm = __ballot(lead && (c & kClsWs));
+      const unsigned long long PNm = __ballot(lead && (c & kClsPunct));
+      const unsigned long long CONT = ~LEAD;
+      unsigned long long WB = WSm | PNm | ((prev_wb && (CONT & 1ull)) ? 1ull : 0ull);
+      WB |= (WB << 1) & CONT;
+      WB |= (WB << 1) & CONT;
+      WB |= (WB << 1) & CONT;
+      const unsigned long long SS = L.sbits[blk];
+      const unsigned long long first_bit = blk == 0 ? (1ull << off0) : 0ull;
+      const unsigned long long before = (WB << 1) | (prev_wb ? 1ull : 0ull) | SS | first_bit;
+      const unsigned long long SYM = LEAD & ~WSm & INR;
+      const unsigned long long WSTART = SYM & (PNm | before);
+      const unsigned long long CUT = LEAD & (WSm | PNm | SS) & __ballot(inr && p > off0 && p + 4 <= staged);
+      if (CUT) cut = (int)(blk * 64 + 63 - __builtin_clzll(CUT));
+      if (lane == 0) L.endm[blk] = WSm | WSTART | ~INR;
+      if ((WSTART >> lane) & 1ull) L.wl[nw + __popcll(WSTART & lt)] = (uint16_t)p;
+      nw += __popcll(WSTART);
+      if (inr) wref[abase + p] = kInvalidTok;  // word starts are overwritten below (same wave: stores stay in order)
+      prev_wb = (WB >> 63) & 1ull;
+    }
+    __syncthreads();
+    uint32_t ce = staged;
+    if (!last) {
+      if (cut < 0) {
+        // a single word longer than the chunk (or a lone separator in front of one): one lane, global memory
+        if (lane == 0) {
+          uint64_t s = s_next;
+          while (s < s_hi && sent_off[s] <= cb) s++;
+          const uint64_t send = sent_off[s];
+          uint64_t e = cb;
+          bool first = true, has_word = true;
+          uint32_t nchar = 0, cp0 = 0;
+          while (e < send) {
+            const uint8_t b = text[e];
+            int len = utf8_len(b);
+            if (e + len > send) len = (int)(send - e);
+            uint32_t cp = b;
+            if (b >= 0x80 && len > 1) {
+              cp = b & (0xFF >> (len + 1));
+              for (int i = 1; i < len; i++) cp = (cp << 6) | (text[e + i] & 0x3F);
+            }
+            const uint8_t c = utf8_is_cont(b) ? kClsWs : (cp < kNumCodePoints ? cls_tab[cp] : (uint8_t)0);
+            if (c & kClsWs) { if (first) { e += len; has_word = false; } break; }
+            if (c & kClsPunct) { if (first) { e += len; nchar = 1; cp0 = cp; } break; }
+            if (first) cp0 = cp;
+            nchar++;
+            e += len;
+            first = false;
+          }
+          for (uint64_t g = cb; g < e; g++) wref[g] = kInvalidTok;
+          if (has_word && e > cb)
+            wref[cb] = nchar == 1 ? cp0 : (kRefSlot | dd_find_or_insert(D, text, text + cb, (uint32_t)(e - cb), cb));
+          L.giant_end = e;
+        }
+        __syncthreads();
+        cb = L.giant_end;
+        uint32_t gone = 0;
+        for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
+          if (sent_off[s] >= cb) break;
+          gone++;
+        }
+        for (int d = 32; d >= 1; d >>= 1) gone += __shfl_xor(gone, d);
+        s_next += gone;
+        __syncthreads();
+        if (cb >= span_end) break;
+        continue;
+      }
+      ce = (uint32_t)cut;
+    }
+    // one lane per word
+    if (!(dbg & 1))
+    for (uint32_t k0 = 0; k0 < nw; k0 += 64) {
+      const uint32_t k = k0 + lane;
+      const uint32_t s = k < nw ? L.wl[k] : 0xFFFFu;
+      const bool mine_w = k < nw && s < ce;
+      bool is_new = false;
+      uint32_t idx = 0, wlen = 0;
+      if (mine_w) {
+        uint32_t w = s >> 6;
+        unsigned long long m = (s & 63) == 63 ? 0ull : (L.endm[w] & ~((2ull << (s & 63)) - 1ull));
+        while (!m && w + 1 < nblk) m = L.endm[++w];
+        uint32_t e = m ? w * 64 + (uint32_t)__builtin_ctzll(m) : ce;
+        if (e > ce) e = ce;
+        wlen = e - s;
+        const uint8_t b0 = L.txt[s];
+        const uint32_t l0 = (uint32_t)utf8_len(b0);
+        uint32_t r;
+        if (wlen <= l0 || (dbg & 2)) {  // a single symbol: it is its own token
+          uint32_t cp = b0;
+          if (b0 >= 0xC0 && wlen > 1) {
+            cp = b0 & (0xFF >> (wlen + 1));
+            for (uint32_t i = 1; i < wlen; i++) cp = (cp << 6) | (L.txt[s + i] & 0x3F);
+          }
+          r = cp;
+        } else {
+          idx = dd_find_or_insert_lds(D, text, &L.txt[s], wlen, abase + s, is_new);
+          r = kRefSlot | idx;
+        }
+        wref[abase + s] = r;
+      }
+      dd_register_wave(D, is_new, idx, &L.txt[mine_w ? s : 0], wlen);
+    }
+    if (last) break;
+    cb = abase + ce;
+    uint32_t gone = 0;
+    for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
+      if (sent_off[s] >= cb) break;
+      gone++;
+    }
+    for (int d = 32; d >= 1; d >>= 1) gone += __shfl_xor(gone, d);
+    s_next += gone;
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ uint32_t ref_count(uint32_t v, const unsigned long long *__restrict__ rec, uint64_t &src) {
+  src = 0;
+  if (v == kInvalidTok) return 0;
+  if (!(v & kRefSlot)) return 1;
+  const unsigned long long r = rec[v & ~kRefSlot];
+  src = r & kDOffMask;
+  return (uint32_t)(r >> 40);
+}
+
+// after the unique words are encoded: their (token offset, count) goes to their table slot
+__global__ void bpe_urec_kernel(const uint32_t *__restrict__ uslot, const uint64_t *__restrict__ u_off, uint64_t n_uniq,
+                                unsigned long long *__restrict__ rec) {
+  const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < n_uniq) rec[uslot[u]] = (unsigned long long)u_off[u] | ((unsigned long long)(u_off[u + 1] - u_off[u]) << 40);
+}
+
+// tokens per tile (the records of a tile's span are contiguous in wref)
+__global__ __launch_bounds__(64) void bpe_refcount_kernel(const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
+                                                          const uint32_t *__restrict__ wref, const unsigned long long *__restrict__ rec,
+                                                          uint32_t *__restrict__ tile_tok) {
+  const uint64_t t = blockIdx.x;
+  const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
+  uint32_t total = 0;
+  if (s_lo != s_hi) {
+    const uint64_t a = sent_off[s_lo], b = sent_off[s_hi];
+    for (uint64_t g = a + threadIdx.x; g < b; g += 64) {
+      uint64_t src;
+      total += ref_count(wref[g], rec, src);
+    }
+    for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
+  }
+  if (threadIdx.x == 0) tile_tok[t] = total;
+}
+
+// final tokens + sentence offsets
+__global__ __launch_bounds__(64) void bpe_refwrite_kernel(const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
+                                                          uint64_t n_tiles, uint64_t n_sent, const uint32_t *__restrict__ wref,
+                                                          const unsigned long long *__restrict__ rec,
+                                                          const uint32_t *__restrict__ u_ids, const uint32_t *__restrict__ tile_base,
+                                                          const unsigned long long *__restrict__ blk_base,
+                                                          const uint64_t *__restrict__ n_tokens, uint32_t *__restrict__ out_ids,
+                                                          uint64_t *__restrict__ out_off) {
+  __shared__ uint32_t pre[kDCap];
+  const int lane = threadIdx.x;
+  const uint64_t t = blockIdx.x;
+  const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
+  if (t == n_tiles - 1 && lane == 0) out_off[n_sent] = *n_tokens;
+  if (s_lo == s_hi) return;
+  const uint64_t base = blk_base[t >> 10] + tile_base[t];
+  const uint64_t a = sent_off[s_lo], b = sent_off[s_hi];
+  uint64_t s_next = s_lo;
+  uint32_t run = 0;
+  for (uint64_t c0 = a; c0 < b || c0 == a; c0 += kDCap) {
+    const uint64_t c1 = c0 + kDCap < b ? c0 + kDCap : b;
+    for (uint64_t g0 = c0; g0 < c1; g0 += 64) {
+      const uint64_t g = g0 + lane;
+      uint64_t src = 0;
+      const uint32_t v = g < c1 ? wref[g] : kInvalidTok;
+      const uint32_t n = ref_count(v, rec, src);
+      uint32_t x = n;
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+      }
+      const uint32_t ex = run + x - n;
+      if (g < c1) pre[g - c0] = ex;
+      if (n == 1 && !(v & kRefSlot)) out_ids[base + ex] = v;
+      else for (uint32_t j = 0; j < n; j++) out_ids[base + ex + j] = u_ids[src + j];
+      run += __shfl(x, 63);
+    }
+    __syncthreads();
+    // sentences that start inside [c0, c1) -- and at b itself on the last chunk
+    const bool lastc = c1 == b;
+    uint32_t mine = 0;
+    for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
+      const uint64_t o = sent_off[s];
+      if (o > c1 || (o == c1 && !lastc)) break;
+      out_off[s] = base + (o < c1 ? pre[o - c0] : run);
+      mine++;
+    }
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    s_next += mine;
+    __syncthreads();
+    if (lastc) break;
+  }
+}
+
 }  // namespace swt
 
 using namespace swt;
@@ -506,6 +952,11 @@ struct swt_bpe_table {
   uint32_t n_merges = 0;
   TileWorkspace ws;
   DevBuf in_text, in_off, out_ids, out_off, n_tok;  // staging for the host-buffer entry point
+  // word-level dedup inside one call
+  TileWorkspace ws2;          // workspaces of the encode over the unique words
+  DevBuf dd_slot, dd_rec, dd_uslot, dd_utext, dd_uoff, dd_uids, dd_uout_off, dd_misc;
+  uint32_t dd_bits = 0, dd_epoch = 0;
+  uint64_t dd_h_ubytes = 0;
 };
 
 static int bpe_upload(swt_bpe_table *t) {
@@ -572,8 +1023,122 @@ void swt_bpe_table_destroy(swt_bpe_table *t) {
   if (t->d_slots) (void)hipFree(t->d_slots);
   if (t->d_merged) (void)hipFree(t->d_merged);
   t->ws.release();
-  for (DevBuf *b : {&t->in_text, &t->in_off, &t->out_ids, &t->out_off, &t->n_tok}) b->release();
+  t->ws2.release();
+  for (DevBuf *b : {&t->in_text, &t->in_off, &t->out_ids, &t->out_off, &t->n_tok, &t->dd_slot, &t->dd_rec, &t->dd_uslot, &t->dd_utext, &t->dd_uoff,
+                    &t->dd_uids, &t->dd_uout_off, &t->dd_misc})
+    b->release();
   delete t;
+}
+
+// the direct path: every word occurrence goes through the merge rounds
+static int bpe_encode_direct(swt_bpe_table *t, TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off,
+                             uint64_t n_sent, uint32_t *d_out_ids, uint64_t *d_out_off, uint64_t *d_n_tokens, const uint8_t *d_cls,
+                             bool timed, hipStream_t st) {
+  const uint64_t n_tiles = tile_count(n_bytes, kBpeTile);
+  if (n_tiles > 0x7FFFFFFFull)
+    return fail(SWT_ERR_UNSUPPORTED, "text too large for one call (%llu bytes)", (unsigned long long)n_bytes);
+  int rc;
+  if ((rc = ws.reserve(n_bytes, n_sent, n_tiles))) return rc;
+  launch_plan(d_sent_off, n_sent, n_tiles, kBpeTile, ws.plan.as<uint64_t>(), st);
+  if (timed) prof_begin(st);
+  if (t->packed)
+    hipLaunchKernelGGL(bpe_encode_kernel<true>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
+                       ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, ws.scratch.as<uint32_t>(),
+                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), (uint32_t)debug_knob(0));
+  else
+    hipLaunchKernelGGL(bpe_encode_kernel<false>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
+                       ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, ws.scratch.as<uint32_t>(),
+                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), (uint32_t)debug_knob(0));
+  if (timed) prof_end(st);
+  launch_scan_gather(d_sent_off, n_sent, n_tiles, ws, d_out_ids, d_out_off, d_n_tokens, st);
+  SWT_HIP(hipGetLastError());
+  return SWT_OK;
+}
+
+// the dedup path; returns 1 when the caller should fall back to the direct path (table or unique-word buffers too small)
+static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off, uint64_t n_sent,
+                            uint32_t *d_out_ids, uint64_t *d_out_off, uint64_t *d_n_tokens, const uint8_t *d_cls, hipStream_t st) {
+  int rc;
+  const uint64_t n_tiles = tile_count(n_bytes, kDTile);
+  if (n_tiles > 0x7FFFFFFFull || n_bytes > (1ull << 30)) return 1;  // larger batches: direct path
+  if ((rc = t->ws.reserve(n_bytes, n_sent, n_tiles))) return rc;
+  // table: one slot per two bytes of text is always enough (a tabled word has at least two bytes); never cleared
+  uint32_t bits = 16;
+  while ((1ull << bits) < n_bytes + 16 && bits < 30) bits++;
+  if (bits > t->dd_bits) {
+    t->dd_slot.release();
+    t->dd_rec.release();
+    if ((rc = t->dd_slot.reserve(((size_t)1 << bits) * 8)) || (rc = t->dd_rec.reserve(((size_t)1 << bits) * 8))) return rc;
+    SWT_HIP(hipMemsetAsync(t->dd_slot.p, 0, ((size_t)1 << bits) * 8, st));
+    t->dd_bits = bits;
+    t->dd_epoch = 0;
+  }
+  if (++t->dd_epoch >= 256) {
+    SWT_HIP(hipMemsetAsync(t->dd_slot.p, 0, ((size_t)1 << t->dd_bits) * 8, st));
+    t->dd_epoch = 1;
+  }
+  const uint64_t max_uniq = n_bytes / 2 + 2;
+  if ((rc = t->dd_utext.reserve(n_bytes + 64)) || (rc = t->dd_uoff.reserve((max_uniq + 2) * 8)) || (rc = t->dd_misc.reserve(64)) ||
+      (rc = t->dd_uslot.reserve((max_uniq + 2) * 4)))
+    return rc;
+  unsigned long long *d_counter = t->dd_misc.as<unsigned long long>();
+  SWT_HIP(hipMemsetAsync(d_counter, 0, 32, st));
+  DedupTab D;
+  D.slot = t->dd_slot.as<unsigned long long>();
+  D.rec = t->dd_rec.as<unsigned long long>();
+  D.uslot = t->dd_uslot.as<uint32_t>();
+  D.n_bytes = n_bytes;
+  D.count_cas = (debug_knob(2) & 4) ? 1u : 0u;
+  D.bits = t->dd_bits;
+  D.epoch = t->dd_epoch;
+  D.ucounter = d_counter;
+  D.utext = t->dd_utext.as<uint8_t>();
+  D.uoff = t->dd_uoff.as<uint64_t>();
+  D.utext_cap = n_bytes;
+  D.max_uniq = (uint32_t)(max_uniq < (1u << 28) - 1 ? max_uniq : (1u << 28) - 1);
+  D.overflow = reinterpret_cast<unsigned int *>(d_counter + 1);
+  uint32_t *wref = t->ws.scratch.as<uint32_t>();
+  launch_plan(d_sent_off, n_sent, n_tiles, kDTile, t->ws.plan.as<uint64_t>(), st);
+  prof_begin(st);
+  hipLaunchKernelGGL(bpe_wordref_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
+                     t->ws.plan.as<uint64_t>(), d_cls, D, wref, (uint32_t)debug_knob(2));
+  prof_end(st);
+  unsigned long long h_misc[2] = {0, 0};
+  SWT_HIP(hipMemcpyAsync(h_misc, d_counter, 16, hipMemcpyDeviceToHost, st));
+  SWT_HIP(hipStreamSynchronize(st));
+  if (D.count_cas) {
+    unsigned int c[4];
+    SWT_HIP(hipMemcpy(c, d_counter + 1, 16, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[swt] dedup CAS: %u inserted, %u lost to another lane; uniques %llu\n", c[1], c[2], h_misc[0] >> 36);
+  }
+  if ((unsigned int)h_misc[1]) return 1;
+  const uint64_t n_uniq = h_misc[0] >> 36, ubytes = h_misc[0] & ((1ull << 36) - 1ull);
+  t->dd_h_ubytes = ubytes;  // lives in the handle: the copy below may run after this function returns
+  SWT_HIP(hipMemcpyAsync(t->dd_uoff.as<uint64_t>() + n_uniq, &t->dd_h_ubytes, 8, hipMemcpyHostToDevice, st));
+  // encode the unique words once (raw-word mode: each one is a "sentence")
+  if ((rc = t->dd_uids.reserve((ubytes + 64) * 4)) || (rc = t->dd_uout_off.reserve((n_uniq + 2) * 8))) return rc;
+  uint64_t *d_ntok2 = reinterpret_cast<uint64_t *>(d_counter + 2);
+  if (n_uniq) {
+    if ((rc = bpe_encode_direct(t, t->ws2, t->dd_utext.as<uint8_t>(), ubytes, t->dd_uoff.as<uint64_t>(), n_uniq,
+                                t->dd_uids.as<uint32_t>(), t->dd_uout_off.as<uint64_t>(), d_ntok2, nullptr, false, st)))
+      return rc;
+  } else {
+    SWT_HIP(hipMemsetAsync(t->dd_uout_off.p, 0, 16, st));
+  }
+  // records -> counts -> scan -> tokens
+  if (n_uniq)
+    hipLaunchKernelGGL(bpe_urec_kernel, dim3((unsigned)((n_uniq + 255) / 256)), dim3(256), 0, st, D.uslot, t->dd_uout_off.as<uint64_t>(),
+                       n_uniq, D.rec);
+  hipLaunchKernelGGL(bpe_refcount_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, t->ws.plan.as<uint64_t>(), wref,
+                     D.rec, t->ws.tile_tok.as<uint32_t>());
+  const uint64_t nb = (n_tiles + 1023) / 1024;
+  unsigned long long *bb = t->ws.blk.as<unsigned long long>();
+  launch_scan_only(n_tiles, t->ws, d_n_tokens, st);
+  hipLaunchKernelGGL(bpe_refwrite_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, t->ws.plan.as<uint64_t>(), n_tiles,
+                     n_sent, wref, D.rec, t->dd_uids.as<uint32_t>(), t->ws.tile_base.as<uint32_t>(),
+                     bb + 1 + nb, d_n_tokens, d_out_ids, d_out_off);
+  SWT_HIP(hipGetLastError());
+  return SWT_OK;
 }
 
 int swt_bpe_encode_dev(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off,
@@ -586,30 +1151,19 @@ int swt_bpe_encode_dev(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes
   hipStream_t st = (hipStream_t)stream;
   const uint8_t *d_cls = nullptr;
   if ((rc = device_class_table(&d_cls))) return rc;
-  if (flags & SWT_BPE_RAW_WORDS) d_cls = nullptr;  // no classes: nothing splits, nothing is dropped
-  const uint64_t n_tiles = tile_count(n_bytes, kBpeTile);
-  if (n_tiles > 0x7FFFFFFFull)
-    return fail(SWT_ERR_UNSUPPORTED, "text too large for one call (%llu bytes)", (unsigned long long)n_bytes);
-  if ((rc = t->ws.reserve(n_bytes, n_sent, n_tiles))) return rc;
   if (n_sent == 0) {
     SWT_HIP(hipMemsetAsync(d_out_off, 0, 8, st));
     SWT_HIP(hipMemsetAsync(d_n_tokens, 0, 8, st));
     return SWT_OK;
   }
-  launch_plan(d_sent_off, n_sent, n_tiles, kBpeTile, t->ws.plan.as<uint64_t>(), st);
-  prof_begin(st);
-  if (t->packed)
-    hipLaunchKernelGGL(bpe_encode_kernel<true>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
-                       t->ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, t->ws.scratch.as<uint32_t>(),
-                       t->ws.sent_local.as<uint32_t>(), t->ws.tile_tok.as<uint32_t>(), (uint32_t)debug_knob(0));
-  else
-    hipLaunchKernelGGL(bpe_encode_kernel<false>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
-                       t->ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, t->ws.scratch.as<uint32_t>(),
-                       t->ws.sent_local.as<uint32_t>(), t->ws.tile_tok.as<uint32_t>(), (uint32_t)debug_knob(0));
-  prof_end(st);
-  launch_scan_gather(d_sent_off, n_sent, n_tiles, t->ws, d_out_ids, d_out_off, d_n_tokens, st);
-  SWT_HIP(hipGetLastError());
-  return SWT_OK;
+  const bool raw = (flags & SWT_BPE_RAW_WORDS) != 0;
+  // debug knob 1: bit 0 = never dedup, bit 1 = dedup whatever the batch size (tests)
+  if (!raw && !(flags & SWT_BPE_NO_DEDUP) && (n_bytes >= kDedupMinBytes || (debug_knob(1) & 2)) && !(debug_knob(1) & 1)) {
+    rc = bpe_encode_dedup(t, d_text, n_bytes, d_sent_off, n_sent, d_out_ids, d_out_off, d_n_tokens, d_cls, st);
+    if (rc <= 0) return rc;  // done, or a real error
+  }
+  // raw-word mode: no classes, so nothing splits and nothing is dropped
+  return bpe_encode_direct(t, t->ws, d_text, n_bytes, d_sent_off, n_sent, d_out_ids, d_out_off, d_n_tokens, raw ? nullptr : d_cls, true, st);
 }
 
 int swt_bpe_encode(swt_bpe_table *t, const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, uint32_t *out_ids,

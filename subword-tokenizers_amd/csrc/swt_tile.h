@@ -126,6 +126,7 @@ inline uint64_t tile_count(uint64_t n_bytes, uint32_t tile = kTile) { return n_b
 
 // Host launchers of the skeleton's own kernels (defined in swt_tile.hip).
 void launch_plan(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, uint32_t tile, uint64_t *d_plan, hipStream_t st);
+void launch_scan_only(uint64_t n_tiles, const TileWorkspace &ws, uint64_t *d_n_tokens, hipStream_t st);
 void launch_scan_gather(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, const TileWorkspace &ws,
                         uint32_t *d_out_ids, uint64_t *d_out_off, uint64_t *d_n_tokens, hipStream_t st);
 

@@ -114,6 +114,13 @@ void launch_plan(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, 
   hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n_tiles + 1 + 255) / 256)), dim3(256), 0, st, d_sent_off, n_sent, n_tiles, tile, d_plan);
 }
 
+void launch_scan_only(uint64_t n_tiles, const TileWorkspace &ws, uint64_t *d_n_tokens, hipStream_t st) {
+  const uint64_t nb = (n_tiles + 1023) / 1024;
+  unsigned long long *b = ws.blk.as<unsigned long long>();
+  hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)nb), dim3(1024), 0, st, ws.tile_tok.as<uint32_t>(), n_tiles,
+                     ws.tile_base.as<uint32_t>(), b + 1, b + 1 + nb, reinterpret_cast<unsigned int *>(b), d_n_tokens);
+}
+
 void launch_scan_gather(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, const TileWorkspace &ws,
                         uint32_t *d_out_ids, uint64_t *d_out_off, uint64_t *d_n_tokens, hipStream_t st) {
   const uint64_t nb = (n_tiles + 1023) / 1024;

@@ -118,6 +118,30 @@ def test_bpe_edge_shapes(bpe, bpe_orc):
         same_bpe(bpe, bpe_orc, texts)
 
 
+def test_bpe_dedup_path_equals_direct_path(bpe, bpe_orc, dev, corpora):
+    """word-level dedup inside a call (default for batches >= 256 KiB) and the direct path give the same ids"""
+    cases = [
+        [], [""], ["", "a", "", "b", ""], ["!" * 5000], ["słowo " * 3000], ["x" * 20000], ["ab" * 6000 + " " + "nie " * 10],
+        ["ż" * 3000 + " koniec"], ["q" * 300 + " " + "q" * 300, "q" * 300],          # 255+-byte words are never matched
+        ["a" * 4095, "b" * 4096, "c" * 4097, "d" * 2047, "e" * 2048, "f" * 2049, "g" * 1023, "h" * 1024, "i" * 1025],
+        ["wyraz"] * 3000, corpora["pan"][:400], ["\U0001F600 emoji \U0001F600\U0001F601 x", "中文 字", "İstanbul", "a\x00b"],
+    ]
+    try:
+        dev.debug_knob(1, 2)  # dedup whatever the size
+        for texts in cases:
+            same_bpe(bpe, bpe_orc, texts)
+        ids_d, off_d = bpe.encode_ids_batch(corpora["t5k"])
+        dev.debug_knob(1, 1)  # never dedup
+        ids_n, off_n = bpe.encode_ids_batch(corpora["t5k"])
+    finally:
+        dev.debug_knob(1, 0)
+    assert np.array_equal(ids_d, ids_n) and np.array_equal(off_d, off_n)
+    # calling again reuses the table under a new epoch
+    for _ in range(3):
+        ids_e, off_e = bpe.encode_ids_batch(corpora["t5k"])
+        assert np.array_equal(ids_e, ids_n) and np.array_equal(off_e, off_n)
+
+
 def test_bpe_ragged_random_batches(bpe, bpe_orc, corpora):
     rng = np.random.default_rng(7)
     pool = corpora["t5k"] + corpora["pan"] + ["", " ", "x" * 5000, "ala, ma! kota?"]
