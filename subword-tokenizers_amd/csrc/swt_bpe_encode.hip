@@ -515,18 +515,18 @@ typedef uint64_t u64u __attribute__((aligned(1)));  // unaligned 8-byte access (
 struct DedupTab {
   unsigned long long *slot;      // epoch:8 | tag:8 | byte length:8 | representative offset:40
   unsigned long long *rec;       // per slot, filled after the unique words are encoded: token offset:40 | count:24
-  uint32_t *uslot;               // per unique word: its slot
   uint64_t n_bytes;              // size of the text (wide compares stay inside it)
-  uint32_t count_cas;            // diagnostics: tally CAS successes / failures behind `overflow`
+  uint32_t diag;                 // diagnostics: bit 0 tallies CAS successes / failures behind `overflow`
   uint32_t bits;
   uint32_t epoch;
-  unsigned long long *ucounter;  // unique words:28 | unique bytes:36, advanced by one atomicAdd per new word
-  uint8_t *utext;                // the unique words, concatenated
-  uint64_t *uoff;                // their offsets (monotone in uid because of the packed counter)
-  uint64_t utext_cap;
-  uint32_t max_uniq;
+  // New words are NOT numbered with a global counter (one hot address serialises every returning atomic of the chip:
+  // that alone cost 170 us of a 230 us kernel).  The tile that inserted a word lists it; a scan over the tiles'
+  // (count, bytes) numbers the words afterwards (bpe_ureg_kernel).
+  unsigned long long *newlist;   // byte length:24 | position:40; the entries of a tile start at [span_base >> 1]
+  unsigned long long *tile_new;  // per tile: new words:28 | their bytes:36
   unsigned int *overflow;
 };
+constexpr uint32_t kDMaxWordBytes = (1u << 24) - 1u;
 
 // the same function as the wide form in dd_find_or_insert_lds, byte by byte (words in global memory)
 __device__ __forceinline__ unsigned long long dd_pack8(const uint8_t *p, uint32_t n) {
@@ -548,7 +548,8 @@ __device__ __forceinline__ unsigned long long dd_hash(const uint8_t *p, uint32_t
 }
 
 __device__ uint32_t dd_find_or_insert(const DedupTab &D, const uint8_t *__restrict__ text, const uint8_t *mine, uint32_t len,
-                                      uint64_t gpos) {
+                                      uint64_t gpos, bool &is_new) {
+  is_new = false;
   const unsigned long long h = dd_hash(mine, len);
   const uint32_t mask = (1u << D.bits) - 1u;
   const uint32_t lf = len < 255u ? len : 255u;
@@ -559,15 +560,7 @@ __device__ uint32_t dd_find_or_insert(const DedupTab &D, const uint8_t *__restri
     if ((uint32_t)(v >> 56) != D.epoch) {  // free in this call (never used, or left over from an earlier call)
       const unsigned long long prev = atomicCAS(&D.slot[idx], v, head | gpos);
       if (prev == v) {
-        const unsigned long long old = atomicAdd(D.ucounter, (1ull << 36) | (unsigned long long)len);
-        const uint64_t u = old >> 36, boff = old & ((1ull << 36) - 1ull);
-        if (u < D.max_uniq && boff + len <= D.utext_cap) {
-          D.uoff[u] = boff;
-          D.uslot[u] = idx;
-          for (uint32_t i = 0; i < len; i++) D.utext[boff + i] = mine[i];
-        } else {
-          __hip_atomic_store(D.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        is_new = true;
         return idx;
       }
       v = prev;
@@ -610,9 +603,9 @@ __device__ __forceinline__ uint32_t dd_find_or_insert_lds(const DedupTab &D, con
     unsigned long long v = __hip_atomic_load(&D.slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((uint32_t)(v >> 56) != D.epoch) {  // free in this call (never used, or left over from an earlier call)
       const unsigned long long prev = atomicCAS(&D.slot[idx], v, head | gpos);
-      if (D.count_cas) atomicAdd(&D.overflow[prev == v ? 1 : 2], 1u);
+      if (D.diag & 1u) atomicAdd(&D.overflow[prev == v ? 1 : 2], 1u);
       if (prev == v) {
-        is_new = true;  // registered by the caller, one atomic per wave (dd_register_wave)
+        is_new = true;  // listed by the caller
         return idx;
       }
       v = prev;
@@ -639,36 +632,6 @@ __device__ __forceinline__ uint32_t dd_find_or_insert_lds(const DedupTab &D, con
   }
 }
 
-// The lanes of a wave that inserted a new word reserve their places in the unique-word list together: ONE returning
-// atomic per wave step on the packed counter (a single hot word serialises every returning atomic of the chip).
-// Must be called by all 64 lanes.
-__device__ __forceinline__ void dd_register_wave(const DedupTab &D, bool is_new, uint32_t idx, const uint8_t *mine, uint32_t len) {
-  const unsigned long long M = __ballot(is_new);
-  if (!M) return;
-  const int lane = threadIdx.x & 63;
-  uint32_t x = is_new ? len : 0u;
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t y = __shfl_up(x, d);
-    if (lane >= d) x += y;
-  }
-  const uint32_t tot_len = __shfl(x, 63);
-  const uint32_t n_new = (uint32_t)__popcll(M);
-  unsigned long long old = 0;
-  if (lane == 0) old = atomicAdd(D.ucounter, ((unsigned long long)n_new << 36) | (unsigned long long)tot_len);
-  old = __shfl(old, 0);
-  if (is_new) {
-    const uint64_t u = (old >> 36) + __popcll(M & ((1ull << lane) - 1ull));
-    const uint64_t boff = (old & ((1ull << 36) - 1ull)) + (x - len);
-    if (u < D.max_uniq && boff + len <= D.utext_cap) {
-      D.uoff[u] = boff;
-      D.uslot[u] = idx;
-      for (uint32_t i = 0; i < len; i++) D.utext[boff + i] = mine[i];
-    } else {
-      __hip_atomic_store(D.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 struct WordrefLds {
   __attribute__((aligned(16))) uint8_t txt[kDCap + 16];
   uint16_t wl[kDCap];
@@ -676,6 +639,7 @@ struct WordrefLds {
   unsigned long long endm[kDBlocks + 1];
   __attribute__((aligned(16))) uint8_t cls_lo[kClsLds];
   uint64_t giant_end;
+  uint32_t giant_new;
 };
 
 __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restrict__ text, uint64_t n_bytes,
@@ -687,11 +651,17 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
   const unsigned long long lt = (1ull << lane) - 1ull;
   const uint64_t t = blockIdx.x;
   const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
-  if (s_lo == s_hi) return;
+  if (s_lo == s_hi) {
+    if (lane == 0) D.tile_new[t] = 0ull;
+    return;
+  }
   reinterpret_cast<uint4 *>(L.cls_lo)[lane] = reinterpret_cast<const uint4 *>(cls_tab)[lane];
   const uint64_t span_base = sent_off[s_lo], span_end = sent_off[s_hi];
   uint64_t s_next = s_lo;
   uint64_t cb = span_base;
+  unsigned long long *const my_list = D.newlist + (span_base >> 1);  // room for one entry per two bytes of the span
+  uint32_t n_new = 0;            // wave-uniform
+  unsigned long long my_bytes = 0;  // per lane, summed at the end
   for (;;) {
     const uint64_t abase = cb & ~15ull;
     const uint32_t off0 = (uint32_t)(cb - abase);
@@ -786,12 +756,27 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
             first = false;
           }
           for (uint64_t g = cb; g < e; g++) wref[g] = kInvalidTok;
-          if (has_word && e > cb)
-            wref[cb] = nchar == 1 ? cp0 : (kRefSlot | dd_find_or_insert(D, text, text + cb, (uint32_t)(e - cb), cb));
+          L.giant_new = 0;
+          if (has_word && e > cb) {
+            if (nchar == 1) {
+              wref[cb] = cp0;
+            } else {
+              bool fresh;
+              const uint64_t wl = e - cb;
+              if (wl > kDMaxWordBytes) __hip_atomic_store(D.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              wref[cb] = kRefSlot | dd_find_or_insert(D, text, text + cb, (uint32_t)(wl > kDMaxWordBytes ? kDMaxWordBytes : wl), cb, fresh);
+              if (fresh) {
+                my_list[n_new] = ((unsigned long long)(wl > kDMaxWordBytes ? kDMaxWordBytes : wl) << 40) | cb;
+                my_bytes += wl > kDMaxWordBytes ? kDMaxWordBytes : wl;
+                L.giant_new = 1;
+              }
+            }
+          }
           L.giant_end = e;
         }
         __syncthreads();
         cb = L.giant_end;
+        n_new += L.giant_new;
         uint32_t gone = 0;
         for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
           if (sent_off[s] >= cb) break;
@@ -836,7 +821,12 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
         }
         wref[abase + s] = r;
       }
-      dd_register_wave(D, is_new, idx, &L.txt[mine_w ? s : 0], wlen);
+      const unsigned long long NEWm = __ballot(is_new);
+      if (is_new) {
+        my_list[n_new + __popcll(NEWm & lt)] = ((unsigned long long)wlen << 40) | (abase + s);
+        my_bytes += wlen;
+      }
+      n_new += (uint32_t)__popcll(NEWm);
     }
     if (last) break;
     cb = abase + ce;
@@ -848,6 +838,45 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
     for (int d = 32; d >= 1; d >>= 1) gone += __shfl_xor(gone, d);
     s_next += gone;
     __syncthreads();
+  }
+  for (int d = 32; d >= 1; d >>= 1) my_bytes += __shfl_xor(my_bytes, d);
+  if (lane == 0) D.tile_new[t] = ((unsigned long long)n_new << 36) | my_bytes;
+}
+
+// Numbers the new words of every tile (scan of tile_new) and copies them into the unique-word text.
+__global__ __launch_bounds__(64) void bpe_ureg_kernel(const uint8_t *__restrict__ text, const uint64_t *__restrict__ sent_off,
+                                                      const uint64_t *__restrict__ plan, DedupTab D,
+                                                      const unsigned long long *__restrict__ new_local,
+                                                      const unsigned long long *__restrict__ new_blk_base,
+                                                      const uint32_t *__restrict__ wref, uint32_t *__restrict__ uslot,
+                                                      uint64_t *__restrict__ uoff, uint8_t *__restrict__ utext) {
+  const int lane = threadIdx.x;
+  const uint64_t t = blockIdx.x;
+  const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
+  if (s_lo == s_hi) return;
+  const uint32_t n_new = (uint32_t)(D.tile_new[t] >> 36);
+  if (!n_new) return;
+  const unsigned long long base = new_blk_base[t >> 10] + new_local[t];
+  const uint64_t u0 = base >> 36;
+  uint64_t b0 = base & ((1ull << 36) - 1ull);
+  const unsigned long long *my_list = D.newlist + (sent_off[s_lo] >> 1);
+  for (uint32_t k0 = 0; k0 < n_new; k0 += 64) {
+    const uint32_t k = k0 + lane;
+    const unsigned long long e = k < n_new ? my_list[k] : 0ull;
+    const uint32_t len = (uint32_t)(e >> 40);
+    const uint64_t pos = e & kDOffMask;
+    uint32_t x = len;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    if (k < n_new) {
+      const uint64_t bo = b0 + (x - len);
+      uoff[u0 + k] = bo;
+      uslot[u0 + k] = wref[pos] & ~kRefSlot;
+      for (uint32_t i = 0; i < len; i++) utext[bo + i] = text[pos + i];
+    }
+    b0 += __shfl(x, 63);
   }
 }
 
@@ -954,7 +983,7 @@ struct swt_bpe_table {
   DevBuf in_text, in_off, out_ids, out_off, n_tok;  // staging for the host-buffer entry point
   // word-level dedup inside one call
   TileWorkspace ws2;          // workspaces of the encode over the unique words
-  DevBuf dd_slot, dd_rec, dd_uslot, dd_utext, dd_uoff, dd_uids, dd_uout_off, dd_misc;
+  DevBuf dd_slot, dd_rec, dd_uslot, dd_utext, dd_uoff, dd_uids, dd_uout_off, dd_misc, dd_newlist, dd_tile_new, dd_new_local, dd_new_blk;
   uint32_t dd_bits = 0, dd_epoch = 0;
   uint64_t dd_h_ubytes = 0;
 };
@@ -1078,24 +1107,26 @@ static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_
     t->dd_epoch = 1;
   }
   const uint64_t max_uniq = n_bytes / 2 + 2;
+  const uint64_t nb_new = (n_tiles + 1023) / 1024;
   if ((rc = t->dd_utext.reserve(n_bytes + 64)) || (rc = t->dd_uoff.reserve((max_uniq + 2) * 8)) || (rc = t->dd_misc.reserve(64)) ||
-      (rc = t->dd_uslot.reserve((max_uniq + 2) * 4)))
+      (rc = t->dd_uslot.reserve((max_uniq + 2) * 4)) || (rc = t->dd_newlist.reserve((n_bytes / 2 + 2) * 8)) ||
+      (rc = t->dd_tile_new.reserve((n_tiles + 1) * 8)) || (rc = t->dd_new_local.reserve((n_tiles + 1) * 8)))
     return rc;
-  unsigned long long *d_counter = t->dd_misc.as<unsigned long long>();
+  if (t->dd_new_blk.cap < (2 * nb_new + 2) * 8) {
+    if ((rc = t->dd_new_blk.reserve((2 * nb_new + 2) * 8))) return rc;
+    SWT_HIP(hipMemsetAsync(t->dd_new_blk.p, 0, t->dd_new_blk.cap, st));  // the scan's ticket starts at zero (and leaves it so)
+  }
+  unsigned long long *d_counter = t->dd_misc.as<unsigned long long>();  // [0] scan total, [1] overflow flag + diagnostics, [2] tokens
   SWT_HIP(hipMemsetAsync(d_counter, 0, 32, st));
   DedupTab D;
   D.slot = t->dd_slot.as<unsigned long long>();
   D.rec = t->dd_rec.as<unsigned long long>();
-  D.uslot = t->dd_uslot.as<uint32_t>();
   D.n_bytes = n_bytes;
-  D.count_cas = (debug_knob(2) & 4) ? 1u : 0u;
+  D.diag = (debug_knob(2) & 4) ? 1u : 0u;
   D.bits = t->dd_bits;
   D.epoch = t->dd_epoch;
-  D.ucounter = d_counter;
-  D.utext = t->dd_utext.as<uint8_t>();
-  D.uoff = t->dd_uoff.as<uint64_t>();
-  D.utext_cap = n_bytes;
-  D.max_uniq = (uint32_t)(max_uniq < (1u << 28) - 1 ? max_uniq : (1u << 28) - 1);
+  D.newlist = t->dd_newlist.as<unsigned long long>();
+  D.tile_new = t->dd_tile_new.as<unsigned long long>();
   D.overflow = reinterpret_cast<unsigned int *>(d_counter + 1);
   uint32_t *wref = t->ws.scratch.as<uint32_t>();
   launch_plan(d_sent_off, n_sent, n_tiles, kDTile, t->ws.plan.as<uint64_t>(), st);
@@ -1103,16 +1134,23 @@ static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_
   hipLaunchKernelGGL(bpe_wordref_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
                      t->ws.plan.as<uint64_t>(), d_cls, D, wref, (uint32_t)debug_knob(2));
   prof_end(st);
+  launch_scan_u64(n_tiles, D.tile_new, t->dd_new_local.as<unsigned long long>(), t->dd_new_blk.as<unsigned long long>(),
+                  reinterpret_cast<uint64_t *>(d_counter), st);
+  hipLaunchKernelGGL(bpe_ureg_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, d_sent_off, t->ws.plan.as<uint64_t>(), D,
+                     t->dd_new_local.as<unsigned long long>(), t->dd_new_blk.as<unsigned long long>() + 1 + nb_new, wref,
+                     t->dd_uslot.as<uint32_t>(), t->dd_uoff.as<uint64_t>(), t->dd_utext.as<uint8_t>());
   unsigned long long h_misc[2] = {0, 0};
   SWT_HIP(hipMemcpyAsync(h_misc, d_counter, 16, hipMemcpyDeviceToHost, st));
   SWT_HIP(hipStreamSynchronize(st));
-  if (D.count_cas) {
+  if (D.diag & 1u) {
     unsigned int c[4];
     SWT_HIP(hipMemcpy(c, d_counter + 1, 16, hipMemcpyDeviceToHost));
     fprintf(stderr, "[swt] dedup CAS: %u inserted, %u lost to another lane; uniques %llu\n", c[1], c[2], h_misc[0] >> 36);
   }
   if ((unsigned int)h_misc[1]) return 1;
   const uint64_t n_uniq = h_misc[0] >> 36, ubytes = h_misc[0] & ((1ull << 36) - 1ull);
+  if (n_uniq > max_uniq || ubytes > n_bytes) return fail(SWT_ERR_STATE, "dedup: %llu unique words / %llu bytes out of bounds",
+                                                         (unsigned long long)n_uniq, (unsigned long long)ubytes);
   t->dd_h_ubytes = ubytes;  // lives in the handle: the copy below may run after this function returns
   SWT_HIP(hipMemcpyAsync(t->dd_uoff.as<uint64_t>() + n_uniq, &t->dd_h_ubytes, 8, hipMemcpyHostToDevice, st));
   // encode the unique words once (raw-word mode: each one is a "sentence")
@@ -1127,7 +1165,7 @@ static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_
   }
   // records -> counts -> scan -> tokens
   if (n_uniq)
-    hipLaunchKernelGGL(bpe_urec_kernel, dim3((unsigned)((n_uniq + 255) / 256)), dim3(256), 0, st, D.uslot, t->dd_uout_off.as<uint64_t>(),
+    hipLaunchKernelGGL(bpe_urec_kernel, dim3((unsigned)((n_uniq + 255) / 256)), dim3(256), 0, st, t->dd_uslot.as<uint32_t>(), t->dd_uout_off.as<uint64_t>(),
                        n_uniq, D.rec);
   hipLaunchKernelGGL(bpe_refcount_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, t->ws.plan.as<uint64_t>(), wref,
                      D.rec, t->ws.tile_tok.as<uint32_t>());

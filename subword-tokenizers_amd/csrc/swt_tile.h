@@ -127,6 +127,10 @@ inline uint64_t tile_count(uint64_t n_bytes, uint32_t tile = kTile) { return n_b
 // Host launchers of the skeleton's own kernels (defined in swt_tile.hip).
 void launch_plan(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, uint32_t tile, uint64_t *d_plan, hipStream_t st);
 void launch_scan_only(uint64_t n_tiles, const TileWorkspace &ws, uint64_t *d_n_tokens, hipStream_t st);
+// the same scan over 64-bit values: d_local[i] = exclusive sum inside i's group of 1024, blk = [ticket (zero), totals[nb],
+// bases[nb]] with nb = ceil(n / 1024); global exclusive sum of i = blk[1 + nb + (i >> 10)] + d_local[i]
+void launch_scan_u64(uint64_t n, const unsigned long long *d_in, unsigned long long *d_local, unsigned long long *blk,
+                     uint64_t *d_total, hipStream_t st);
 void launch_scan_gather(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, const TileWorkspace &ws,
                         uint32_t *d_out_ids, uint64_t *d_out_off, uint64_t *d_n_tokens, hipStream_t st);
 

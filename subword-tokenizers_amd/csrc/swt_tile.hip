@@ -20,8 +20,9 @@ __global__ void plan_kernel(const uint64_t *__restrict__ sent_off, uint64_t n_se
 
 // Exclusive scan of the tile totals, one launch: every workgroup scans its 1024 tiles locally and publishes its total;
 // the last one to arrive (ticket) scans the workgroup totals.  Global base of tile t = blk_base[t >> 10] + tile_base[t].
-__global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t *__restrict__ tile_tok, uint64_t n_tiles,
-                                                         uint32_t *__restrict__ tile_base, unsigned long long *__restrict__ blk_tot,
+template <class T>
+__global__ __launch_bounds__(1024) void tile_scan_kernel(const T *__restrict__ tile_tok, uint64_t n_tiles,
+                                                         T *__restrict__ tile_base, unsigned long long *__restrict__ blk_tot,
                                                          unsigned long long *__restrict__ blk_base, unsigned int *__restrict__ ticket,
                                                          uint64_t *__restrict__ n_tokens) {
   __shared__ unsigned long long wsum[16];
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t *__restr
   __syncthreads();
   unsigned long long wb = 0;
   for (int w = 0; w < wave; w++) wb += wsum[w];
-  if (i < n_tiles) tile_base[i] = (uint32_t)(wb + x - v);
+  if (i < n_tiles) tile_base[i] = (T)(wb + x - v);
   if (tid == 1023) {
     blk_tot[blockIdx.x] = wb + x;
     __threadfence();  // agent-scope release of blk_tot before the ticket
@@ -117,8 +118,15 @@ void launch_plan(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, 
 void launch_scan_only(uint64_t n_tiles, const TileWorkspace &ws, uint64_t *d_n_tokens, hipStream_t st) {
   const uint64_t nb = (n_tiles + 1023) / 1024;
   unsigned long long *b = ws.blk.as<unsigned long long>();
-  hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)nb), dim3(1024), 0, st, ws.tile_tok.as<uint32_t>(), n_tiles,
+  hipLaunchKernelGGL(tile_scan_kernel<uint32_t>, dim3((unsigned)nb), dim3(1024), 0, st, ws.tile_tok.as<uint32_t>(), n_tiles,
                      ws.tile_base.as<uint32_t>(), b + 1, b + 1 + nb, reinterpret_cast<unsigned int *>(b), d_n_tokens);
+}
+
+void launch_scan_u64(uint64_t n, const unsigned long long *d_in, unsigned long long *d_local, unsigned long long *blk,
+                     uint64_t *d_total, hipStream_t st) {
+  const uint64_t nb = (n + 1023) / 1024;
+  hipLaunchKernelGGL(tile_scan_kernel<unsigned long long>, dim3((unsigned)nb), dim3(1024), 0, st, d_in, n, d_local, blk + 1,
+                     blk + 1 + nb, reinterpret_cast<unsigned int *>(blk), d_total);
 }
 
 void launch_scan_gather(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, const TileWorkspace &ws,
@@ -128,7 +136,7 @@ void launch_scan_gather(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_
   unsigned long long *b = ws.blk.as<unsigned long long>();
   unsigned int *ticket = reinterpret_cast<unsigned int *>(b);
   unsigned long long *blk_tot = b + 1, *blk_base = b + 1 + nb;
-  hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)nb), dim3(1024), 0, st, ws.tile_tok.as<uint32_t>(), n_tiles,
+  hipLaunchKernelGGL(tile_scan_kernel<uint32_t>, dim3((unsigned)nb), dim3(1024), 0, st, ws.tile_tok.as<uint32_t>(), n_tiles,
                      ws.tile_base.as<uint32_t>(), blk_tot, blk_base, ticket, d_n_tokens);
   hipLaunchKernelGGL(gather_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, st, d_sent_off, ws.plan.as<uint64_t>(), n_tiles,
                      n_sent, ws.scratch.as<uint32_t>(), ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(),
