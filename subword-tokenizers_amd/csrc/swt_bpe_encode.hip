@@ -522,7 +522,7 @@ struct DedupTab {
   // New words are NOT numbered with a global counter (one hot address serialises every returning atomic of the chip:
   // that alone cost 170 us of a 230 us kernel).  The tile that inserted a word lists it; a scan over the tiles'
   // (count, bytes) numbers the words afterwards (bpe_ureg_kernel).
-  unsigned long long *newlist;   // byte length:24 | position:40; the entries of a tile start at [span_base >> 1]
+  unsigned long long *newlist;   // slot:32 | position:32 (the inserter leaves the byte length in rec[slot]); a tile's entries start at [span_base >> 1]
   unsigned long long *tile_new;  // per tile: new words:28 | their bytes:36
   unsigned int *overflow;
 };
@@ -638,13 +638,16 @@ struct WordrefLds {
   unsigned long long sbits[kDBlocks + 1];
   unsigned long long endm[kDBlocks + 1];
   __attribute__((aligned(16))) uint8_t cls_lo[kClsLds];
+  unsigned long long wst[kDBlocks + 1];  // word starts per 64-byte block, and how many came before the block
+  uint32_t nwb[kDBlocks + 1];
   uint64_t giant_end;
-  uint32_t giant_new;
+  uint32_t giant_new, giant_word;
 };
 
 __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restrict__ text, uint64_t n_bytes,
                                                          const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
                                                          const uint8_t *__restrict__ cls_tab, DedupTab D, uint32_t *__restrict__ wref,
+                                                         uint32_t *__restrict__ sent_word, uint32_t *__restrict__ tile_words,
                                                          uint32_t dbg) {
   __shared__ WordrefLds L;
   const int lane = threadIdx.x;
@@ -652,7 +655,7 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
   const uint64_t t = blockIdx.x;
   const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
   if (s_lo == s_hi) {
-    if (lane == 0) D.tile_new[t] = 0ull;
+    if (lane == 0) { D.tile_new[t] = 0ull; tile_words[t] = 0u; }
     return;
   }
   reinterpret_cast<uint4 *>(L.cls_lo)[lane] = reinterpret_cast<const uint4 *>(cls_tab)[lane];
@@ -660,8 +663,9 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
   uint64_t s_next = s_lo;
   uint64_t cb = span_base;
   unsigned long long *const my_list = D.newlist + (span_base >> 1);  // room for one entry per two bytes of the span
-  uint32_t n_new = 0;            // wave-uniform
-  unsigned long long my_bytes = 0;  // per lane, summed at the end
+  uint32_t *const my_rec = wref + span_base;  // the tile's word records, dense, in text order (at most one per byte)
+  uint32_t n_new = 0, words_done = 0;  // wave-uniform
+  unsigned long long my_bytes = 0;     // per lane, summed at the end
   for (;;) {
     const uint64_t abase = cb & ~15ull;
     const uint32_t off0 = (uint32_t)(cb - abase);
@@ -720,10 +724,13 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
       const unsigned long long WSTART = SYM & (PNm | before);
       const unsigned long long CUT = LEAD & (WSm | PNm | SS) & __ballot(inr && p > off0 && p + 4 <= staged);
       if (CUT) cut = (int)(blk * 64 + 63 - __builtin_clzll(CUT));
-      if (lane == 0) L.endm[blk] = WSm | WSTART | ~INR;
+      if (lane == 0) {
+        L.endm[blk] = WSm | WSTART | ~INR;
+        L.wst[blk] = WSTART;
+        L.nwb[blk] = nw;
+      }
       if ((WSTART >> lane) & 1ull) L.wl[nw + __popcll(WSTART & lt)] = (uint16_t)p;
       nw += __popcll(WSTART);
-      if (inr) wref[abase + p] = kInvalidTok;  // word starts are overwritten below (same wave: stores stay in order)
       prev_wb = (WB >> 63) & 1ull;
     }
     __syncthreads();
@@ -755,19 +762,25 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
             e += len;
             first = false;
           }
-          for (uint64_t g = cb; g < e; g++) wref[g] = kInvalidTok;
           L.giant_new = 0;
+          L.giant_word = 0;
           if (has_word && e > cb) {
+            L.giant_word = 1;
             if (nchar == 1) {
-              wref[cb] = cp0;
+              my_rec[words_done] = cp0;
             } else {
               bool fresh;
-              const uint64_t wl = e - cb;
-              if (wl > kDMaxWordBytes) __hip_atomic_store(D.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              wref[cb] = kRefSlot | dd_find_or_insert(D, text, text + cb, (uint32_t)(wl > kDMaxWordBytes ? kDMaxWordBytes : wl), cb, fresh);
+              uint64_t wl = e - cb;
+              if (wl > kDMaxWordBytes) {
+                __hip_atomic_store(D.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                wl = kDMaxWordBytes;
+              }
+              const uint32_t idx = dd_find_or_insert(D, text, text + cb, (uint32_t)wl, cb, fresh);
+              my_rec[words_done] = kRefSlot | idx;
               if (fresh) {
-                my_list[n_new] = ((unsigned long long)(wl > kDMaxWordBytes ? kDMaxWordBytes : wl) << 40) | cb;
-                my_bytes += wl > kDMaxWordBytes ? kDMaxWordBytes : wl;
+                D.rec[idx] = wl;
+                my_list[n_new] = ((unsigned long long)idx << 32) | cb;
+                my_bytes += wl;
                 L.giant_new = 1;
               }
             }
@@ -775,11 +788,14 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
           L.giant_end = e;
         }
         __syncthreads();
+        const uint32_t wd_before = words_done;
         cb = L.giant_end;
         n_new += L.giant_new;
+        words_done += L.giant_word;
         uint32_t gone = 0;
         for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
           if (sent_off[s] >= cb) break;
+          sent_word[s] = wd_before;
           gone++;
         }
         for (int d = 32; d >= 1; d >>= 1) gone += __shfl_xor(gone, d);
@@ -791,6 +807,7 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
       ce = (uint32_t)cut;
     }
     // one lane per word
+    const uint32_t wd0 = words_done;
     if (!(dbg & 1))
     for (uint32_t k0 = 0; k0 < nw; k0 += 64) {
       const uint32_t k = k0 + lane;
@@ -819,36 +836,44 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
           idx = dd_find_or_insert_lds(D, text, &L.txt[s], wlen, abase + s, is_new);
           r = kRefSlot | idx;
         }
-        wref[abase + s] = r;
+        my_rec[wd0 + k] = r;  // the words before the cut are a prefix of the list
       }
       const unsigned long long NEWm = __ballot(is_new);
       if (is_new) {
-        my_list[n_new + __popcll(NEWm & lt)] = ((unsigned long long)wlen << 40) | (abase + s);
+        D.rec[idx] = wlen;
+        my_list[n_new + __popcll(NEWm & lt)] = ((unsigned long long)idx << 32) | (abase + s);
         my_bytes += wlen;
       }
       n_new += (uint32_t)__popcll(NEWm);
+      words_done += (uint32_t)__popcll(__ballot(mine_w));
     }
-    if (last) break;
+    // sentences that start in what this chunk consumed: how many of the tile's words come before them
     cb = abase + ce;
     uint32_t gone = 0;
     for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
-      if (sent_off[s] >= cb) break;
+      const uint64_t o = sent_off[s];
+      if (!last && o >= cb) break;
+      const uint32_t rel = (uint32_t)(o - abase);
+      sent_word[s] = rel >= staged ? words_done : wd0 + L.nwb[rel >> 6] + (uint32_t)__popcll(L.wst[rel >> 6] & ((1ull << (rel & 63)) - 1ull));
       gone++;
     }
+    if (last) break;
     for (int d = 32; d >= 1; d >>= 1) gone += __shfl_xor(gone, d);
     s_next += gone;
     __syncthreads();
   }
   for (int d = 32; d >= 1; d >>= 1) my_bytes += __shfl_xor(my_bytes, d);
-  if (lane == 0) D.tile_new[t] = ((unsigned long long)n_new << 36) | my_bytes;
+  if (lane == 0) {
+    D.tile_new[t] = ((unsigned long long)n_new << 36) | my_bytes;
+    tile_words[t] = words_done;
+  }
 }
 
 // Numbers the new words of every tile (scan of tile_new) and copies them into the unique-word text.
 __global__ __launch_bounds__(64) void bpe_ureg_kernel(const uint8_t *__restrict__ text, const uint64_t *__restrict__ sent_off,
                                                       const uint64_t *__restrict__ plan, DedupTab D,
                                                       const unsigned long long *__restrict__ new_local,
-                                                      const unsigned long long *__restrict__ new_blk_base,
-                                                      const uint32_t *__restrict__ wref, uint32_t *__restrict__ uslot,
+                                                      const unsigned long long *__restrict__ new_blk_base, uint32_t *__restrict__ uslot,
                                                       uint64_t *__restrict__ uoff, uint8_t *__restrict__ utext) {
   const int lane = threadIdx.x;
   const uint64_t t = blockIdx.x;
@@ -863,8 +888,9 @@ __global__ __launch_bounds__(64) void bpe_ureg_kernel(const uint8_t *__restrict_
   for (uint32_t k0 = 0; k0 < n_new; k0 += 64) {
     const uint32_t k = k0 + lane;
     const unsigned long long e = k < n_new ? my_list[k] : 0ull;
-    const uint32_t len = (uint32_t)(e >> 40);
-    const uint64_t pos = e & kDOffMask;
+    const uint32_t idx = (uint32_t)(e >> 32);
+    const uint64_t pos = e & 0xFFFFFFFFull;
+    const uint32_t len = k < n_new ? (uint32_t)D.rec[idx] : 0u;
     uint32_t x = len;
     for (int d = 1; d < 64; d <<= 1) {
       const uint32_t y = __shfl_up(x, d);
@@ -873,7 +899,7 @@ __global__ __launch_bounds__(64) void bpe_ureg_kernel(const uint8_t *__restrict_
     if (k < n_new) {
       const uint64_t bo = b0 + (x - len);
       uoff[u0 + k] = bo;
-      uslot[u0 + k] = wref[pos] & ~kRefSlot;
+      uslot[u0 + k] = idx;
       for (uint32_t i = 0; i < len; i++) utext[bo + i] = text[pos + i];
     }
     b0 += __shfl(x, 63);
@@ -882,7 +908,6 @@ __global__ __launch_bounds__(64) void bpe_ureg_kernel(const uint8_t *__restrict_
 
 __device__ __forceinline__ uint32_t ref_count(uint32_t v, const unsigned long long *__restrict__ rec, uint64_t &src) {
   src = 0;
-  if (v == kInvalidTok) return 0;
   if (!(v & kRefSlot)) return 1;
   const unsigned long long r = rec[v & ~kRefSlot];
   src = r & kDOffMask;
@@ -896,18 +921,19 @@ __global__ void bpe_urec_kernel(const uint32_t *__restrict__ uslot, const uint64
   if (u < n_uniq) rec[uslot[u]] = (unsigned long long)u_off[u] | ((unsigned long long)(u_off[u + 1] - u_off[u]) << 40);
 }
 
-// tokens per tile (the records of a tile's span are contiguous in wref)
+// tokens per tile (a tile's word records are the first tile_words[t] entries behind wref[span_base])
 __global__ __launch_bounds__(64) void bpe_refcount_kernel(const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
-                                                          const uint32_t *__restrict__ wref, const unsigned long long *__restrict__ rec,
-                                                          uint32_t *__restrict__ tile_tok) {
+                                                          const uint32_t *__restrict__ wref, const uint32_t *__restrict__ tile_words,
+                                                          const unsigned long long *__restrict__ rec, uint32_t *__restrict__ tile_tok) {
   const uint64_t t = blockIdx.x;
   const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
   uint32_t total = 0;
   if (s_lo != s_hi) {
-    const uint64_t a = sent_off[s_lo], b = sent_off[s_hi];
-    for (uint64_t g = a + threadIdx.x; g < b; g += 64) {
+    const uint32_t *my_rec = wref + sent_off[s_lo];
+    const uint32_t n_w = tile_words[t];
+    for (uint32_t k = threadIdx.x; k < n_w; k += 64) {
       uint64_t src;
-      total += ref_count(wref[g], rec, src);
+      total += ref_count(my_rec[k], rec, src);
     }
     for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
   }
@@ -917,6 +943,7 @@ __global__ __launch_bounds__(64) void bpe_refcount_kernel(const uint64_t *__rest
 // final tokens + sentence offsets
 __global__ __launch_bounds__(64) void bpe_refwrite_kernel(const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
                                                           uint64_t n_tiles, uint64_t n_sent, const uint32_t *__restrict__ wref,
+                                                          const uint32_t *__restrict__ tile_words, const uint32_t *__restrict__ sent_word,
                                                           const unsigned long long *__restrict__ rec,
                                                           const uint32_t *__restrict__ u_ids, const uint32_t *__restrict__ tile_base,
                                                           const unsigned long long *__restrict__ blk_base,
@@ -929,35 +956,39 @@ __global__ __launch_bounds__(64) void bpe_refwrite_kernel(const uint64_t *__rest
   if (t == n_tiles - 1 && lane == 0) out_off[n_sent] = *n_tokens;
   if (s_lo == s_hi) return;
   const uint64_t base = blk_base[t >> 10] + tile_base[t];
-  const uint64_t a = sent_off[s_lo], b = sent_off[s_hi];
+  const uint32_t *my_rec = wref + sent_off[s_lo];
+  const uint32_t n_w = tile_words[t];
   uint64_t s_next = s_lo;
   uint32_t run = 0;
-  for (uint64_t c0 = a; c0 < b || c0 == a; c0 += kDCap) {
-    const uint64_t c1 = c0 + kDCap < b ? c0 + kDCap : b;
-    for (uint64_t g0 = c0; g0 < c1; g0 += 64) {
-      const uint64_t g = g0 + lane;
+  for (uint32_t k0 = 0;; k0 += kDCap) {
+    const uint32_t k1 = n_w - k0 > (uint32_t)kDCap ? k0 + kDCap : n_w;
+    for (uint32_t j0 = k0; j0 < k1; j0 += 64) {
+      const uint32_t j = j0 + lane;
       uint64_t src = 0;
-      const uint32_t v = g < c1 ? wref[g] : kInvalidTok;
-      const uint32_t n = ref_count(v, rec, src);
+      uint32_t v = 0, n = 0;
+      if (j < k1) {
+        v = my_rec[j];
+        n = ref_count(v, rec, src);
+      }
       uint32_t x = n;
       for (int d = 1; d < 64; d <<= 1) {
         const uint32_t y = __shfl_up(x, d);
         if (lane >= d) x += y;
       }
       const uint32_t ex = run + x - n;
-      if (g < c1) pre[g - c0] = ex;
+      if (j < k1) pre[j - k0] = ex;
       if (n == 1 && !(v & kRefSlot)) out_ids[base + ex] = v;
-      else for (uint32_t j = 0; j < n; j++) out_ids[base + ex + j] = u_ids[src + j];
+      else for (uint32_t i = 0; i < n; i++) out_ids[base + ex + i] = u_ids[src + i];
       run += __shfl(x, 63);
     }
     __syncthreads();
-    // sentences that start inside [c0, c1) -- and at b itself on the last chunk
-    const bool lastc = c1 == b;
+    // sentences whose first word lies in [k0, k1) -- and, on the last chunk, those behind the last word
+    const bool lastc = k1 == n_w;
     uint32_t mine = 0;
     for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
-      const uint64_t o = sent_off[s];
-      if (o > c1 || (o == c1 && !lastc)) break;
-      out_off[s] = base + (o < c1 ? pre[o - c0] : run);
+      const uint32_t w = sent_word[s];
+      if (w > k1 || (w == k1 && !lastc)) break;
+      out_off[s] = base + (w < k1 ? pre[w - k0] : run);
       mine++;
     }
     for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
@@ -983,7 +1014,7 @@ struct swt_bpe_table {
   DevBuf in_text, in_off, out_ids, out_off, n_tok;  // staging for the host-buffer entry point
   // word-level dedup inside one call
   TileWorkspace ws2;          // workspaces of the encode over the unique words
-  DevBuf dd_slot, dd_rec, dd_uslot, dd_utext, dd_uoff, dd_uids, dd_uout_off, dd_misc, dd_newlist, dd_tile_new, dd_new_local, dd_new_blk;
+  DevBuf dd_slot, dd_rec, dd_uslot, dd_utext, dd_uoff, dd_uids, dd_uout_off, dd_misc, dd_newlist, dd_tile_new, dd_new_local, dd_new_blk, dd_tile_words;
   uint32_t dd_bits = 0, dd_epoch = 0;
   uint64_t dd_h_ubytes = 0;
 };
@@ -1062,13 +1093,13 @@ void swt_bpe_table_destroy(swt_bpe_table *t) {
 // the direct path: every word occurrence goes through the merge rounds
 static int bpe_encode_direct(swt_bpe_table *t, TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off,
                              uint64_t n_sent, uint32_t *d_out_ids, uint64_t *d_out_off, uint64_t *d_n_tokens, const uint8_t *d_cls,
-                             bool timed, hipStream_t st) {
-  const uint64_t n_tiles = tile_count(n_bytes, kBpeTile);
+                             bool timed, hipStream_t st, uint32_t tile = kBpeTile) {
+  const uint64_t n_tiles = tile_count(n_bytes, tile);
   if (n_tiles > 0x7FFFFFFFull)
     return fail(SWT_ERR_UNSUPPORTED, "text too large for one call (%llu bytes)", (unsigned long long)n_bytes);
   int rc;
   if ((rc = ws.reserve(n_bytes, n_sent, n_tiles))) return rc;
-  launch_plan(d_sent_off, n_sent, n_tiles, kBpeTile, ws.plan.as<uint64_t>(), st);
+  launch_plan(d_sent_off, n_sent, n_tiles, tile, ws.plan.as<uint64_t>(), st);
   if (timed) prof_begin(st);
   if (t->packed)
     hipLaunchKernelGGL(bpe_encode_kernel<true>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
@@ -1110,7 +1141,8 @@ static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_
   const uint64_t nb_new = (n_tiles + 1023) / 1024;
   if ((rc = t->dd_utext.reserve(n_bytes + 64)) || (rc = t->dd_uoff.reserve((max_uniq + 2) * 8)) || (rc = t->dd_misc.reserve(64)) ||
       (rc = t->dd_uslot.reserve((max_uniq + 2) * 4)) || (rc = t->dd_newlist.reserve((n_bytes / 2 + 2) * 8)) ||
-      (rc = t->dd_tile_new.reserve((n_tiles + 1) * 8)) || (rc = t->dd_new_local.reserve((n_tiles + 1) * 8)))
+      (rc = t->dd_tile_new.reserve((n_tiles + 1) * 8)) || (rc = t->dd_new_local.reserve((n_tiles + 1) * 8)) ||
+      (rc = t->dd_tile_words.reserve((n_tiles + 1) * 4)))
     return rc;
   if (t->dd_new_blk.cap < (2 * nb_new + 2) * 8) {
     if ((rc = t->dd_new_blk.reserve((2 * nb_new + 2) * 8))) return rc;
@@ -1132,12 +1164,13 @@ static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_
   launch_plan(d_sent_off, n_sent, n_tiles, kDTile, t->ws.plan.as<uint64_t>(), st);
   prof_begin(st);
   hipLaunchKernelGGL(bpe_wordref_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
-                     t->ws.plan.as<uint64_t>(), d_cls, D, wref, (uint32_t)debug_knob(2));
+                     t->ws.plan.as<uint64_t>(), d_cls, D, wref, t->ws.sent_local.as<uint32_t>(), t->dd_tile_words.as<uint32_t>(),
+                     (uint32_t)debug_knob(2));
   prof_end(st);
   launch_scan_u64(n_tiles, D.tile_new, t->dd_new_local.as<unsigned long long>(), t->dd_new_blk.as<unsigned long long>(),
                   reinterpret_cast<uint64_t *>(d_counter), st);
   hipLaunchKernelGGL(bpe_ureg_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, d_sent_off, t->ws.plan.as<uint64_t>(), D,
-                     t->dd_new_local.as<unsigned long long>(), t->dd_new_blk.as<unsigned long long>() + 1 + nb_new, wref,
+                     t->dd_new_local.as<unsigned long long>(), t->dd_new_blk.as<unsigned long long>() + 1 + nb_new,
                      t->dd_uslot.as<uint32_t>(), t->dd_uoff.as<uint64_t>(), t->dd_utext.as<uint8_t>());
   unsigned long long h_misc[2] = {0, 0};
   SWT_HIP(hipMemcpyAsync(h_misc, d_counter, 16, hipMemcpyDeviceToHost, st));
@@ -1158,7 +1191,8 @@ static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_
   uint64_t *d_ntok2 = reinterpret_cast<uint64_t *>(d_counter + 2);
   if (n_uniq) {
     if ((rc = bpe_encode_direct(t, t->ws2, t->dd_utext.as<uint8_t>(), ubytes, t->dd_uoff.as<uint64_t>(), n_uniq,
-                                t->dd_uids.as<uint32_t>(), t->dd_uout_off.as<uint64_t>(), d_ntok2, nullptr, false, st)))
+                                t->dd_uids.as<uint32_t>(), t->dd_uout_off.as<uint64_t>(), d_ntok2, nullptr, false, st,
+                                debug_knob(3) > 0 ? (uint32_t)debug_knob(3) : (uint32_t)kBpeTile)))
       return rc;
   } else {
     SWT_HIP(hipMemsetAsync(t->dd_uout_off.p, 0, 16, st));
@@ -1168,12 +1202,13 @@ static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_
     hipLaunchKernelGGL(bpe_urec_kernel, dim3((unsigned)((n_uniq + 255) / 256)), dim3(256), 0, st, t->dd_uslot.as<uint32_t>(), t->dd_uout_off.as<uint64_t>(),
                        n_uniq, D.rec);
   hipLaunchKernelGGL(bpe_refcount_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, t->ws.plan.as<uint64_t>(), wref,
-                     D.rec, t->ws.tile_tok.as<uint32_t>());
+                     t->dd_tile_words.as<uint32_t>(), D.rec, t->ws.tile_tok.as<uint32_t>());
   const uint64_t nb = (n_tiles + 1023) / 1024;
   unsigned long long *bb = t->ws.blk.as<unsigned long long>();
   launch_scan_only(n_tiles, t->ws, d_n_tokens, st);
   hipLaunchKernelGGL(bpe_refwrite_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, t->ws.plan.as<uint64_t>(), n_tiles,
-                     n_sent, wref, D.rec, t->dd_uids.as<uint32_t>(), t->ws.tile_base.as<uint32_t>(),
+                     n_sent, wref, t->dd_tile_words.as<uint32_t>(), t->ws.sent_local.as<uint32_t>(), D.rec, t->dd_uids.as<uint32_t>(),
+                     t->ws.tile_base.as<uint32_t>(),
                      bb + 1 + nb, d_n_tokens, d_out_ids, d_out_off);
   SWT_HIP(hipGetLastError());
   return SWT_OK;
