@@ -13,9 +13,11 @@ data/train-85k.json -- with the first 8,000 pretrained me
 text (UTF-8, 1 MB = 1e6 B) encoded per second, inputs resident in HBM when the timed region starts.
 A "step" is one pass of the whole path (plan + encode + scan + gather kernels) over the batch.
 
-  roofline      dominant kernel (bpe_encode_kernel) timed with HIP events on its own stream inside the library
-                (swt_profile_*); achieved = algorithmic bytes / launch time; algorithmic bytes per launch =
-                input bytes + 4 B per output token + 8 B per sentence offset.
+  roofline      timed with HIP events on the launch stream inside the library (swt_profile_*); achieved = algorithmic
+                bytes / time; algorithmic bytes per call = input bytes + 4 B per output token + 8 B per sentence
+                offset.  FastBPE encode is a pipeline of nine short kernels: its line is that
+                of the whole call (first kernel start .. last kernel end) with the longest kernel beside it; the
+                other workloads time their dominant kernel.
   cpu_baseline  the C oracle (oracle/, a port of the reference's algorithm) on one host core of this box, on the
                 same S85k batch.  The oracle is only the checker/baseline here, never the thing measured.
 """
@@ -126,6 +128,12 @@ def bench_bpe_encode(args, torch, dist, rank, world, local):
     barrier_sync(torch, dist)
     elapsed = max_over_ranks(torch, dist, time.perf_counter() - t0)
     kernel_ms, launches = N.profile_read()
+    # outside the timed region: the same step with one event pair around ALL kernels of a call (profile level 2)
+    N.profile_enable(2)
+    for _ in range(min(max(args.steps, 1), 20)):
+        step()
+    torch.cuda.synchronize()
+    call_ms, calls = N.profile_read()
     N.profile_enable(False)
     total_bytes = sum_over_ranks(torch, dist, float(n_bytes))
 
@@ -147,13 +155,21 @@ def bench_bpe_encode(args, torch, dist, rank, world, local):
         cpu_s = time.perf_counter() - t1
         if not (np.array_equal(ids, oids) and np.array_equal(offs, ooff)):
             raise SystemExit("PARITY FAILURE: device ids differ from the oracle on the benchmark batch")
+        # Since the word-level dedup the batch passes through nine short kernels and none of them touches all of the
+        # algorithmic bytes, so the roofline line is that of the whole call: algorithmic bytes of the batch over the
+        # time from the first kernel's start to the last kernel's end (HIP events on the launch stream).  The longest
+        # single kernel (bpe_encode_kernel over the unique words) is reported beside it.
         algo = n_bytes + 4.0 * n_tok + 8.0 * (n_sent + 1)
-        per_launch_s = kernel_ms / 1e3 / max(launches, 1)
-        achieved = algo / per_launch_s / 1e9
+        per_call_s = call_ms / 1e3 / max(calls, 1)
+        achieved = algo / per_call_s / 1e9
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_from_profile("bpe_encode"),
-                "kernel": "bpe_encode_kernel", "kernel_us": round(per_launch_s * 1e6, 2),
-                "algorithmic_bytes_per_launch": int(algo), "launches_timed": int(launches)}
+                "kernel": "dedup pipeline: plan, bpe_wordref, scan, bpe_ureg, plan_dev, bpe_encode (unique words), "
+                          "bpe_refcount, scan, bpe_refwrite",
+                "kernel_us": round(per_call_s * 1e6, 2),
+                "algorithmic_bytes_per_launch": int(algo), "launches_timed": int(calls),
+                "dominant_kernel": {"name": "bpe_encode_kernel", "us": round(kernel_ms * 1e3 / max(launches, 1), 2),
+                                    "launches_timed": int(launches)}}
         cpu = {"value": round(n_bytes / 1e6 / cpu_s, 3), "unit": "MB/s", "cores": 1, "kind": "port",
                "sample": "the whole S85k batch (%.1f MB), one pass of oracle/swt_oracle.c orc_bpe_tokenize_batch" % (n_bytes / 1e6)}
     return {

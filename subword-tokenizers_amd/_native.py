@@ -136,7 +136,8 @@ def debug_knob(which, value):
 
 
 def profile_enable(on=True):
-    check(lib().swt_profile_enable(1 if on else 0))
+    """True/1 = time the dominant kernel of each path, 2 = time all kernels of a call, False/0 = off"""
+    check(lib().swt_profile_enable(int(on)))
 
 
 def profile_read():

@@ -141,7 +141,10 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
     const uint8_t *__restrict__ text, uint64_t n_bytes, const uint64_t *__restrict__ sent_off,
     const uint64_t *__restrict__ plan, const uint8_t *__restrict__ cls_tab, const BpeSlot *__restrict__ slots,
     uint32_t bits, const uint32_t *__restrict__ merged_of_rank, uint32_t *__restrict__ scratch,
-    uint32_t *__restrict__ sent_local, uint32_t *__restrict__ tile_tok, uint32_t dbg) {
+    uint32_t *__restrict__ sent_local, uint32_t *__restrict__ tile_tok, const uint32_t *__restrict__ uslot,
+    unsigned long long *__restrict__ rec, uint32_t dbg) {
+  // uslot/rec (dedup path, every "sentence" is one unique word): the word's token run -- its place in scratch and its
+  // length -- goes straight to the word's table slot, and nobody needs a scan or a gather of this launch's output.
   __shared__ BpeLds L;
   const int lane = threadIdx.x;
   const unsigned long long lt = (1ull << lane) - 1ull;  // lanes below me
@@ -289,6 +292,7 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
         for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
           if (sent_off[s] >= g.end) break;
           sent_local[s] = run;
+          if (rec) rec[uslot[s]] = (unsigned long long)(span_base + run) | ((unsigned long long)g.ntok << 32);
           mine++;
         }
         for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
@@ -480,6 +484,12 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
       uint32_t e = total;
       if (rel < ce && (rel >> 6) < nblk) e = L.blkpre[rel >> 6] + __popcll(L.vmask[rel >> 6] & ((1ull << (rel & 63)) - 1ull));
       sent_local[s] = run + e;
+      if (rec && rel < ce) {  // a word never straddles the cut, so its end lies in this chunk too
+        const uint64_t rel2 = sent_off[s + 1] - abase;
+        uint32_t e2 = total;
+        if (rel2 < ce && (rel2 >> 6) < nblk) e2 = L.blkpre[rel2 >> 6] + __popcll(L.vmask[rel2 >> 6] & ((1ull << (rel2 & 63)) - 1ull));
+        rec[uslot[s]] = (unsigned long long)(span_base + run + e) | ((unsigned long long)(e2 - e) << 32);
+      }
       mine++;
     }
     for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
@@ -514,7 +524,8 @@ typedef uint64_t u64u __attribute__((aligned(1)));  // unaligned 8-byte access (
 
 struct DedupTab {
   unsigned long long *slot;      // epoch:8 | tag:8 | byte length:8 | representative offset:40
-  unsigned long long *rec;       // per slot, filled after the unique words are encoded: token offset:40 | count:24
+  unsigned long long *rec;       // per slot: the inserter leaves the byte length; the unique-word encode replaces it by
+                                 // token count:32 | place of the tokens in its scratch:32
   uint64_t n_bytes;              // size of the text (wide compares stay inside it)
   uint32_t diag;                 // diagnostics: bit 0 tallies CAS successes / failures behind `overflow`
   uint32_t bits;
@@ -523,10 +534,9 @@ struct DedupTab {
   // that alone cost 170 us of a 230 us kernel).  The tile that inserted a word lists it; a scan over the tiles'
   // (count, bytes) numbers the words afterwards (bpe_ureg_kernel).
   unsigned long long *newlist;   // slot:32 | position:32 (the inserter leaves the byte length in rec[slot]); a tile's entries start at [span_base >> 1]
-  unsigned long long *tile_new;  // per tile: new words:28 | their bytes:36
+  unsigned long long *tile_new;  // per tile: new words:32 | their bytes:32 (a dedup call holds at most 2^30 bytes)
   unsigned int *overflow;
 };
-constexpr uint32_t kDMaxWordBytes = (1u << 24) - 1u;
 
 // the same function as the wide form in dd_find_or_insert_lds, byte by byte (words in global memory)
 __device__ __forceinline__ unsigned long long dd_pack8(const uint8_t *p, uint32_t n) {
@@ -770,11 +780,7 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
               my_rec[words_done] = cp0;
             } else {
               bool fresh;
-              uint64_t wl = e - cb;
-              if (wl > kDMaxWordBytes) {
-                __hip_atomic_store(D.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                wl = kDMaxWordBytes;
-              }
+              const uint64_t wl = e - cb;
               const uint32_t idx = dd_find_or_insert(D, text, text + cb, (uint32_t)wl, cb, fresh);
               my_rec[words_done] = kRefSlot | idx;
               if (fresh) {
@@ -864,7 +870,7 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
   }
   for (int d = 32; d >= 1; d >>= 1) my_bytes += __shfl_xor(my_bytes, d);
   if (lane == 0) {
-    D.tile_new[t] = ((unsigned long long)n_new << 36) | my_bytes;
+    D.tile_new[t] = ((unsigned long long)n_new << 32) | my_bytes;
     tile_words[t] = words_done;
   }
 }
@@ -873,17 +879,19 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
 __global__ __launch_bounds__(64) void bpe_ureg_kernel(const uint8_t *__restrict__ text, const uint64_t *__restrict__ sent_off,
                                                       const uint64_t *__restrict__ plan, DedupTab D,
                                                       const unsigned long long *__restrict__ new_local,
-                                                      const unsigned long long *__restrict__ new_blk_base, uint32_t *__restrict__ uslot,
+                                                      const unsigned long long *__restrict__ new_blk_base,
+                                                      const unsigned long long *__restrict__ d_total, uint32_t *__restrict__ uslot,
                                                       uint64_t *__restrict__ uoff, uint8_t *__restrict__ utext) {
   const int lane = threadIdx.x;
   const uint64_t t = blockIdx.x;
   const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
+  if (t == 0 && lane == 0) uoff[*d_total >> 32] = *d_total & 0xFFFFFFFFull;  // the end of the last unique word
   if (s_lo == s_hi) return;
-  const uint32_t n_new = (uint32_t)(D.tile_new[t] >> 36);
+  const uint32_t n_new = (uint32_t)(D.tile_new[t] >> 32);
   if (!n_new) return;
   const unsigned long long base = new_blk_base[t >> 10] + new_local[t];
-  const uint64_t u0 = base >> 36;
-  uint64_t b0 = base & ((1ull << 36) - 1ull);
+  const uint64_t u0 = base >> 32;
+  uint64_t b0 = base & 0xFFFFFFFFull;
   const unsigned long long *my_list = D.newlist + (sent_off[s_lo] >> 1);
   for (uint32_t k0 = 0; k0 < n_new; k0 += 64) {
     const uint32_t k = k0 + lane;
@@ -910,15 +918,8 @@ __device__ __forceinline__ uint32_t ref_count(uint32_t v, const unsigned long lo
   src = 0;
   if (!(v & kRefSlot)) return 1;
   const unsigned long long r = rec[v & ~kRefSlot];
-  src = r & kDOffMask;
-  return (uint32_t)(r >> 40);
-}
-
-// after the unique words are encoded: their (token offset, count) goes to their table slot
-__global__ void bpe_urec_kernel(const uint32_t *__restrict__ uslot, const uint64_t *__restrict__ u_off, uint64_t n_uniq,
-                                unsigned long long *__restrict__ rec) {
-  const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (u < n_uniq) rec[uslot[u]] = (unsigned long long)u_off[u] | ((unsigned long long)(u_off[u + 1] - u_off[u]) << 40);
+  src = r & 0xFFFFFFFFull;
+  return (uint32_t)(r >> 32);
 }
 
 // tokens per tile (a tile's word records are the first tile_words[t] entries behind wref[span_base])
@@ -1014,9 +1015,8 @@ struct swt_bpe_table {
   DevBuf in_text, in_off, out_ids, out_off, n_tok;  // staging for the host-buffer entry point
   // word-level dedup inside one call
   TileWorkspace ws2;          // workspaces of the encode over the unique words
-  DevBuf dd_slot, dd_rec, dd_uslot, dd_utext, dd_uoff, dd_uids, dd_uout_off, dd_misc, dd_newlist, dd_tile_new, dd_new_local, dd_new_blk, dd_tile_words;
+  DevBuf dd_slot, dd_rec, dd_uslot, dd_utext, dd_uoff, dd_misc, dd_newlist, dd_tile_new, dd_new_local, dd_new_blk, dd_tile_words;
   uint32_t dd_bits = 0, dd_epoch = 0;
-  uint64_t dd_h_ubytes = 0;
 };
 
 static int bpe_upload(swt_bpe_table *t) {
@@ -1085,42 +1085,52 @@ void swt_bpe_table_destroy(swt_bpe_table *t) {
   t->ws.release();
   t->ws2.release();
   for (DevBuf *b : {&t->in_text, &t->in_off, &t->out_ids, &t->out_off, &t->n_tok, &t->dd_slot, &t->dd_rec, &t->dd_uslot, &t->dd_utext, &t->dd_uoff,
-                    &t->dd_uids, &t->dd_uout_off, &t->dd_misc})
+                    &t->dd_misc, &t->dd_newlist, &t->dd_tile_new, &t->dd_new_local, &t->dd_new_blk, &t->dd_tile_words})
     b->release();
   delete t;
 }
 
 // the direct path: every word occurrence goes through the merge rounds
+static void launch_encode_kernel(swt_bpe_table *t, uint64_t n_tiles, const TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes,
+                                 const uint64_t *d_sent_off, const uint8_t *d_cls, const uint32_t *d_uslot, unsigned long long *d_rec,
+                                 hipStream_t st) {
+  if (t->packed)
+    hipLaunchKernelGGL(bpe_encode_kernel<true>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
+                       ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, ws.scratch.as<uint32_t>(),
+                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, (uint32_t)debug_knob(0));
+  else
+    hipLaunchKernelGGL(bpe_encode_kernel<false>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
+                       ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, ws.scratch.as<uint32_t>(),
+                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, (uint32_t)debug_knob(0));
+}
+
 static int bpe_encode_direct(swt_bpe_table *t, TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off,
                              uint64_t n_sent, uint32_t *d_out_ids, uint64_t *d_out_off, uint64_t *d_n_tokens, const uint8_t *d_cls,
-                             bool timed, hipStream_t st, uint32_t tile = kBpeTile) {
-  const uint64_t n_tiles = tile_count(n_bytes, tile);
+                             hipStream_t st) {
+  const uint64_t n_tiles = tile_count(n_bytes, kBpeTile);
   if (n_tiles > 0x7FFFFFFFull)
     return fail(SWT_ERR_UNSUPPORTED, "text too large for one call (%llu bytes)", (unsigned long long)n_bytes);
   int rc;
   if ((rc = ws.reserve(n_bytes, n_sent, n_tiles))) return rc;
-  launch_plan(d_sent_off, n_sent, n_tiles, tile, ws.plan.as<uint64_t>(), st);
-  if (timed) prof_begin(st);
-  if (t->packed)
-    hipLaunchKernelGGL(bpe_encode_kernel<true>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
-                       ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, ws.scratch.as<uint32_t>(),
-                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), (uint32_t)debug_knob(0));
-  else
-    hipLaunchKernelGGL(bpe_encode_kernel<false>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
-                       ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, ws.scratch.as<uint32_t>(),
-                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), (uint32_t)debug_knob(0));
-  if (timed) prof_end(st);
+  prof_begin(st, 2);
+  launch_plan(d_sent_off, n_sent, n_tiles, kBpeTile, ws.plan.as<uint64_t>(), st);
+  prof_begin(st);
+  launch_encode_kernel(t, n_tiles, ws, d_text, n_bytes, d_sent_off, d_cls, nullptr, nullptr, st);
+  prof_end(st);
   launch_scan_gather(d_sent_off, n_sent, n_tiles, ws, d_out_ids, d_out_off, d_n_tokens, st);
+  prof_end(st, 2);
   SWT_HIP(hipGetLastError());
   return SWT_OK;
 }
 
-// the dedup path; returns 1 when the caller should fall back to the direct path (table or unique-word buffers too small)
+// The dedup path: nine launches, no host round trip (the number of unique words stays on the device: the unique-word
+// encode is launched over as many tiles as the whole text could need and the tiles behind the real ones find an empty
+// plan).  Returns 1 when the batch is too large for the 32-bit fields of this path (the caller takes the direct path).
 static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off, uint64_t n_sent,
                             uint32_t *d_out_ids, uint64_t *d_out_off, uint64_t *d_n_tokens, const uint8_t *d_cls, hipStream_t st) {
   int rc;
   const uint64_t n_tiles = tile_count(n_bytes, kDTile);
-  if (n_tiles > 0x7FFFFFFFull || n_bytes > (1ull << 30)) return 1;  // larger batches: direct path
+  if (n_bytes > (1ull << 30)) return 1;
   if ((rc = t->ws.reserve(n_bytes, n_sent, n_tiles))) return rc;
   // table: one slot per two bytes of text is always enough (a tabled word has at least two bytes); never cleared
   uint32_t bits = 16;
@@ -1137,19 +1147,19 @@ static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_
     SWT_HIP(hipMemsetAsync(t->dd_slot.p, 0, ((size_t)1 << t->dd_bits) * 8, st));
     t->dd_epoch = 1;
   }
-  const uint64_t max_uniq = n_bytes / 2 + 2;
+  const uint64_t max_uniq = n_bytes / 2 + 2;                 // a tabled word has at least two bytes
+  const uint64_t n_tiles2 = tile_count(n_bytes, kBpeTile);   // the unique words together are no longer than the text
   const uint64_t nb_new = (n_tiles + 1023) / 1024;
   if ((rc = t->dd_utext.reserve(n_bytes + 64)) || (rc = t->dd_uoff.reserve((max_uniq + 2) * 8)) || (rc = t->dd_misc.reserve(64)) ||
       (rc = t->dd_uslot.reserve((max_uniq + 2) * 4)) || (rc = t->dd_newlist.reserve((n_bytes / 2 + 2) * 8)) ||
       (rc = t->dd_tile_new.reserve((n_tiles + 1) * 8)) || (rc = t->dd_new_local.reserve((n_tiles + 1) * 8)) ||
-      (rc = t->dd_tile_words.reserve((n_tiles + 1) * 4)))
+      (rc = t->dd_tile_words.reserve((n_tiles + 1) * 4)) || (rc = t->ws2.reserve(n_bytes, max_uniq, n_tiles2)))
     return rc;
   if (t->dd_new_blk.cap < (2 * nb_new + 2) * 8) {
     if ((rc = t->dd_new_blk.reserve((2 * nb_new + 2) * 8))) return rc;
     SWT_HIP(hipMemsetAsync(t->dd_new_blk.p, 0, t->dd_new_blk.cap, st));  // the scan's ticket starts at zero (and leaves it so)
   }
-  unsigned long long *d_counter = t->dd_misc.as<unsigned long long>();  // [0] scan total, [1] overflow flag + diagnostics, [2] tokens
-  SWT_HIP(hipMemsetAsync(d_counter, 0, 32, st));
+  unsigned long long *d_misc = t->dd_misc.as<unsigned long long>();  // [0] unique words:32 | their bytes:32, [1..2] diagnostics
   DedupTab D;
   D.slot = t->dd_slot.as<unsigned long long>();
   D.rec = t->dd_rec.as<unsigned long long>();
@@ -1159,58 +1169,44 @@ static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_
   D.epoch = t->dd_epoch;
   D.newlist = t->dd_newlist.as<unsigned long long>();
   D.tile_new = t->dd_tile_new.as<unsigned long long>();
-  D.overflow = reinterpret_cast<unsigned int *>(d_counter + 1);
+  D.overflow = reinterpret_cast<unsigned int *>(d_misc + 1);
+  if (D.diag) SWT_HIP(hipMemsetAsync(d_misc, 0, 32, st));
   uint32_t *wref = t->ws.scratch.as<uint32_t>();
-  launch_plan(d_sent_off, n_sent, n_tiles, kDTile, t->ws.plan.as<uint64_t>(), st);
+  uint64_t *plan1 = t->ws.plan.as<uint64_t>();
+  unsigned long long *new_local = t->dd_new_local.as<unsigned long long>(), *new_blk = t->dd_new_blk.as<unsigned long long>();
+  prof_begin(st, 2);
+  launch_plan(d_sent_off, n_sent, n_tiles, kDTile, plan1, st);
+  prof_begin(st, 3);
+  hipLaunchKernelGGL(bpe_wordref_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off, plan1, d_cls, D, wref,
+                     t->ws.sent_local.as<uint32_t>(), t->dd_tile_words.as<uint32_t>(), (uint32_t)debug_knob(2));
+  prof_end(st, 3);
+  launch_scan_u64(n_tiles, D.tile_new, new_local, new_blk, reinterpret_cast<uint64_t *>(d_misc), st);
+  hipLaunchKernelGGL(bpe_ureg_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, d_sent_off, plan1, D, new_local,
+                     new_blk + 1 + nb_new, d_misc, t->dd_uslot.as<uint32_t>(), t->dd_uoff.as<uint64_t>(), t->dd_utext.as<uint8_t>());
+  // encode the unique words once (raw-word mode: each one is a "sentence"); their token runs stay in ws2.scratch
+  launch_plan_dev(t->dd_uoff.as<uint64_t>(), d_misc, n_tiles2, kBpeTile, t->ws2.plan.as<uint64_t>(), st);
   prof_begin(st);
-  hipLaunchKernelGGL(bpe_wordref_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
-                     t->ws.plan.as<uint64_t>(), d_cls, D, wref, t->ws.sent_local.as<uint32_t>(), t->dd_tile_words.as<uint32_t>(),
-                     (uint32_t)debug_knob(2));
+  launch_encode_kernel(t, n_tiles2, t->ws2, t->dd_utext.as<uint8_t>(), n_bytes, t->dd_uoff.as<uint64_t>(), nullptr,
+                       t->dd_uslot.as<uint32_t>(), D.rec, st);
   prof_end(st);
-  launch_scan_u64(n_tiles, D.tile_new, t->dd_new_local.as<unsigned long long>(), t->dd_new_blk.as<unsigned long long>(),
-                  reinterpret_cast<uint64_t *>(d_counter), st);
-  hipLaunchKernelGGL(bpe_ureg_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, d_sent_off, t->ws.plan.as<uint64_t>(), D,
-                     t->dd_new_local.as<unsigned long long>(), t->dd_new_blk.as<unsigned long long>() + 1 + nb_new,
-                     t->dd_uslot.as<uint32_t>(), t->dd_uoff.as<uint64_t>(), t->dd_utext.as<uint8_t>());
-  unsigned long long h_misc[2] = {0, 0};
-  SWT_HIP(hipMemcpyAsync(h_misc, d_counter, 16, hipMemcpyDeviceToHost, st));
-  SWT_HIP(hipStreamSynchronize(st));
-  if (D.diag & 1u) {
-    unsigned int c[4];
-    SWT_HIP(hipMemcpy(c, d_counter + 1, 16, hipMemcpyDeviceToHost));
-    fprintf(stderr, "[swt] dedup CAS: %u inserted, %u lost to another lane; uniques %llu\n", c[1], c[2], h_misc[0] >> 36);
-  }
-  if ((unsigned int)h_misc[1]) return 1;
-  const uint64_t n_uniq = h_misc[0] >> 36, ubytes = h_misc[0] & ((1ull << 36) - 1ull);
-  if (n_uniq > max_uniq || ubytes > n_bytes) return fail(SWT_ERR_STATE, "dedup: %llu unique words / %llu bytes out of bounds",
-                                                         (unsigned long long)n_uniq, (unsigned long long)ubytes);
-  t->dd_h_ubytes = ubytes;  // lives in the handle: the copy below may run after this function returns
-  SWT_HIP(hipMemcpyAsync(t->dd_uoff.as<uint64_t>() + n_uniq, &t->dd_h_ubytes, 8, hipMemcpyHostToDevice, st));
-  // encode the unique words once (raw-word mode: each one is a "sentence")
-  if ((rc = t->dd_uids.reserve((ubytes + 64) * 4)) || (rc = t->dd_uout_off.reserve((n_uniq + 2) * 8))) return rc;
-  uint64_t *d_ntok2 = reinterpret_cast<uint64_t *>(d_counter + 2);
-  if (n_uniq) {
-    if ((rc = bpe_encode_direct(t, t->ws2, t->dd_utext.as<uint8_t>(), ubytes, t->dd_uoff.as<uint64_t>(), n_uniq,
-                                t->dd_uids.as<uint32_t>(), t->dd_uout_off.as<uint64_t>(), d_ntok2, nullptr, false, st,
-                                debug_knob(3) > 0 ? (uint32_t)debug_knob(3) : (uint32_t)kBpeTile)))
-      return rc;
-  } else {
-    SWT_HIP(hipMemsetAsync(t->dd_uout_off.p, 0, 16, st));
-  }
   // records -> counts -> scan -> tokens
-  if (n_uniq)
-    hipLaunchKernelGGL(bpe_urec_kernel, dim3((unsigned)((n_uniq + 255) / 256)), dim3(256), 0, st, t->dd_uslot.as<uint32_t>(), t->dd_uout_off.as<uint64_t>(),
-                       n_uniq, D.rec);
-  hipLaunchKernelGGL(bpe_refcount_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, t->ws.plan.as<uint64_t>(), wref,
+  hipLaunchKernelGGL(bpe_refcount_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, plan1, wref,
                      t->dd_tile_words.as<uint32_t>(), D.rec, t->ws.tile_tok.as<uint32_t>());
   const uint64_t nb = (n_tiles + 1023) / 1024;
-  unsigned long long *bb = t->ws.blk.as<unsigned long long>();
   launch_scan_only(n_tiles, t->ws, d_n_tokens, st);
-  hipLaunchKernelGGL(bpe_refwrite_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, t->ws.plan.as<uint64_t>(), n_tiles,
-                     n_sent, wref, t->dd_tile_words.as<uint32_t>(), t->ws.sent_local.as<uint32_t>(), D.rec, t->dd_uids.as<uint32_t>(),
-                     t->ws.tile_base.as<uint32_t>(),
-                     bb + 1 + nb, d_n_tokens, d_out_ids, d_out_off);
+  hipLaunchKernelGGL(bpe_refwrite_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, plan1, n_tiles, n_sent, wref,
+                     t->dd_tile_words.as<uint32_t>(), t->ws.sent_local.as<uint32_t>(), D.rec, t->ws2.scratch.as<uint32_t>(),
+                     t->ws.tile_base.as<uint32_t>(), t->ws.blk.as<unsigned long long>() + 1 + nb, d_n_tokens, d_out_ids, d_out_off);
+  prof_end(st, 2);
   SWT_HIP(hipGetLastError());
+  if (D.diag) {
+    unsigned long long h[3] = {0, 0, 0};
+    SWT_HIP(hipMemcpyAsync(h, d_misc, 24, hipMemcpyDeviceToHost, st));
+    SWT_HIP(hipStreamSynchronize(st));
+    const unsigned int *c = reinterpret_cast<const unsigned int *>(h + 1);
+    fprintf(stderr, "[swt] dedup: %llu unique words, %llu bytes; CAS %u inserted, %u lost to another lane\n", h[0] >> 32,
+            h[0] & 0xFFFFFFFFull, c[1], c[2]);
+  }
   return SWT_OK;
 }
 
@@ -1236,7 +1232,7 @@ int swt_bpe_encode_dev(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes
     if (rc <= 0) return rc;  // done, or a real error
   }
   // raw-word mode: no classes, so nothing splits and nothing is dropped
-  return bpe_encode_direct(t, t->ws, d_text, n_bytes, d_sent_off, n_sent, d_out_ids, d_out_off, d_n_tokens, raw ? nullptr : d_cls, true, st);
+  return bpe_encode_direct(t, t->ws, d_text, n_bytes, d_sent_off, n_sent, d_out_ids, d_out_off, d_n_tokens, raw ? nullptr : d_cls, st);
 }
 
 int swt_bpe_encode(swt_bpe_table *t, const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, uint32_t *out_ids,

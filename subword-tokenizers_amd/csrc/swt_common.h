@@ -31,8 +31,9 @@ int device_cus();
 int debug_knob(int which);
 
 // ---- dominant-kernel timing (bench.py roofline) ---------------------------------------------------
-void prof_begin(hipStream_t st);
-void prof_end(hipStream_t st);
+// level 1 = the dominant kernel of a path, 2 = all kernels of a call, 3.. = diagnostics (swt_profile_enable selects one)
+void prof_begin(hipStream_t st, int level = 1);
+void prof_end(hipStream_t st, int level = 1);
 
 // ---- device buffers ----------------------------------------------------------------------------
 // Grow-only device buffer (reused across calls so the hot path never allocates in steady state).

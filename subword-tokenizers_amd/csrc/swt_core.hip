@@ -79,11 +79,11 @@ void DevBuf::release() {
 static int g_knobs[8] = {0};
 int debug_knob(int which) { return (which >= 0 && which < 8) ? g_knobs[which] : 0; }
 
-static bool g_prof_on = false;
+static int g_prof_on = 0;  // 0 off, else the level that is being timed
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pending, g_prof_pool;
 
-void prof_begin(hipStream_t st) {
-  if (!g_prof_on) return;
+void prof_begin(hipStream_t st, int level) {
+  if (g_prof_on != level) return;
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (!g_prof_pool.empty()) {
     ev = g_prof_pool.back();
@@ -95,8 +95,8 @@ void prof_begin(hipStream_t st) {
   g_prof_pending.push_back(ev);
 }
 
-void prof_end(hipStream_t st) {
-  if (!g_prof_on || g_prof_pending.empty()) return;
+void prof_end(hipStream_t st, int level) {
+  if (g_prof_on != level || g_prof_pending.empty()) return;
   (void)hipEventRecord(g_prof_pending.back().second, st);
 }
 
@@ -171,7 +171,7 @@ int swt_debug_knob(int which, int value) {
 }
 
 int swt_profile_enable(int on) {
-  swt::g_prof_on = on != 0;
+  swt::g_prof_on = on;
   return SWT_OK;
 }
 

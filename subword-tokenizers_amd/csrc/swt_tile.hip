@@ -18,6 +18,25 @@ __global__ void plan_kernel(const uint64_t *__restrict__ sent_off, uint64_t n_se
   plan[t] = lo;
 }
 
+// The same plan when the number of sentences and bytes is only known on the device (*d_total = sentences:32 | bytes:32):
+// the launch covers n_tiles_max tiles and the tiles behind the real ones come out empty (plan[t] = n_sent).
+__global__ void plan_dev_kernel(const uint64_t *__restrict__ sent_off, const unsigned long long *__restrict__ d_total,
+                                uint64_t n_tiles_max, uint32_t tile, uint64_t *__restrict__ plan) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > n_tiles_max) return;
+  const unsigned long long tot = *d_total;
+  const uint64_t n_sent = tot >> 32, n_bytes = tot & 0xFFFFFFFFull;
+  const uint64_t n_tiles = n_bytes ? (n_bytes + tile - 1) / tile : 1;
+  if (t >= n_tiles) { plan[t] = n_sent; return; }
+  const uint64_t target = t * (uint64_t)tile;
+  uint64_t lo = 0, hi = n_sent;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (sent_off[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  plan[t] = lo;
+}
+
 // Exclusive scan of the tile totals, one launch: every workgroup scans its 1024 tiles locally and publishes its total;
 // the last one to arrive (ticket) scans the workgroup totals.  Global base of tile t = blk_base[t >> 10] + tile_base[t].
 template <class T>
@@ -101,9 +120,12 @@ int TileWorkspace::reserve(uint64_t n_bytes, uint64_t n_sent, uint64_t n_tiles) 
   if ((rc = tile_tok.reserve((n_tiles + 1) * 4))) return rc;
   if ((rc = tile_base.reserve((n_tiles + 2) * 4))) return rc;
   const uint64_t nb = (n_tiles + 1023) / 1024;
-  const bool fresh = blk.p == nullptr;
+  const void *before = blk.p;
   if ((rc = blk.reserve((2 * nb + 4) * 8))) return rc;
-  if (fresh) SWT_HIP(hipMemset(blk.p, 0, 8));  // the ticket (reset by the scan kernel itself afterwards)
+  if (blk.p != before) {  // a new buffer: zero the ticket once (the scan kernel resets it itself afterwards)
+    SWT_HIP(hipMemset(blk.p, 0, 8));
+    SWT_HIP(hipDeviceSynchronize());  // rare path; callers launch on streams that need not order with the null stream
+  }
   return SWT_OK;
 }
 
@@ -113,6 +135,12 @@ void TileWorkspace::release() {
 
 void launch_plan(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, uint32_t tile, uint64_t *d_plan, hipStream_t st) {
   hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n_tiles + 1 + 255) / 256)), dim3(256), 0, st, d_sent_off, n_sent, n_tiles, tile, d_plan);
+}
+
+void launch_plan_dev(const uint64_t *d_sent_off, const unsigned long long *d_total, uint64_t n_tiles_max, uint32_t tile,
+                     uint64_t *d_plan, hipStream_t st) {
+  hipLaunchKernelGGL(plan_dev_kernel, dim3((unsigned)((n_tiles_max + 1 + 255) / 256)), dim3(256), 0, st, d_sent_off, d_total,
+                     n_tiles_max, tile, d_plan);
 }
 
 void launch_scan_only(uint64_t n_tiles, const TileWorkspace &ws, uint64_t *d_n_tokens, hipStream_t st) {
