@@ -36,7 +36,6 @@ constexpr int kClsLds = 1024;    // code points whose class is served from LDS (
 
 constexpr int kBpeTile = 256;   // bytes of sentence starts per tile
 constexpr int kBpeCap = 512;    // staged bytes per chunk
-constexpr int kBpeBlocks = kBpeCap / 64;
 constexpr uint32_t kNoPos = 0xFFFFu;
 
 __device__ __forceinline__ bool slot_lookup(const BpeSlot *__restrict__ slots, uint32_t bits, uint32_t l, uint32_t r,
@@ -114,19 +113,21 @@ __device__ GiantResult giant_word(const uint8_t *__restrict__ text, uint64_t pos
   return r;
 }
 
+template <int Cap>
 struct BpeLds {
-  __attribute__((aligned(16))) uint8_t txt[kBpeCap + 16];
-  uint32_t sym[kBpeCap];           // per byte position: symbol id (token id at the end) or kInvalidTok
-  uint16_t nxt[kBpeCap];           // per byte position: next live symbol of the same word, kNoPos for the last one
-  uint32_t act[kBpeCap];           // symbols of unfinished words: position | head position << 16
-  uint32_t aval[kBpeCap];          // per list entry: table value of (this symbol, next symbol); kNoRank when none
-  uint32_t wm[2][kBpeCap / 2];     // per word (indexed by head >> 1): minimum table value, this round / next round
-  unsigned long long sbits[kBpeBlocks + 1];  // sentence-start bit per byte
-  unsigned long long mark[kBpeBlocks + 1];   // "my predecessor is a candidate of a twin pair (a,a)"
-  unsigned long long tk[kBpeBlocks + 1];     // taken: this symbol merges with its next one this round
-  unsigned long long dead[kBpeBlocks + 1];   // consumed by the symbol before it this round
-  unsigned long long vmask[kBpeBlocks + 1];  // phase E
-  uint32_t blkpre[kBpeBlocks + 1];
+  static constexpr int Blocks = Cap / 64;
+  __attribute__((aligned(16))) uint8_t txt[Cap + 16];
+  uint32_t sym[Cap];           // per byte position: symbol id (token id at the end) or kInvalidTok
+  uint16_t nxt[Cap];           // per byte position: next live symbol of the same word, kNoPos for the last one
+  uint32_t act[Cap];           // symbols of unfinished words: position | head position << 16
+  uint32_t aval[Cap];          // per list entry: table value of (this symbol, next symbol); kNoRank when none
+  uint32_t wm[2][Cap / 2];     // per word (indexed by head >> 1): minimum table value, this round / next round
+  unsigned long long sbits[Blocks + 1];  // sentence-start bit per byte
+  unsigned long long mark[Blocks + 1];   // "my predecessor is a candidate of a twin pair (a,a)"
+  unsigned long long tk[Blocks + 1];     // taken: this symbol merges with its next one this round
+  unsigned long long dead[Blocks + 1];   // consumed by the symbol before it this round
+  unsigned long long vmask[Blocks + 1];  // phase E
+  uint32_t blkpre[Blocks + 1];
   __attribute__((aligned(16))) uint8_t cls_lo[kClsLds];  // classes of U+0000..U+03FF
   GiantResult giant;
 };
@@ -136,7 +137,7 @@ __device__ __forceinline__ bool bit_at(const unsigned long long *m, uint32_t p) 
 // Packed = true: the table value of a pair is rank << 16 | (merged - SWT_SYM_BASE), so a merge round learns the
 // merged symbol without touching memory (tables below 65,534 merges); false: the value is the rank and the merged
 // symbol is read from merged_of_rank[].
-template <bool Packed>
+template <bool Packed, int Cap>
 __global__ __launch_bounds__(64) void bpe_encode_kernel(
     const uint8_t *__restrict__ text, uint64_t n_bytes, const uint64_t *__restrict__ sent_off,
     const uint64_t *__restrict__ plan, const uint8_t *__restrict__ cls_tab, const BpeSlot *__restrict__ slots,
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
     unsigned long long *__restrict__ rec, uint32_t dbg) {
   // uslot/rec (dedup path, every "sentence" is one unique word): the word's token run -- its place in scratch and its
   // length -- goes straight to the word's table slot, and nobody needs a scan or a gather of this launch's output.
-  __shared__ BpeLds L;
+  constexpr int Blocks = Cap / 64;
+  __shared__ BpeLds<Cap> L;
   const int lane = threadIdx.x;
   const unsigned long long lt = (1ull << lane) - 1ull;  // lanes below me
   const unsigned long long le = (2ull << lane) - 1ull;  // me and below
@@ -170,8 +172,8 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
     const uint64_t abase = cb & ~15ull;
     const uint32_t off0 = (uint32_t)(cb - abase);
     const uint64_t avail = span_end - abase;
-    const bool last = avail <= (uint64_t)kBpeCap;
-    const uint32_t staged = last ? (uint32_t)avail : (uint32_t)kBpeCap;
+    const bool last = avail <= (uint64_t)Cap;
+    const uint32_t staged = last ? (uint32_t)avail : (uint32_t)Cap;
     const uint32_t nblk = (staged + 63) >> 6;
 
     // ---- A. stage [abase, abase+staged): one dwordx4 per lane
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
         for (int i = 0; i < 16; i++) L.txt[c + i] = (g + i < n_bytes) ? text[g + i] : (uint8_t)' ';
       }
     }
-    if (lane <= kBpeBlocks) { L.sbits[lane] = 0ull; L.mark[lane] = 0ull; L.tk[lane] = 0ull; L.dead[lane] = 0ull; }
+    if (lane <= Blocks) { L.sbits[lane] = 0ull; L.mark[lane] = 0ull; L.tk[lane] = 0ull; L.dead[lane] = 0ull; }
     __syncthreads();
     for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
       const uint64_t o = sent_off[s];
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
         __syncthreads();
       }
       na = keep;
-      if (lane <= kBpeBlocks) { L.tk[lane] = 0ull; L.mark[lane] = 0ull; L.dead[lane] = 0ull; }
+      if (lane <= Blocks) { L.tk[lane] = 0ull; L.mark[lane] = 0ull; L.dead[lane] = 0ull; }
       cur ^= 1;
       __syncthreads();
     }
@@ -514,6 +516,8 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
 //   count / write   per tile: records -> token counts -> scan -> tokens copied from the unique words' results
 // Slots carry an 8-bit epoch, so the table is never cleared between calls.
 constexpr int kDTile = 1024;
+constexpr int kUTile = 128;     // smallest tile of the unique-word pass (chunk = 2 such tiles); measured: 64 -> 84 us, 128 -> 72 us, 256 -> 88 us
+constexpr uint64_t kUMaxTiles = 8192;  // its launch size: 256 CUs x 32 single-wave workgroups
 constexpr int kDCap = 2048;
 constexpr int kDBlocks = kDCap / 64;
 constexpr uint64_t kDedupMinBytes = 1u << 18;
@@ -1031,13 +1035,22 @@ static int bpe_upload(swt_bpe_table *t) {
   return SWT_OK;
 }
 
+template <bool Packed, int Cap>
+static void launch_encode_kernel_as(swt_bpe_table *t, uint64_t n_tiles, const TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes,
+                                    const uint64_t *d_sent_off, const uint8_t *d_cls, const uint32_t *d_uslot,
+                                    unsigned long long *d_rec, hipStream_t st) {
+  hipLaunchKernelGGL((bpe_encode_kernel<Packed, Cap>), dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
+                     ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, ws.scratch.as<uint32_t>(),
+                     ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, (uint32_t)debug_knob(0));
+}
+
 extern "C" {
 
 // diagnostics (not part of include/swt.h): resident workgroups per CU the runtime grants the encode kernel
 int swt_debug_occupancy(int which) {
   int n = -1;
-  hipError_t e = which ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<false>, 64, 0)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<true>, 64, 0);
+  hipError_t e = which ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<false, kBpeCap>, 64, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<true, kBpeCap>, 64, 0);
   return e == hipSuccess ? n : -(int)e;
 }
 
@@ -1091,17 +1104,17 @@ void swt_bpe_table_destroy(swt_bpe_table *t) {
 }
 
 // the direct path: every word occurrence goes through the merge rounds
+// cap = staged bytes per chunk (LDS footprint ~ 20 B per byte): 512 for running text, less for the unique-word pass
 static void launch_encode_kernel(swt_bpe_table *t, uint64_t n_tiles, const TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes,
                                  const uint64_t *d_sent_off, const uint8_t *d_cls, const uint32_t *d_uslot, unsigned long long *d_rec,
-                                 hipStream_t st) {
-  if (t->packed)
-    hipLaunchKernelGGL(bpe_encode_kernel<true>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
-                       ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, ws.scratch.as<uint32_t>(),
-                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, (uint32_t)debug_knob(0));
-  else
-    hipLaunchKernelGGL(bpe_encode_kernel<false>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
-                       ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, ws.scratch.as<uint32_t>(),
-                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, (uint32_t)debug_knob(0));
+                                 hipStream_t st, int cap = kBpeCap) {
+#define SWT_ENC(P, C) launch_encode_kernel_as<P, C>(t, n_tiles, ws, d_text, n_bytes, d_sent_off, d_cls, d_uslot, d_rec, st)
+  if (t->packed) {
+    if (cap == 128) SWT_ENC(true, 128); else if (cap == 256) SWT_ENC(true, 256); else SWT_ENC(true, 512);
+  } else {
+    if (cap == 128) SWT_ENC(false, 128); else if (cap == 256) SWT_ENC(false, 256); else SWT_ENC(false, 512);
+  }
+#undef SWT_ENC
 }
 
 static int bpe_encode_direct(swt_bpe_table *t, TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off,
@@ -1148,7 +1161,11 @@ static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_
     t->dd_epoch = 1;
   }
   const uint64_t max_uniq = n_bytes / 2 + 2;                 // a tabled word has at least two bytes
-  const uint64_t n_tiles2 = tile_count(n_bytes, kBpeTile);   // the unique words together are no longer than the text
+  // the unique-word pass: few words, so short tiles (more waves, each with fewer serial steps per merge round)
+  // (the launch has a fixed number of workgroups, at most one resident wave set of the chip; the tile size follows on the device)
+  const uint32_t tile2 = debug_knob(3) == 256 ? 256u : (debug_knob(3) == 64 ? 64u : (uint32_t)kUTile);
+  uint64_t n_tiles2 = tile_count(n_bytes, tile2);            // the unique words together are no longer than the text
+  if (n_tiles2 > kUMaxTiles) n_tiles2 = kUMaxTiles;
   const uint64_t nb_new = (n_tiles + 1023) / 1024;
   if ((rc = t->dd_utext.reserve(n_bytes + 64)) || (rc = t->dd_uoff.reserve((max_uniq + 2) * 8)) || (rc = t->dd_misc.reserve(64)) ||
       (rc = t->dd_uslot.reserve((max_uniq + 2) * 4)) || (rc = t->dd_newlist.reserve((n_bytes / 2 + 2) * 8)) ||
@@ -1184,10 +1201,10 @@ static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_
   hipLaunchKernelGGL(bpe_ureg_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, d_sent_off, plan1, D, new_local,
                      new_blk + 1 + nb_new, d_misc, t->dd_uslot.as<uint32_t>(), t->dd_uoff.as<uint64_t>(), t->dd_utext.as<uint8_t>());
   // encode the unique words once (raw-word mode: each one is a "sentence"); their token runs stay in ws2.scratch
-  launch_plan_dev(t->dd_uoff.as<uint64_t>(), d_misc, n_tiles2, kBpeTile, t->ws2.plan.as<uint64_t>(), st);
+  launch_plan_dev(t->dd_uoff.as<uint64_t>(), d_misc, n_tiles2, tile2, t->ws2.plan.as<uint64_t>(), st);
   prof_begin(st);
   launch_encode_kernel(t, n_tiles2, t->ws2, t->dd_utext.as<uint8_t>(), n_bytes, t->dd_uoff.as<uint64_t>(), nullptr,
-                       t->dd_uslot.as<uint32_t>(), D.rec, st);
+                       t->dd_uslot.as<uint32_t>(), D.rec, st, (int)(2 * tile2));
   prof_end(st);
   // records -> counts -> scan -> tokens
   hipLaunchKernelGGL(bpe_refcount_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, plan1, wref,

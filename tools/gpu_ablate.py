@@ -25,7 +25,7 @@ def run(knob, reps=20):
         bpe._table.encode_dev(d_text.data_ptr(), nb, d_off.data_ptr(), ns, d_out.data_ptr(), d_oo.data_ptr(), d_n.data_ptr(), 0, 0)
     torch.cuda.synchronize(); ms, n = N.profile_read(); N.profile_enable(False)
     return ms / n * 1e3
-N.debug_knob(1, 1)
+N.debug_knob(1, 0 if os.environ.get("SWT_ABLATE_DEDUP") else 1)  # default: the direct path; SWT_ABLATE_DEDUP=1: the unique-word pass
 for name, k in [("full", 0), ("stage only", 1), ("no class table", 2), ("no first-round lookups", 4), ("no merge loop", 8),
                 ("no word phase D", 16), ("no compaction/record", 32), ("no D, no lookups", 20), ("no D/lookups/cls", 22),
                 ("B only (no C-lookups, D, E)", 52)]:
