@@ -142,6 +142,28 @@ def test_bpe_dedup_path_equals_direct_path(bpe, bpe_orc, dev, corpora):
         assert np.array_equal(ids_e, ids_n) and np.array_equal(off_e, off_n)
 
 
+def test_bpe_dedup_growing_batches_and_epoch_wrap(swt, oracle, dev, bpe, corpora):
+    """a fresh handle whose workspaces grow from call to call (scan tickets of new buffers), and more than 256 calls on
+    one handle (the word table's 8-bit epoch wraps and the table is cleared)"""
+    merges = list(bpe.merges_list[:2000])
+    tok = swt.FastBPE()
+    tok.merges_list = list(merges)
+    tok._build_table()
+    orc = oracle.OracleBPE(merges)
+    pan, t5k = corpora["pan"], corpora["t5k"]
+    try:
+        dev.debug_knob(1, 2)
+        for texts in (pan[:3], pan[:200], t5k[:3000], pan[:50], t5k, ["a b c"]):
+            same_bpe(tok, orc, texts)
+        small = pan[:40]
+        want = orc.tokenize_batch_ids(small)
+        for i in range(300):
+            ids, off = tok.encode_ids_batch(small)
+            assert np.array_equal(ids, want[0]) and np.array_equal(off, want[1]), i
+    finally:
+        dev.debug_knob(1, 0)
+
+
 def test_bpe_ragged_random_batches(bpe, bpe_orc, corpora):
     rng = np.random.default_rng(7)
     pool = corpora["t5k"] + corpora["pan"] + ["", " ", "x" * 5000, "ala, ma! kota?"]

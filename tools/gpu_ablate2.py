@@ -18,7 +18,7 @@ def run(knob, reps=4):
     N.debug_knob(2, knob)
     for _ in range(3):
         bpe._table.encode_dev(d_text.data_ptr(), nb, d_off.data_ptr(), ns, d_out.data_ptr(), d_oo.data_ptr(), d_n.data_ptr(), 0, 0)
-    torch.cuda.synchronize(); N.profile_enable(True); N.profile_read()
+    torch.cuda.synchronize(); N.profile_enable(3); N.profile_read()
     for _ in range(reps):
         bpe._table.encode_dev(d_text.data_ptr(), nb, d_off.data_ptr(), ns, d_out.data_ptr(), d_oo.data_ptr(), d_n.data_ptr(), 0, 0)
     torch.cuda.synchronize(); ms, n = N.profile_read(); N.profile_enable(False)
