@@ -523,11 +523,6 @@ constexpr int kDBlocks = kDCap / 64;
 constexpr uint64_t kDedupMinBytes = 1u << 18;
 constexpr unsigned long long kDOffMask = (1ull << 40) - 1ull;
 constexpr uint32_t kRefSlot = 0x80000000u;
-// The unique words are numbered by LENGTH CLASS first (then tile, then text order), so the tiles of the unique-word pass
-// hold words of similar length: a tile pays one merge round per round of its longest word, and mixed tiles made every
-// tile pay for a long one.
-constexpr int kDClasses = 4;
-__device__ __forceinline__ uint32_t dd_len_class(uint32_t len) { return len <= 5u ? 0u : (len <= 8u ? 1u : (len <= 12u ? 2u : 3u)); }
 
 typedef uint64_t u64u __attribute__((aligned(1)));  // unaligned 8-byte access (one global_load / ds_read on gfx950)
 
@@ -543,8 +538,7 @@ struct DedupTab {
   // that alone cost 170 us of a 230 us kernel).  The tile that inserted a word lists it; a scan over the tiles'
   // (count, bytes) numbers the words afterwards (bpe_ureg_kernel).
   unsigned long long *newlist;   // slot:32 | position:32 (the inserter leaves the byte length in rec[slot]); a tile's entries start at [span_base >> 1]
-  unsigned long long *tile_new;  // [length class][tile]: new words:32 | their bytes:32 (a dedup call holds at most 2^30 bytes)
-  uint64_t n_tiles;
+  unsigned long long *tile_new;  // per tile: new words:32 | their bytes:32 (a dedup call holds at most 2^30 bytes)
   unsigned int *overflow;
 };
 
@@ -662,7 +656,6 @@ struct WordrefLds {
   uint32_t nwb[kDBlocks + 1];
   uint64_t giant_end;
   uint32_t giant_new, giant_word;
-  unsigned long long cnew[kDClasses];  // per length class: new words:32 | bytes:32
 };
 
 __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restrict__ text, uint64_t n_bytes,
@@ -676,8 +669,7 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
   const uint64_t t = blockIdx.x;
   const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
   if (s_lo == s_hi) {
-    if (lane < kDClasses) D.tile_new[(uint64_t)lane * D.n_tiles + t] = 0ull;
-    if (lane == 0) tile_words[t] = 0u;
+    if (lane == 0) { D.tile_new[t] = 0ull; tile_words[t] = 0u; }
     return;
   }
   reinterpret_cast<uint4 *>(L.cls_lo)[lane] = reinterpret_cast<const uint4 *>(cls_tab)[lane];
@@ -687,7 +679,7 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
   unsigned long long *const my_list = D.newlist + (span_base >> 1);  // room for one entry per two bytes of the span
   uint32_t *const my_rec = wref + span_base;  // the tile's word records, dense, in text order (at most one per byte)
   uint32_t n_new = 0, words_done = 0;  // wave-uniform
-  if (lane < kDClasses) L.cnew[lane] = 0ull;
+  unsigned long long my_bytes = 0;     // per lane, summed at the end
   for (;;) {
     const uint64_t abase = cb & ~15ull;
     const uint32_t off0 = (uint32_t)(cb - abase);
@@ -798,7 +790,7 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
               if (fresh) {
                 D.rec[idx] = wl;
                 my_list[n_new] = ((unsigned long long)idx << 32) | cb;
-                atomicAdd(&L.cnew[dd_len_class((uint32_t)(wl > 0xFFFFu ? 0xFFFFu : wl))], (1ull << 32) | wl);
+                my_bytes += wl;
                 L.giant_new = 1;
               }
             }
@@ -860,7 +852,7 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
       if (is_new) {
         D.rec[idx] = wlen;
         my_list[n_new + __popcll(NEWm & lt)] = ((unsigned long long)idx << 32) | (abase + s);
-        atomicAdd(&L.cnew[dd_len_class(wlen)], (1ull << 32) | wlen);
+        my_bytes += wlen;
       }
       n_new += (uint32_t)__popcll(NEWm);
       words_done += (uint32_t)__popcll(__ballot(mine_w));
@@ -880,14 +872,14 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
     s_next += gone;
     __syncthreads();
   }
-  __syncthreads();
-  if (lane < kDClasses) D.tile_new[(uint64_t)lane * D.n_tiles + t] = L.cnew[lane];
-  if (lane == 0) tile_words[t] = words_done;
-  (void)n_new;
+  for (int d = 32; d >= 1; d >>= 1) my_bytes += __shfl_xor(my_bytes, d);
+  if (lane == 0) {
+    D.tile_new[t] = ((unsigned long long)n_new << 32) | my_bytes;
+    tile_words[t] = words_done;
+  }
 }
 
-// Numbers the new words (scan of tile_new: class-major, then tile; inside a tile in text order) and copies them into the
-// unique-word text.
+// Numbers the new words of every tile (scan of tile_new) and copies them into the unique-word text.
 __global__ __launch_bounds__(64) void bpe_ureg_kernel(const uint8_t *__restrict__ text, const uint64_t *__restrict__ sent_off,
                                                       const uint64_t *__restrict__ plan, DedupTab D,
                                                       const unsigned long long *__restrict__ new_local,
@@ -895,53 +887,34 @@ __global__ __launch_bounds__(64) void bpe_ureg_kernel(const uint8_t *__restrict_
                                                       const unsigned long long *__restrict__ d_total, uint32_t *__restrict__ uslot,
                                                       uint64_t *__restrict__ uoff, uint8_t *__restrict__ utext) {
   const int lane = threadIdx.x;
-  const unsigned long long lt = (1ull << lane) - 1ull;
   const uint64_t t = blockIdx.x;
   const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
   if (t == 0 && lane == 0) uoff[*d_total >> 32] = *d_total & 0xFFFFFFFFull;  // the end of the last unique word
   if (s_lo == s_hi) return;
-  uint32_t n_new = 0;
-  uint64_t u0[kDClasses], b0[kDClasses];
-#pragma unroll
-  for (int c = 0; c < kDClasses; c++) {
-    const uint64_t i = (uint64_t)c * D.n_tiles + t;
-    n_new += (uint32_t)(D.tile_new[i] >> 32);
-    const unsigned long long base = new_blk_base[i >> 10] + new_local[i];
-    u0[c] = base >> 32;
-    b0[c] = base & 0xFFFFFFFFull;
-  }
+  const uint32_t n_new = (uint32_t)(D.tile_new[t] >> 32);
   if (!n_new) return;
+  const unsigned long long base = new_blk_base[t >> 10] + new_local[t];
+  const uint64_t u0 = base >> 32;
+  uint64_t b0 = base & 0xFFFFFFFFull;
   const unsigned long long *my_list = D.newlist + (sent_off[s_lo] >> 1);
   for (uint32_t k0 = 0; k0 < n_new; k0 += 64) {
     const uint32_t k = k0 + lane;
-    const bool have = k < n_new;
-    const unsigned long long e = have ? my_list[k] : 0ull;
+    const unsigned long long e = k < n_new ? my_list[k] : 0ull;
     const uint32_t idx = (uint32_t)(e >> 32);
     const uint64_t pos = e & 0xFFFFFFFFull;
-    const uint32_t len = have ? (uint32_t)D.rec[idx] : 0u;
-    const uint32_t cls = dd_len_class(len);
-    // byte prefix inside my class: one 64-bit wave scan, classes 0..2 in narrow fields (64 words of at most 12 bytes)
-    const int sh = cls == 0 ? 0 : (cls == 1 ? 9 : (cls == 2 ? 19 : 29));
-    unsigned long long x = have ? ((unsigned long long)len << sh) : 0ull;
+    const uint32_t len = k < n_new ? (uint32_t)D.rec[idx] : 0u;
+    uint32_t x = len;
     for (int d = 1; d < 64; d <<= 1) {
-      const unsigned long long y = __shfl_up(x, d);
+      const uint32_t y = __shfl_up(x, d);
       if (lane >= d) x += y;
     }
-    const unsigned long long tot = __shfl(x, 63);
-    unsigned long long Mc[kDClasses];
-#pragma unroll
-    for (int c = 0; c < kDClasses; c++) Mc[c] = __ballot(have && cls == (uint32_t)c);
-    if (have) {
-      const uint64_t incl = cls == 0 ? (x & 0x1FFull) : (cls == 1 ? ((x >> 9) & 0x3FFull) : (cls == 2 ? ((x >> 19) & 0x3FFull) : (x >> 29)));
-      const uint64_t u = u0[cls] + (uint32_t)__popcll(Mc[cls] & lt);
-      const uint64_t bo = b0[cls] + incl - len;
-      uoff[u] = bo;
-      uslot[u] = idx;
+    if (k < n_new) {
+      const uint64_t bo = b0 + (x - len);
+      uoff[u0 + k] = bo;
+      uslot[u0 + k] = idx;
       for (uint32_t i = 0; i < len; i++) utext[bo + i] = text[pos + i];
     }
-    u0[0] += (uint32_t)__popcll(Mc[0]); u0[1] += (uint32_t)__popcll(Mc[1]);
-    u0[2] += (uint32_t)__popcll(Mc[2]); u0[3] += (uint32_t)__popcll(Mc[3]);
-    b0[0] += tot & 0x1FFull; b0[1] += (tot >> 9) & 0x3FFull; b0[2] += (tot >> 19) & 0x3FFull; b0[3] += tot >> 29;
+    b0 += __shfl(x, 63);
   }
 }
 
@@ -1193,10 +1166,10 @@ static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_
   const uint32_t tile2 = debug_knob(3) == 256 ? 256u : (debug_knob(3) == 64 ? 64u : (uint32_t)kUTile);
   uint64_t n_tiles2 = tile_count(n_bytes, tile2);            // the unique words together are no longer than the text
   if (n_tiles2 > kUMaxTiles) n_tiles2 = kUMaxTiles;
-  const uint64_t nb_new = (kDClasses * n_tiles + 1023) / 1024;
+  const uint64_t nb_new = (n_tiles + 1023) / 1024;
   if ((rc = t->dd_utext.reserve(n_bytes + 64)) || (rc = t->dd_uoff.reserve((max_uniq + 2) * 8)) || (rc = t->dd_misc.reserve(64)) ||
       (rc = t->dd_uslot.reserve((max_uniq + 2) * 4)) || (rc = t->dd_newlist.reserve((n_bytes / 2 + 2) * 8)) ||
-      (rc = t->dd_tile_new.reserve((kDClasses * n_tiles + 1) * 8)) || (rc = t->dd_new_local.reserve((kDClasses * n_tiles + 1) * 8)) ||
+      (rc = t->dd_tile_new.reserve((n_tiles + 1) * 8)) || (rc = t->dd_new_local.reserve((n_tiles + 1) * 8)) ||
       (rc = t->dd_tile_words.reserve((n_tiles + 1) * 4)) || (rc = t->ws2.reserve(n_bytes, max_uniq, n_tiles2)))
     return rc;
   if (t->dd_new_blk.cap < (2 * nb_new + 2) * 8) {
@@ -1213,7 +1186,6 @@ static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_
   D.epoch = t->dd_epoch;
   D.newlist = t->dd_newlist.as<unsigned long long>();
   D.tile_new = t->dd_tile_new.as<unsigned long long>();
-  D.n_tiles = n_tiles;
   D.overflow = reinterpret_cast<unsigned int *>(d_misc + 1);
   if (D.diag) SWT_HIP(hipMemsetAsync(d_misc, 0, 32, st));
   uint32_t *wref = t->ws.scratch.as<uint32_t>();
@@ -1225,7 +1197,7 @@ static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_
   hipLaunchKernelGGL(bpe_wordref_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off, plan1, d_cls, D, wref,
                      t->ws.sent_local.as<uint32_t>(), t->dd_tile_words.as<uint32_t>(), (uint32_t)debug_knob(2));
   prof_end(st, 3);
-  launch_scan_u64(kDClasses * n_tiles, D.tile_new, new_local, new_blk, reinterpret_cast<uint64_t *>(d_misc), st);
+  launch_scan_u64(n_tiles, D.tile_new, new_local, new_blk, reinterpret_cast<uint64_t *>(d_misc), st);
   hipLaunchKernelGGL(bpe_ureg_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, d_sent_off, plan1, D, new_local,
                      new_blk + 1 + nb_new, d_misc, t->dd_uslot.as<uint32_t>(), t->dd_uoff.as<uint64_t>(), t->dd_utext.as<uint8_t>());
   // encode the unique words once (raw-word mode: each one is a "sentence"); their token runs stay in ws2.scratch

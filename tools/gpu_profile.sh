@@ -11,13 +11,23 @@ for w in bpe_encode wp_encode bpe_train; do
 done
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --workload bpe_encode --steps 5 --warmup 1 > $O/pmc_$c.json 2> $O/pmc_$c.err; echo "pmc $c exit=$?"
-  f=$(find $O/pmc_$c -name "*counter_collection.csv" | head -1); echo $f; head -1 "$f"; grep bpe_encode_kernel "$f" | head -3
-  python3 - "$f" $c <<'PY'
-import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "bpe_encode_kernel" in r.get("Kernel_Name", "")]
-vals = [float(r["Counter_Value"]) for r in rows if r.get("Counter_Name") == sys.argv[2]]
-print(sys.argv[2], "launches", len(vals), "mean", sum(vals) / max(len(vals), 1))
+  f=$(find $O/pmc_$c -name "*counter_collection.csv" | head -1); echo $f
+  python3 - "$f" $c $O <<'PY'
+import csv, sys, collections
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "swt::" in r.get("Kernel_Name", "") and r.get("Counter_Name") == sys.argv[2]]
+per = collections.defaultdict(list)
+for r in rows:
+    per[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+calls = len(per.get("swt::bpe_wordref_kernel", [])) or 1
+tot = 0.0
+with open("%s/bpe_encode_%s_per_kernel.csv" % (sys.argv[3], sys.argv[2]), "w") as o:
+    o.write("kernel,launches,mean_%s_KiB_per_launch\n" % sys.argv[2])
+    for k, v in sorted(per.items()):
+        o.write("%s,%d,%.1f\n" % (k, len(v), sum(v) / len(v)))
+        tot += sum(v)
+    o.write("ALL swt kernels per call (%d calls),,%.1f\n" % (calls, tot / calls))
+print(open("%s/bpe_encode_%s_per_kernel.csv" % (sys.argv[3], sys.argv[2])).read())
 PY
 done
-rm -rf $O/bpe_encode $O/wp_encode $O/bpe_train
+rm -rf $O/bpe_encode $O/wp_encode $O/bpe_train $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 ls -la $O
