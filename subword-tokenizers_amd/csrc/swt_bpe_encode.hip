@@ -535,16 +535,11 @@ struct DedupTab {
   uint32_t bits;
   uint32_t epoch;
   // New words are NOT numbered with a global counter (one hot address serialises every returning atomic of the chip:
-  // that alone cost 170 us of a 230 us kernel).  The tile that inserted a word lists it and numbers its list itself once
-  // it knows the (count, bytes) of the tiles before it (decoupled look-back, swt_tile.h).
+  // that alone cost 170 us of a 230 us kernel).  The tile that inserted a word lists it; a scan over the tiles'
+  // (count, bytes) numbers the words afterwards (bpe_ureg_kernel).
   unsigned long long *newlist;   // slot:32 | position:32 (the inserter leaves the byte length in rec[slot]); a tile's entries start at [span_base >> 1]
-  unsigned long long *desc_new;  // look-back descriptors of bpe_wordref_kernel: new words:31 | their bytes:31
-  unsigned long long *total;     // out: unique words:32 | their bytes:32
-  uint32_t *uslot;               // per unique word: its slot
-  uint8_t *utext;                // the unique words, concatenated
-  uint64_t *uoff;                // their offsets
-  uint64_t n_tiles;
-  unsigned int *overflow;        // [0] a look-back gave up (never seen), [1..2] diagnostics
+  unsigned long long *tile_new;  // per tile: new words:32 | their bytes:32 (a dedup call holds at most 2^30 bytes)
+  unsigned int *overflow;
 };
 
 // the same function as the wide form in dd_find_or_insert_lds, byte by byte (words in global memory)
@@ -674,16 +669,7 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
   const uint64_t t = blockIdx.x;
   const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
   if (s_lo == s_hi) {
-    if (lane == 0) tile_words[t] = 0u;
-    if (t + 1 == D.n_tiles) {  // the last tile reports the totals
-      const unsigned long long base = lookback_exclusive(D.desc_new, t, 0ull, D.overflow);
-      if (lane == 0) {
-        *D.total = ((base >> 31) << 32) | (base & 0x7FFFFFFFull);
-        D.uoff[base >> 31] = base & 0x7FFFFFFFull;
-      }
-    } else if (lane == 0) {
-      __hip_atomic_store(&D.desc_new[t], t == 0 ? kLbIncl : kLbAgg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (lane == 0) { D.tile_new[t] = 0ull; tile_words[t] = 0u; }
     return;
   }
   reinterpret_cast<uint4 *>(L.cls_lo)[lane] = reinterpret_cast<const uint4 *>(cls_tab)[lane];
@@ -887,19 +873,36 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
     __syncthreads();
   }
   for (int d = 32; d >= 1; d >>= 1) my_bytes += __shfl_xor(my_bytes, d);
-  if (lane == 0) tile_words[t] = words_done;
-  // Number this tile's new words: (count, bytes) of the tiles before it by decoupled look-back, then copy the words into
-  // the unique-word text.  (This used to be a scan launch plus a registration launch.)
-  const unsigned long long base = lookback_exclusive(D.desc_new, t, ((unsigned long long)n_new << 31) | my_bytes, D.overflow);
-  const uint64_t u0 = base >> 31;
-  uint64_t b0 = base & 0x7FFFFFFFull;
+  if (lane == 0) {
+    D.tile_new[t] = ((unsigned long long)n_new << 32) | my_bytes;
+    tile_words[t] = words_done;
+  }
+}
+
+// Numbers the new words of every tile (scan of tile_new) and copies them into the unique-word text.
+__global__ __launch_bounds__(64) void bpe_ureg_kernel(const uint8_t *__restrict__ text, const uint64_t *__restrict__ sent_off,
+                                                      const uint64_t *__restrict__ plan, DedupTab D,
+                                                      const unsigned long long *__restrict__ new_local,
+                                                      const unsigned long long *__restrict__ new_blk_base,
+                                                      const unsigned long long *__restrict__ d_total, uint32_t *__restrict__ uslot,
+                                                      uint64_t *__restrict__ uoff, uint8_t *__restrict__ utext) {
+  const int lane = threadIdx.x;
+  const uint64_t t = blockIdx.x;
+  const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
+  if (t == 0 && lane == 0) uoff[*d_total >> 32] = *d_total & 0xFFFFFFFFull;  // the end of the last unique word
+  if (s_lo == s_hi) return;
+  const uint32_t n_new = (uint32_t)(D.tile_new[t] >> 32);
+  if (!n_new) return;
+  const unsigned long long base = new_blk_base[t >> 10] + new_local[t];
+  const uint64_t u0 = base >> 32;
+  uint64_t b0 = base & 0xFFFFFFFFull;
+  const unsigned long long *my_list = D.newlist + (sent_off[s_lo] >> 1);
   for (uint32_t k0 = 0; k0 < n_new; k0 += 64) {
     const uint32_t k = k0 + lane;
-    // the list and rec[] were written by lanes of this wave: read them back past the vector cache
-    const unsigned long long e = k < n_new ? __hip_atomic_load(&my_list[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    const unsigned long long e = k < n_new ? my_list[k] : 0ull;
     const uint32_t idx = (uint32_t)(e >> 32);
     const uint64_t pos = e & 0xFFFFFFFFull;
-    const uint32_t len = k < n_new ? (uint32_t)__hip_atomic_load(&D.rec[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    const uint32_t len = k < n_new ? (uint32_t)D.rec[idx] : 0u;
     uint32_t x = len;
     for (int d = 1; d < 64; d <<= 1) {
       const uint32_t y = __shfl_up(x, d);
@@ -907,15 +910,11 @@ __global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restri
     }
     if (k < n_new) {
       const uint64_t bo = b0 + (x - len);
-      D.uoff[u0 + k] = bo;
-      D.uslot[u0 + k] = idx;
-      for (uint32_t i = 0; i < len; i++) D.utext[bo + i] = text[pos + i];
+      uoff[u0 + k] = bo;
+      uslot[u0 + k] = idx;
+      for (uint32_t i = 0; i < len; i++) utext[bo + i] = text[pos + i];
     }
     b0 += __shfl(x, 63);
-  }
-  if (t + 1 == D.n_tiles && lane == 0) {
-    *D.total = ((unsigned long long)(u0 + n_new) << 32) | b0;
-    D.uoff[u0 + n_new] = b0;  // the end of the last unique word
   }
 }
 
@@ -927,39 +926,43 @@ __device__ __forceinline__ uint32_t ref_count(uint32_t v, const unsigned long lo
   return (uint32_t)(r >> 32);
 }
 
-// Final tokens + sentence offsets, one launch: count the tile's tokens from its word records, get the tokens of the tiles
-// before it by decoupled look-back (this used to be a count launch and a scan launch), then copy.
+// tokens per tile (a tile's word records are the first tile_words[t] entries behind wref[span_base])
+__global__ __launch_bounds__(64) void bpe_refcount_kernel(const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
+                                                          const uint32_t *__restrict__ wref, const uint32_t *__restrict__ tile_words,
+                                                          const unsigned long long *__restrict__ rec, uint32_t *__restrict__ tile_tok) {
+  const uint64_t t = blockIdx.x;
+  const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
+  uint32_t total = 0;
+  if (s_lo != s_hi) {
+    const uint32_t *my_rec = wref + sent_off[s_lo];
+    const uint32_t n_w = tile_words[t];
+    for (uint32_t k = threadIdx.x; k < n_w; k += 64) {
+      uint64_t src;
+      total += ref_count(my_rec[k], rec, src);
+    }
+    for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
+  }
+  if (threadIdx.x == 0) tile_tok[t] = total;
+}
+
+// final tokens + sentence offsets
 __global__ __launch_bounds__(64) void bpe_refwrite_kernel(const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
                                                           uint64_t n_tiles, uint64_t n_sent, const uint32_t *__restrict__ wref,
                                                           const uint32_t *__restrict__ tile_words, const uint32_t *__restrict__ sent_word,
                                                           const unsigned long long *__restrict__ rec,
-                                                          const uint32_t *__restrict__ u_ids, unsigned long long *__restrict__ desc,
-                                                          unsigned int *__restrict__ err, uint64_t *__restrict__ n_tokens,
-                                                          uint32_t *__restrict__ out_ids, uint64_t *__restrict__ out_off) {
+                                                          const uint32_t *__restrict__ u_ids, const uint32_t *__restrict__ tile_base,
+                                                          const unsigned long long *__restrict__ blk_base,
+                                                          const uint64_t *__restrict__ n_tokens, uint32_t *__restrict__ out_ids,
+                                                          uint64_t *__restrict__ out_off) {
   __shared__ uint32_t pre[kDCap];
   const int lane = threadIdx.x;
   const uint64_t t = blockIdx.x;
   const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
-  const bool empty = s_lo == s_hi;
-  const uint32_t *my_rec = wref + (empty ? 0 : sent_off[s_lo]);
-  const uint32_t n_w = empty ? 0u : tile_words[t];
-  uint32_t total = 0;
-  for (uint32_t k = lane; k < n_w; k += 64) {
-    uint64_t src;
-    total += ref_count(my_rec[k], rec, src);
-  }
-  for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
-  uint64_t base;
-  if (empty && t + 1 != n_tiles) {
-    if (lane == 0) __hip_atomic_store(&desc[t], t == 0 ? kLbIncl : kLbAgg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
-  }
-  base = lookback_exclusive(desc, t, total, err);
-  if (t + 1 == n_tiles && lane == 0) {
-    *n_tokens = base + total;
-    out_off[n_sent] = base + total;
-  }
-  if (empty) return;
+  if (t == n_tiles - 1 && lane == 0) out_off[n_sent] = *n_tokens;
+  if (s_lo == s_hi) return;
+  const uint64_t base = blk_base[t >> 10] + tile_base[t];
+  const uint32_t *my_rec = wref + sent_off[s_lo];
+  const uint32_t n_w = tile_words[t];
   uint64_t s_next = s_lo;
   uint32_t run = 0;
   for (uint32_t k0 = 0;; k0 += kDCap) {
@@ -1016,9 +1019,8 @@ struct swt_bpe_table {
   DevBuf in_text, in_off, out_ids, out_off, n_tok;  // staging for the host-buffer entry point
   // word-level dedup inside one call
   TileWorkspace ws2;          // workspaces of the encode over the unique words
-  DevBuf dd_slot, dd_rec, dd_uslot, dd_utext, dd_uoff, dd_misc, dd_newlist, dd_desc_new, dd_desc_tok, dd_tile_words;
+  DevBuf dd_slot, dd_rec, dd_uslot, dd_utext, dd_uoff, dd_misc, dd_newlist, dd_tile_new, dd_new_local, dd_new_blk, dd_tile_words;
   uint32_t dd_bits = 0, dd_epoch = 0;
-  bool dd_misc_clean = false;
 };
 
 static int bpe_upload(swt_bpe_table *t) {
@@ -1096,7 +1098,7 @@ void swt_bpe_table_destroy(swt_bpe_table *t) {
   t->ws.release();
   t->ws2.release();
   for (DevBuf *b : {&t->in_text, &t->in_off, &t->out_ids, &t->out_off, &t->n_tok, &t->dd_slot, &t->dd_rec, &t->dd_uslot, &t->dd_utext, &t->dd_uoff,
-                    &t->dd_misc, &t->dd_newlist, &t->dd_desc_new, &t->dd_desc_tok, &t->dd_tile_words})
+                    &t->dd_misc, &t->dd_newlist, &t->dd_tile_new, &t->dd_new_local, &t->dd_new_blk, &t->dd_tile_words})
     b->release();
   delete t;
 }
@@ -1134,7 +1136,7 @@ static int bpe_encode_direct(swt_bpe_table *t, TileWorkspace &ws, const uint8_t 
   return SWT_OK;
 }
 
-// The dedup path: five launches, no host round trip (the number of unique words stays on the device: the unique-word
+// The dedup path: nine launches, no host round trip (the number of unique words stays on the device: the unique-word
 // encode is launched over as many tiles as the whole text could need and the tiles behind the real ones find an empty
 // plan).  Returns 1 when the batch is too large for the 32-bit fields of this path (the caller takes the direct path).
 static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off, uint64_t n_sent,
@@ -1164,17 +1166,17 @@ static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_
   const uint32_t tile2 = debug_knob(3) == 256 ? 256u : (debug_knob(3) == 64 ? 64u : (uint32_t)kUTile);
   uint64_t n_tiles2 = tile_count(n_bytes, tile2);            // the unique words together are no longer than the text
   if (n_tiles2 > kUMaxTiles) n_tiles2 = kUMaxTiles;
+  const uint64_t nb_new = (n_tiles + 1023) / 1024;
   if ((rc = t->dd_utext.reserve(n_bytes + 64)) || (rc = t->dd_uoff.reserve((max_uniq + 2) * 8)) || (rc = t->dd_misc.reserve(64)) ||
       (rc = t->dd_uslot.reserve((max_uniq + 2) * 4)) || (rc = t->dd_newlist.reserve((n_bytes / 2 + 2) * 8)) ||
-      (rc = t->dd_desc_new.reserve((n_tiles + 1) * 8)) || (rc = t->dd_desc_tok.reserve((n_tiles + 1) * 8)) ||
+      (rc = t->dd_tile_new.reserve((n_tiles + 1) * 8)) || (rc = t->dd_new_local.reserve((n_tiles + 1) * 8)) ||
       (rc = t->dd_tile_words.reserve((n_tiles + 1) * 4)) || (rc = t->ws2.reserve(n_bytes, max_uniq, n_tiles2)))
     return rc;
-  // [0] unique words:32 | their bytes:32, [1] low word: "a look-back gave up", then diagnostics
-  unsigned long long *d_misc = t->dd_misc.as<unsigned long long>();
-  if (!t->dd_misc_clean) {
-    SWT_HIP(hipMemsetAsync(d_misc, 0, 32, st));
-    t->dd_misc_clean = true;
+  if (t->dd_new_blk.cap < (2 * nb_new + 2) * 8) {
+    if ((rc = t->dd_new_blk.reserve((2 * nb_new + 2) * 8))) return rc;
+    SWT_HIP(hipMemsetAsync(t->dd_new_blk.p, 0, t->dd_new_blk.cap, st));  // the scan's ticket starts at zero (and leaves it so)
   }
+  unsigned long long *d_misc = t->dd_misc.as<unsigned long long>();  // [0] unique words:32 | their bytes:32, [1..2] diagnostics
   DedupTab D;
   D.slot = t->dd_slot.as<unsigned long long>();
   D.rec = t->dd_rec.as<unsigned long long>();
@@ -1183,31 +1185,35 @@ static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_
   D.bits = t->dd_bits;
   D.epoch = t->dd_epoch;
   D.newlist = t->dd_newlist.as<unsigned long long>();
-  D.desc_new = t->dd_desc_new.as<unsigned long long>();
-  D.total = d_misc;
-  D.uslot = t->dd_uslot.as<uint32_t>();
-  D.utext = t->dd_utext.as<uint8_t>();
-  D.uoff = t->dd_uoff.as<uint64_t>();
-  D.n_tiles = n_tiles;
+  D.tile_new = t->dd_tile_new.as<unsigned long long>();
   D.overflow = reinterpret_cast<unsigned int *>(d_misc + 1);
-  if (D.diag) SWT_HIP(hipMemsetAsync(d_misc + 1, 0, 16, st));
+  if (D.diag) SWT_HIP(hipMemsetAsync(d_misc, 0, 32, st));
   uint32_t *wref = t->ws.scratch.as<uint32_t>();
   uint64_t *plan1 = t->ws.plan.as<uint64_t>();
+  unsigned long long *new_local = t->dd_new_local.as<unsigned long long>(), *new_blk = t->dd_new_blk.as<unsigned long long>();
   prof_begin(st, 2);
-  launch_plan(d_sent_off, n_sent, n_tiles, kDTile, plan1, st, D.desc_new, t->dd_desc_tok.as<unsigned long long>());
+  launch_plan(d_sent_off, n_sent, n_tiles, kDTile, plan1, st);
   prof_begin(st, 3);
   hipLaunchKernelGGL(bpe_wordref_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off, plan1, d_cls, D, wref,
                      t->ws.sent_local.as<uint32_t>(), t->dd_tile_words.as<uint32_t>(), (uint32_t)debug_knob(2));
   prof_end(st, 3);
+  launch_scan_u64(n_tiles, D.tile_new, new_local, new_blk, reinterpret_cast<uint64_t *>(d_misc), st);
+  hipLaunchKernelGGL(bpe_ureg_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, d_sent_off, plan1, D, new_local,
+                     new_blk + 1 + nb_new, d_misc, t->dd_uslot.as<uint32_t>(), t->dd_uoff.as<uint64_t>(), t->dd_utext.as<uint8_t>());
   // encode the unique words once (raw-word mode: each one is a "sentence"); their token runs stay in ws2.scratch
   launch_plan_dev(t->dd_uoff.as<uint64_t>(), d_misc, n_tiles2, tile2, t->ws2.plan.as<uint64_t>(), st);
   prof_begin(st);
   launch_encode_kernel(t, n_tiles2, t->ws2, t->dd_utext.as<uint8_t>(), n_bytes, t->dd_uoff.as<uint64_t>(), nullptr,
                        t->dd_uslot.as<uint32_t>(), D.rec, st, (int)(2 * tile2));
   prof_end(st);
+  // records -> counts -> scan -> tokens
+  hipLaunchKernelGGL(bpe_refcount_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, plan1, wref,
+                     t->dd_tile_words.as<uint32_t>(), D.rec, t->ws.tile_tok.as<uint32_t>());
+  const uint64_t nb = (n_tiles + 1023) / 1024;
+  launch_scan_only(n_tiles, t->ws, d_n_tokens, st);
   hipLaunchKernelGGL(bpe_refwrite_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, plan1, n_tiles, n_sent, wref,
                      t->dd_tile_words.as<uint32_t>(), t->ws.sent_local.as<uint32_t>(), D.rec, t->ws2.scratch.as<uint32_t>(),
-                     t->dd_desc_tok.as<unsigned long long>(), D.overflow, d_n_tokens, d_out_ids, d_out_off);
+                     t->ws.tile_base.as<uint32_t>(), t->ws.blk.as<unsigned long long>() + 1 + nb, d_n_tokens, d_out_ids, d_out_off);
   prof_end(st, 2);
   SWT_HIP(hipGetLastError());
   if (D.diag) {
@@ -1269,14 +1275,6 @@ int swt_bpe_encode(swt_bpe_table *t, const uint8_t *text, const uint64_t *sent_o
   if (rc) return rc;
   uint64_t nt = 0;
   SWT_HIP(hipMemcpy(&nt, t->n_tok.p, 8, hipMemcpyDeviceToHost));
-  if (t->dd_misc.p) {  // the dedup path's look-backs are bounded; one that gave up leaves a mark (never seen so far)
-    unsigned int gave_up = 0;
-    SWT_HIP(hipMemcpy(&gave_up, t->dd_misc.as<unsigned long long>() + 1, 4, hipMemcpyDeviceToHost));
-    if (gave_up) {
-      SWT_HIP(hipMemset(t->dd_misc.as<unsigned long long>() + 1, 0, 4));
-      return fail(SWT_ERR_STATE, "a tile's look-back timed out (workgroups were not dispatched in index order?); the ids of this call are invalid");
-    }
-  }
   *n_tokens = nt;
   SWT_HIP(hipMemcpy(out_off, t->out_off.p, (n_sent + 1) * 8, hipMemcpyDeviceToHost));
   if (nt > out_cap)

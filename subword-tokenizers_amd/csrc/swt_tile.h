@@ -125,56 +125,7 @@ struct TileWorkspace {
 inline uint64_t tile_count(uint64_t n_bytes, uint32_t tile = kTile) { return n_bytes ? (n_bytes + tile - 1) / tile : 1; }
 
 // Host launchers of the skeleton's own kernels (defined in swt_tile.hip).
-// zero_a / zero_b (optional): arrays of n_tiles + 1 words cleared by the same launch (look-back descriptors, below)
-void launch_plan(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, uint32_t tile, uint64_t *d_plan, hipStream_t st,
-                 unsigned long long *zero_a = nullptr, unsigned long long *zero_b = nullptr);
-
-// ---- decoupled look-back over the tiles of ONE launch (single-wave workgroups, tile = blockIdx.x) ----------------------
-// desc[t] = flag:2 | payload:62, cleared before the launch.  Every tile publishes its aggregate as soon as it knows it and
-// then sums the aggregates of the tiles before it, walking back until it meets a tile that already knows its inclusive
-// prefix.  Payloads add as plain 64-bit integers (callers pack fields that cannot overflow into each other).
-// Forward progress rests on workgroups being dispatched in index order (a tile only ever waits for tiles with a lower index,
-// and the lowest unfinished index is always resident).  The wait is BOUNDED all the same: after kLbMaxPolls empty polls
-// the tile gives up, raises *err and continues with what it has, so a launch always drains.
-constexpr unsigned long long kLbAgg = 1ull << 62, kLbIncl = 2ull << 62, kLbPayload = (1ull << 62) - 1ull;
-constexpr uint32_t kLbMaxPolls = 1u << 20;
-
-// all 64 lanes call it; returns the exclusive prefix of tile t and publishes the inclusive one
-__device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long long *desc, uint64_t t, unsigned long long agg,
-                                                                 unsigned int *err) {
-  const int lane = threadIdx.x & 63;
-  if (t == 0) {
-    if (lane == 0) __hip_atomic_store(&desc[0], kLbIncl | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return 0ull;
-  }
-  if (lane == 0) __hip_atomic_store(&desc[t], kLbAgg | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  unsigned long long excl = 0ull;
-  long long hi = (long long)t - 1;  // nearest tile not yet summed
-  uint32_t polls = 0;
-  for (;;) {
-    const long long j = hi - lane;
-    const unsigned long long d = j >= 0 ? __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kLbIncl;
-    const unsigned f = (unsigned)(d >> 62);
-    const unsigned long long EMPTY = __ballot(f == 0u), INCL = __ballot(f == 2u);
-    const int p = INCL ? __builtin_ctzll(INCL) : 64;                   // nearest lane that holds an inclusive prefix
-    const unsigned long long need = p >= 63 ? ~0ull : ((2ull << p) - 1ull);  // lanes 0 .. p
-    if (EMPTY & need) {
-      if (++polls > kLbMaxPolls) {
-        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-      continue;
-    }
-    unsigned long long x = ((need >> lane) & 1ull) ? (d & kLbPayload) : 0ull;
-    for (int k = 32; k >= 1; k >>= 1) x += __shfl_xor(x, k);
-    excl += x;
-    if (p < 64) break;
-    hi -= 64;
-  }
-  if (lane == 0) __hip_atomic_store(&desc[t], kLbIncl | ((excl + agg) & kLbPayload), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return excl;
-}
+void launch_plan(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, uint32_t tile, uint64_t *d_plan, hipStream_t st);
 // sizes on the device: *d_total = sentences:32 | bytes:32; plan[0 .. n_tiles_max] is written for the smallest tile size
 // >= tile_min that needs at most n_tiles_max tiles; the tiles behind the real ones are empty
 void launch_plan_dev(const uint64_t *d_sent_off, const unsigned long long *d_total, uint64_t n_tiles_max, uint32_t tile_min,

@@ -5,12 +5,9 @@ namespace swt {
 
 // plan[t] = first sentence whose first byte is >= t * tile  (lower bound; plan[n_tiles] = n_sent)
 __global__ void plan_kernel(const uint64_t *__restrict__ sent_off, uint64_t n_sent, uint64_t n_tiles, uint32_t tile,
-                            uint64_t *__restrict__ plan, unsigned long long *__restrict__ zero_a,
-                            unsigned long long *__restrict__ zero_b) {
+                            uint64_t *__restrict__ plan) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t > n_tiles) return;
-  if (zero_a) zero_a[t] = 0ull;  // look-back descriptors of the kernels that follow in this call
-  if (zero_b) zero_b[t] = 0ull;
   if (t == n_tiles) { plan[t] = n_sent; return; }
   const uint64_t target = t * (uint64_t)tile;
   uint64_t lo = 0, hi = n_sent;
@@ -140,10 +137,8 @@ void TileWorkspace::release() {
   plan.release(); scratch.release(); sent_local.release(); tile_tok.release(); tile_base.release(); blk.release();
 }
 
-void launch_plan(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, uint32_t tile, uint64_t *d_plan, hipStream_t st,
-                 unsigned long long *zero_a, unsigned long long *zero_b) {
-  hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n_tiles + 1 + 255) / 256)), dim3(256), 0, st, d_sent_off, n_sent, n_tiles, tile, d_plan,
-                     zero_a, zero_b);
+void launch_plan(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, uint32_t tile, uint64_t *d_plan, hipStream_t st) {
+  hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n_tiles + 1 + 255) / 256)), dim3(256), 0, st, d_sent_off, n_sent, n_tiles, tile, d_plan);
 }
 
 void launch_plan_dev(const uint64_t *d_sent_off, const unsigned long long *d_total, uint64_t n_tiles_max, uint32_t tile_min,
