@@ -53,6 +53,8 @@ def lib():
             "orc_bpe_tokenize": (C.c_uint64, [C.c_void_p, _u32p, C.c_uint64, _u32p]),
             "orc_bpe_tokenize_batch": (C.c_uint64, [C.c_void_p, _u32p, _u64p, C.c_uint64, _u32p, _u64p]),
             "orc_train_new": (C.c_void_p, [_u32p, _u64p, C.c_uint64]),
+            "orc_wptrain_new": (C.c_void_p, [_u32p, _u64p, C.c_uint64]),
+            "orc_wp_score_bits": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64]),
             "orc_train_free": (None, [C.c_void_p]),
             "orc_train_n_words": (C.c_uint64, [C.c_void_p]),
             "orc_train_n_symbols": (C.c_uint64, [C.c_void_p]),
@@ -237,6 +239,23 @@ class OracleBPETrainer:
         freq = np.zeros(max(W, 1), dtype=np.uint32)
         lib().orc_train_export(self._h, _p32(syms), _p64(woff), _p32(freq))
         return syms[:self.n_symbols], woff, freq[:W]
+
+
+class OracleWPTrainer(OracleBPETrainer):
+    """NaiveWP.train restated (source/wordpiece.py:29-103): same accessors; merge_ids()' counts are score bit patterns."""
+
+    def __init__(self, corpus):
+        blob, off = pack([t.lower() for t in corpus])
+        self._h = lib().orc_wptrain_new(_p32(blob), _p64(off), len(corpus))
+
+    @property
+    def merged_tokens(self):
+        ids, _ = self.merge_ids()
+        return [self.symbol(int(m)) for _l, _r, m in ids]
+
+
+def wp_score_bits(cnt, fl, fr):
+    return int(lib().orc_wp_score_bits(cnt, fl, fr))
 
 
 class OracleWP:

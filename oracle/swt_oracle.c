@@ -315,12 +315,16 @@ struct orc_train {
   vec32 ml, mr, mm; vec64 mc; /* merges_list (+ the winning count, for diagnostics) */
   map64 pairs;   /* scratch: PAIR_KEY -> index into pk/pc */
   vec64 pk, pc;
+  int wp;        /* 1: NaiveWP.train (wordpiece.py:29-103): '##' symbols, likelihood score */
+  map64 sfreq;   /* wp scratch: symbol id -> frequency */
 };
 
-orc_train *orc_train_new(const uint32_t *text, const uint64_t *sent_off, uint64_t n_sent) {
+static orc_train *train_new(const uint32_t *text, const uint64_t *sent_off, uint64_t n_sent, int wp) {
   orc_train *t = (orc_train *)calloc(1, sizeof *t);
   st_init(&t->st);
   map_init(&t->pairs, 1 << 16);
+  map_init(&t->sfreq, 1 << 12);
+  t->wp = wp;
   /* bpe.py:70-77: preprocessing, then Counter(new_words) -- insertion order = first occurrence */
   strtab words; st_init(&words);
   vec32 wfreq = {0};
@@ -338,30 +342,74 @@ orc_train *orc_train_new(const uint32_t *text, const uint64_t *sent_off, uint64_
       uint64_t k = st_intern(&words, p + i, j - i, &is_new);
       if (is_new) v32_push(&wfreq, 0);
       wfreq.p[k]++;
-      /* bpe.py:75: vocab.update({ch for w in new_words for ch in w}) */
-      for (uint64_t q = i; q < j; q++)
-        if (p[q] < 0x110000u && !seen[p[q]]) { seen[p[q]] = 1; t->vocab_size++; }
+      /* bpe.py:75: vocab.update({ch for w in new_words for ch in w}); the WordPiece initial symbols are counted below */
+      if (!wp)
+        for (uint64_t q = i; q < j; q++)
+          if (p[q] < 0x110000u && !seen[p[q]]) { seen[p[q]] = 1; t->vocab_size++; }
       i = j;
     }
   }
-  free(seen);
   /* bpe.py:79-81: symbols = [s for s in word] */
   uint64_t nw = st_count(&words);
   v64_push(&t->woff, 0);
   for (uint64_t k = 0; k < nw; k++) {
-    for (uint64_t q = words.off.p[k]; q < words.off.p[k + 1]; q++) v32_push(&t->syms, words.blob.p[q]);
+    for (uint64_t q = words.off.p[k]; q < words.off.p[k + 1]; q++) {
+      uint32_t c = words.blob.p[q];
+      if (wp) {
+        /* wordpiece.py:54-57: [word[0]] + ["##" + c for c in word[1:]]; :62-63 vocab |= initial symbols */
+        int is_new = 0;
+        if (q == words.off.p[k]) {
+          if (c < 0x110000u && !seen[c]) { seen[c] = 1; t->vocab_size++; }
+        } else {
+          uint32_t tmp[3] = {'#', '#', c};
+          c = sym_intern(&t->st, tmp, 3, &is_new);
+          if (is_new) t->vocab_size++;
+        }
+      }
+      v32_push(&t->syms, c);
+    }
     v64_push(&t->woff, t->syms.n);
     v32_push(&t->freq, wfreq.p[k]);
   }
+  free(seen);
   st_free(&words); free(wfreq.p);
   return t;
+}
+orc_train *orc_train_new(const uint32_t *text, const uint64_t *sent_off, uint64_t n_sent) { return train_new(text, sent_off, n_sent, 0); }
+orc_train *orc_wptrain_new(const uint32_t *text, const uint64_t *sent_off, uint64_t n_sent) { return train_new(text, sent_off, n_sent, 1); }
+
+/* Python's int / int (wordpiece.py:86): the quotient of two exact integers, correctly rounded (half to even) to a
+ * double.  Returned as the bit pattern (positive doubles order like their patterns).  d = fl * fr can exceed 2^53, where
+ * (double)cnt / (double)d would round twice; then the mantissa comes from a bitwise long division. */
+uint64_t orc_wp_score_bits(uint64_t cnt, uint64_t fl, uint64_t fr) {
+  unsigned __int128 d = (unsigned __int128)fl * fr;
+  double s;
+  if (cnt == 0 || d == 0) return 0;
+  if (d < ((unsigned __int128)1 << 53) && cnt < (1ull << 53)) {
+    s = (double)cnt / (double)(uint64_t)d; /* both exact: IEEE division rounds once */
+  } else {
+    unsigned __int128 r = cnt;
+    int e = 0;
+    while (r < d) { r <<= 1; e--; }            /* r / d in [1, 2) ... */
+    while (r >= 2 * d) { d <<= 1; e++; }       /* ... also when cnt >= 2 d (not reached by a score, kept for the test) */
+    uint64_t mant = 1; r -= d;
+    for (int i = 0; i < 52; i++) { r <<= 1; mant <<= 1; if (r >= d) { r -= d; mant |= 1; } }
+    r <<= 1;
+    int rb = r >= d; if (rb) r -= d;
+    if (rb && (r != 0 || (mant & 1))) mant++;
+    if (mant == (1ull << 53)) { mant >>= 1; e++; }
+    uint64_t bits = ((uint64_t)(e + 1023) << 52) | (mant & ((1ull << 52) - 1));
+    memcpy(&s, &bits, 8);
+  }
+  uint64_t b; memcpy(&b, &s, 8);
+  return b;
 }
 
 void orc_train_free(orc_train *t) {
   if (!t) return;
   st_free(&t->st); free(t->syms.p); free(t->woff.p); free(t->freq.p);
   free(t->ml.p); free(t->mr.p); free(t->mm.p); free(t->mc.p);
-  map_free(&t->pairs); free(t->pk.p); free(t->pc.p); free(t);
+  map_free(&t->pairs); map_free(&t->sfreq); free(t->pk.p); free(t->pc.p); free(t);
 }
 uint64_t orc_train_n_words(const orc_train *t) { return t->woff.n - 1; }
 uint64_t orc_train_n_symbols(const orc_train *t) { return t->syms.n; }
@@ -397,15 +445,48 @@ uint32_t orc_train_run(orc_train *t, uint32_t max_vocab, uint32_t max_steps) {
         else { map_put(&t->pairs, key, t->pk.n); v64_push(&t->pk, key); v64_push(&t->pc, f); }
       }
     }
-    if (t->pk.n == 0) break; /* bpe.py:98-99 */
-    /* bpe.py:102: most_common(1) -> max(): the FIRST maximum in insertion order */
-    uint64_t best = 0;
-    for (uint64_t k = 1; k < t->pk.n; k++) if (t->pc.p[k] > t->pc.p[best]) best = k;
+    if (t->pk.n == 0) break; /* bpe.py:98-99, wordpiece.py:75-76 */
+    uint64_t best = 0, best_val;
+    if (!t->wp) {
+      /* bpe.py:102: most_common(1) -> max(): the FIRST maximum in insertion order */
+      for (uint64_t k = 1; k < t->pk.n; k++) if (t->pc.p[k] > t->pc.p[best]) best = k;
+      best_val = t->pc.p[best];
+    } else {
+      /* wordpiece.py:78-92: symbol frequencies, score = freq / (f_left * f_right), max() = first maximum */
+      map_clear(&t->sfreq);
+      for (uint64_t w = 0; w < nw; w++) {
+        uint32_t f = t->freq.p[w];
+        for (uint64_t i = t->woff.p[w]; i < t->woff.p[w + 1]; i++) {
+          uint64_t *slot = map_find(&t->sfreq, t->syms.p[i]);
+          if (slot) *slot += f; else map_put(&t->sfreq, t->syms.p[i], f);
+        }
+      }
+      best_val = 0;
+      for (uint64_t k = 0; k < t->pk.n; k++) {
+        uint64_t fl = *map_find(&t->sfreq, t->pk.p[k] >> 32), fr = *map_find(&t->sfreq, (uint32_t)t->pk.p[k]);
+        uint64_t sc = orc_wp_score_bits(t->pc.p[k], fl, fr);
+        if (k == 0 || sc > best_val) { best = k; best_val = sc; }
+      }
+    }
     uint32_t l = (uint32_t)(t->pk.p[best] >> 32), r = (uint32_t)t->pk.p[best];
     int is_new;
-    uint32_t mg = sym_concat(&t->st, l, r, &is_new);
-    if (is_new) t->vocab_size++; /* bpe.py:103: set.add grows only for an unseen string */
-    v32_push(&t->ml, l); v32_push(&t->mr, r); v32_push(&t->mm, mg); v64_push(&t->mc, t->pc.p[best]); /* :104 */
+    uint32_t mg;
+    if (!t->wp) {
+      mg = sym_concat(&t->st, l, r, &is_new);
+    } else {
+      /* wordpiece.py:95: merged = left + right[2:] (the right symbol of a pair is never word-initial: it starts with ##) */
+      uint32_t lb[1], *tmp; const uint32_t *lp, *rp; uint64_t ln, rn;
+      if (l < ORC_SYM_BASE) { lb[0] = l; lp = lb; ln = 1; }
+      else { uint64_t k = l - ORC_SYM_BASE; lp = t->st.blob.p + t->st.off.p[k]; ln = t->st.off.p[k + 1] - t->st.off.p[k]; }
+      { uint64_t k = r - ORC_SYM_BASE; rp = t->st.blob.p + t->st.off.p[k] + 2; rn = t->st.off.p[k + 1] - t->st.off.p[k] - 2; }
+      tmp = (uint32_t *)malloc((ln + rn + 1) * 4);
+      memcpy(tmp, lp, ln * 4); memcpy(tmp + ln, rp, rn * 4);
+      if (ln + rn == 1) { mg = tmp[0]; is_new = 0; }  /* cannot happen: both sides hold at least one character */
+      else mg = sym_intern(&t->st, tmp, ln + rn, &is_new);
+      free(tmp);
+    }
+    if (is_new) t->vocab_size++; /* bpe.py:103 / wordpiece.py:96: set.add grows only for an unseen string */
+    v32_push(&t->ml, l); v32_push(&t->mr, r); v32_push(&t->mm, mg); v64_push(&t->mc, best_val); /* :104 */
     /* bpe.py:108-111 with _replace_pair (bpe.py:25-48): rebuild every word */
     uint64_t o = 0;
     for (uint64_t w = 0; w < nw; w++) {

@@ -2,6 +2,7 @@
 by importing the reference (tests/golden/make_golden.py).  CPU only."""
 import hashlib
 import json
+import os
 
 import numpy as np
 import pytest
@@ -140,3 +141,46 @@ def test_batch_forms_agree_with_single(oracle, golden, corpora):
             assert np.array_equal(ids[int(off[i]):int(off[i + 1])], one)
         else:
             assert off[i] == off[i + 1]
+
+
+def _wp_order_cases(golden, ref_dir):
+    import json
+    for c in golden("wp_train_order.json"):
+        if "corpus" in c:
+            corpus = c["corpus"]
+        else:
+            with open(os.path.join(os.path.dirname(ref_dir), c["corpus_ref"]["file"]), encoding="utf-8") as f:
+                corpus = json.load(f)[: c["corpus_ref"]["first"]]
+        yield c, corpus
+
+
+def test_wp_train_order_matches_reference(oracle, golden, ref_dir):
+    """NaiveWP.train (wordpiece.py:29-103): initial symbols, the merge sequence and the final vocabulary of the reference"""
+    n = 0
+    for c, corpus in _wp_order_cases(golden, ref_dir):
+        tr = oracle.OracleWPTrainer(corpus)
+        assert tr.vocab_size == len(c["initial"])
+        tr.run(c["max_vocab"])
+        got = [[l, r] for l, r in tr.merges_list]
+        assert got == c["merges"], (c.get("corpus", c.get("corpus_ref")), got[:5], c["merges"][:5])
+        vocab = set(c["initial"]) | set(tr.merged_tokens)
+        assert sorted(vocab) == c["vocab"]
+        assert tr.vocab_size == len(c["vocab"])
+        n += len(got)
+    assert n > 300
+
+
+def test_wp_score_is_pythons_int_division(oracle):
+    """wordpiece.py:86: freq / (f_l * f_r) on Python ints is the correctly rounded quotient, also past 2^53"""
+    import random
+    import struct
+    rng = random.Random(86)
+    cases = [(1, 1, 1), (1, 3, 1), (2, 3, 7), (1, 2**32 - 1, 2**32 - 1), (5, 2**31 + 11, 2**30 + 3), (2**40, 2**50 + 1, 2**13 - 1)]
+    for _ in range(4000):
+        bits = rng.choice([8, 20, 27, 31, 40, 52, 60, 63])
+        fl, fr = rng.randrange(1, 2**bits), rng.randrange(1, 2**rng.choice([8, 20, 27, 31, 40, 52, 60, 63]))
+        cnt = rng.randrange(1, min(fl, fr, 2**53) + 1)
+        cases.append((cnt, fl, fr))
+    for cnt, fl, fr in cases:
+        want = struct.unpack("<Q", struct.pack("<d", cnt / (fl * fr)))[0]
+        assert oracle.wp_score_bits(cnt, fl, fr) == want, (cnt, fl, fr)
