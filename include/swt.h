@@ -155,6 +155,16 @@ typedef struct swt_bpe_trainer swt_bpe_trainer;
  * (source/bpe.py:70-81).  n_base_symbols = number of distinct code points (the initial len(vocab)). */
 int swt_bpe_train_create_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent,
                               swt_bpe_trainer **out);
+/* NaiveWP.train's state instead (source/wordpiece.py:44-63): the same split and word dedup, symbols
+ * = the word's first code point c and SWT_WP_CONT + c ("##c") for the others, plus exact symbol frequencies.  The handle
+ * works with every swt_bpe_train_* call below; the step maximises the likelihood score freq / (f_left * f_right)
+ * (source/wordpiece.py:84-92: Python's int / int, the correctly rounded quotient; first maximum in first-occurrence
+ * order) and the `count` outputs carry that score's IEEE-754 bit pattern.  Merged symbols start at SWT_WP_MERGED_BASE;
+ * the caller names them left + right[2:] (source/wordpiece.py:95). */
+#define SWT_WP_CONT 0x110000u
+#define SWT_WP_MERGED_BASE 0x220000u
+int swt_wp_train_create_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent,
+                             swt_bpe_trainer **out);
 /* From an already deduplicated word list (symbol ids, CSR offsets, frequencies). */
 int swt_bpe_train_create_words(const uint32_t *syms, const uint64_t *word_off, const uint32_t *freq,
                                uint64_t n_words, swt_bpe_trainer **out);

@@ -11,6 +11,8 @@ import numpy as np
 from . import _build
 
 SYM_BASE = 0x110000
+WP_CONT = 0x110000  # '##c' = WP_CONT + ord(c) in a WordPiece trainer
+WP_MERGED_BASE = 0x220000
 BPE_CONT = 0x80000000
 BPE_RAW_WORDS = 1
 BPE_NO_DEDUP = 2
@@ -52,6 +54,7 @@ SIGNATURES = {
     "swt_wp_encode_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "swt_bpe_train_create_text": (C.c_int, [u8p, u64p, C.c_uint64, vpp]),
+    "swt_wp_train_create_text": (C.c_int, [u8p, u64p, C.c_uint64, vpp]),
     "swt_bpe_train_create_words": (C.c_int, [u32p, u64p, u32p, C.c_uint64, vpp]),
     "swt_bpe_train_destroy": (None, [C.c_void_p]),
     "swt_bpe_train_set_pos_base": (C.c_int, [C.c_void_p, C.c_uint64]),
@@ -289,6 +292,14 @@ class BpeTrainer:
         h = C.c_void_p()
         n_sent = int(sent_off.size - 1)
         check(lib().swt_bpe_train_create_text(ptr(text_u8, u8p), ptr(sent_off, u64p), n_sent, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_text_wordpiece(cls, text_u8, sent_off):
+        """NaiveWP.train's state (wordpiece.py:44-63): '##' symbols, likelihood score; `count` outputs = score bit patterns"""
+        h = C.c_void_p()
+        n_sent = int(sent_off.size - 1)
+        check(lib().swt_wp_train_create_text(ptr(text_u8, u8p), ptr(sent_off, u64p), n_sent, C.byref(h)))
         return cls(h)
 
     @classmethod

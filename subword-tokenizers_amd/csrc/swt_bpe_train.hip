@@ -17,6 +17,11 @@
 // Per merge: argmax over cnt[] (max via atomicMax, then tie census); only when the maximum is tied, one read-only
 // scan finds the earliest (word, position) among the tied pairs (bpe.py:102: Counter.most_common(1) returns
 // the first-inserted maximum).  One host round trip per merge: the caller owns the string set and the stop test.
+//
+// WordPiece mode (NaiveWP.train, /root/reference/source/wordpiece.py:29-103): the same stream, histogram
+// and merge-apply; symbols are the word's first character and "##c" (= 0x110000 + c) for the others; a dense
+// symbol-frequency array is kept exact beside the pair histogram, and the argmax key is the likelihood score
+// freq / (f_left * f_right) -- Python's int / int, i.e. the correctly rounded quotient -- compared as a bit pattern.
 #include <algorithm>
 #include <unordered_map>
 
@@ -44,6 +49,43 @@ struct TrainResult {
 struct StepCmd {
   uint32_t l, r, m, valid;
 };
+
+// ---- WordPiece score (wordpiece.py:84-87) --------------------------------------------------------------------------
+constexpr uint32_t kWpCont = 0x110000u;         // "##c" = kWpCont + c
+constexpr uint32_t kWpMergedBase = 0x220000u;   // merged symbols of a WordPiece trainer start here
+constexpr uint64_t kWpSymCap = (uint64_t)kWpMergedBase + (1u << 21);
+
+// RN(cnt / (fl * fr)) as the double's bit pattern.  Below 2^53 both operands are exact doubles and the IEEE division rounds
+// once; above, the mantissa comes from a bitwise long division of the exact integers.
+__device__ __forceinline__ unsigned long long wp_score_bits(unsigned long long cnt, unsigned long long fl, unsigned long long fr) {
+  if (cnt == 0 || fl == 0 || fr == 0) return 0ull;
+  const unsigned __int128 d0 = (unsigned __int128)fl * fr;
+  if (d0 < ((unsigned __int128)1 << 53) && cnt < (1ull << 53))
+    return (unsigned long long)__double_as_longlong((double)cnt / (double)(unsigned long long)d0);
+  unsigned __int128 d = d0, r = cnt;
+  int e = 0;
+  while (r < d) { r <<= 1; e--; }
+  while (r >= 2 * d) { d <<= 1; e++; }
+  unsigned long long mant = 1;
+  r -= d;
+  for (int i = 0; i < 52; i++) {
+    r <<= 1;
+    mant <<= 1;
+    if (r >= d) { r -= d; mant |= 1; }
+  }
+  r <<= 1;
+  const bool rb = r >= d;
+  if (rb) r -= d;
+  if (rb && (r != 0 || (mant & 1))) mant++;
+  if (mant == (1ull << 53)) { mant >>= 1; e++; }
+  return ((unsigned long long)(e + 1023) << 52) | (mant & ((1ull << 52) - 1ull));
+}
+
+// the value the argmax maximises for a live pair: its count (BPE) or its score (WordPiece)
+__device__ __forceinline__ unsigned long long pair_value(unsigned long long key, long long cnt, const long long *__restrict__ sfreq) {
+  if (!sfreq) return (unsigned long long)cnt;
+  return wp_score_bits((unsigned long long)cnt, (unsigned long long)sfreq[key >> 32], (unsigned long long)sfreq[(uint32_t)key]);
+}
 struct StepLog {
   uint32_t l, r;
   unsigned long long count;
@@ -127,15 +169,18 @@ __device__ __forceinline__ void arg_combine(unsigned long long &m, unsigned long
 // and resets the tie-break fields of the result.
 __global__ __launch_bounds__(256) void argmax_kernel(const unsigned long long *__restrict__ keys, const long long *__restrict__ cnt,
                                                      uint64_t cap, ArgPart *__restrict__ parts, unsigned int *__restrict__ ticket,
-                                                     TrainResult *res) {
+                                                     TrainResult *res, const long long *__restrict__ sfreq) {
   __shared__ unsigned long long sm[4], sc[4], sk[4];
   __shared__ bool is_last;
   unsigned long long m = 0, c = 0, k = kEmptyKey;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
     const long long v = cnt[i];
-    if (v > 0 && (unsigned long long)v >= m) {
+    if (v > 0 && (sfreq || (unsigned long long)v >= m)) {
       const unsigned long long key = keys[i];
-      if (key != kEmptyKey) arg_combine(m, c, k, (unsigned long long)v, 1ull, key);
+      if (key != kEmptyKey) {
+        const unsigned long long val = pair_value(key, v, sfreq);
+        if (val >= m) arg_combine(m, c, k, val, 1ull, key);
+      }
     }
   }
   for (int d = 32; d >= 1; d >>= 1) {
@@ -185,13 +230,24 @@ __global__ __launch_bounds__(256) void argmax_kernel(const unsigned long long *_
 // words, so an untied step costs a handful of workgroups that return at once.
 // Device-driven mode (cmd != null, swt_bpe_train_run): this kernel also turns the result into the step's merge command
 // for apply_kernel and logs it -- workgroup 0 when the maximum is unique, the last workgroup of the scan when tied.
+// WordPiece: the symbol frequencies follow the merge.  A pair of two different symbols cannot overlap itself, so the merge
+// happens exactly count(l, r) times (weighted); a twin pair (a, a) is counted by apply_kernel, occurrence by occurrence.
+__device__ __forceinline__ void wp_move_freq(const PairTable &T, uint32_t l, uint32_t r, uint32_t m, long long *sfreq) {
+  if (l == r) return;
+  const long long c = table_get(T, pair_key(l, r));
+  sfreq[l] -= c;
+  sfreq[r] -= c;
+  sfreq[m] += c;
+}
+
 __device__ __forceinline__ void write_cmd(unsigned long long key, unsigned long long mx, StepCmd *cmd, StepLog *log, uint32_t step,
-                                          uint32_t merged) {
+                                          uint32_t merged, const PairTable &T, long long *sfreq) {
   const bool ok = mx > 0 && key != kEmptyKey;
   cmd->l = (uint32_t)(key >> 32);
   cmd->r = (uint32_t)key;
   cmd->m = merged;
   cmd->valid = ok ? 1u : 0u;
+  if (ok && sfreq) wp_move_freq(T, cmd->l, cmd->r, merged, sfreq);
   log[step].l = cmd->l;
   log[step].r = cmd->r;
   log[step].count = mx;
@@ -201,13 +257,13 @@ __device__ __forceinline__ void write_cmd(unsigned long long key, unsigned long 
 __global__ __launch_bounds__(kTrainThreads) void first_pos_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
                                                                   const uint32_t *__restrict__ wlen, uint64_t n_words, PairTable T,
                                                                   TrainResult *res, StepCmd *cmd, StepLog *log, uint32_t step,
-                                                                  uint32_t merged, unsigned int *ticket) {
+                                                                  uint32_t merged, unsigned int *ticket, long long *sfreq) {
   __shared__ bool is_last;
   if (res->n_tied < 2) {
-    if (cmd && blockIdx.x == 0 && threadIdx.x == 0) write_cmd(res->best_key, res->max_count, cmd, log, step, merged);
+    if (cmd && blockIdx.x == 0 && threadIdx.x == 0) write_cmd(res->best_key, res->max_count, cmd, log, step, merged, T, sfreq);
     return;
   }
-  const long long mx = (long long)res->max_count;
+  const unsigned long long mx = res->max_count;
   for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t n = wlen[w];
     if (n < 2) continue;
@@ -217,7 +273,8 @@ __global__ __launch_bounds__(kTrainThreads) void first_pos_kernel(const uint32_t
     uint32_t a = s[0];
     for (uint32_t i = 1; i < n; i++) {
       const uint32_t b = s[i];
-      if (table_get(T, pair_key(a, b)) == mx) {
+      const unsigned long long key = pair_key(a, b);
+      if (pair_value(key, table_get(T, key), sfreq) == mx) {
         atomicMin(&res->best_pos, (unsigned long long)(base + i - 1));
         break;
       }
@@ -236,8 +293,44 @@ __global__ __launch_bounds__(kTrainThreads) void first_pos_kernel(const uint32_t
   const unsigned long long pos = __hip_atomic_load(&res->best_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned long long key = pos != kEmptyKey ? pair_key(sym[pos], sym[pos + 1]) : kEmptyKey;
   res->win_key = key;
-  write_cmd(key, res->max_count, cmd, log, step, merged);
+  write_cmd(key, res->max_count, cmd, log, step, merged, T, sfreq);
   *ticket = 0;
+}
+
+// host-driven WordPiece step (swt_bpe_train_apply): the frequency move of write_cmd as a launch of its own, BEFORE apply_kernel
+__global__ void wp_move_freq_kernel(PairTable T, uint32_t l, uint32_t r, uint32_t m, long long *sfreq) { wp_move_freq(T, l, r, m, sfreq); }
+
+// wordpiece.py:78-81 once: symbol frequencies, weighted by the word's frequency
+__global__ __launch_bounds__(kTrainThreads) void sym_hist_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
+                                                                 const uint32_t *__restrict__ wlen, const uint32_t *__restrict__ freq,
+                                                                 uint64_t n_words, long long *__restrict__ sfreq, uint64_t sym_cap,
+                                                                 unsigned int *__restrict__ bad) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  const uint32_t n = wlen[w];
+  const uint32_t *s = sym + woff[w];
+  const unsigned long long f = freq[w];
+  for (uint32_t i = 0; i < n; i++) {
+    if (s[i] < sym_cap) atomicAdd(reinterpret_cast<unsigned long long *>(&sfreq[s[i]]), f);
+    else *bad = 1u;
+  }
+}
+
+// wordpiece.py:54-57: [word[0]] + ["##" + c for c in word[1:]]
+__global__ __launch_bounds__(kTrainThreads) void wp_symbolise_kernel(uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
+                                                                     uint64_t n_words) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  for (uint64_t i = woff[w] + 1; i < woff[w + 1]; i++) sym[i] += kWpCont;
+}
+
+__global__ void wp_live_symbols_kernel(const long long *__restrict__ sfreq, uint64_t cap, uint32_t *__restrict__ out, uint32_t out_cap,
+                                       unsigned int *__restrict__ n_out) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x)
+    if (sfreq[i] != 0) {
+      const unsigned int k = atomicAdd(n_out, 1u);
+      if (k < out_cap) out[k] = (uint32_t)i;
+    }
 }
 
 __global__ void winner_kernel(const uint32_t *__restrict__ sym, TrainResult *res) {
@@ -253,7 +346,7 @@ __global__ __launch_bounds__(kTrainThreads) void apply_kernel(uint32_t *__restri
                                                               uint64_t n_words, uint32_t l, uint32_t r, uint32_t m, PairTable T,
                                                               TrainResult *res, unsigned long long *__restrict__ log_keys,
                                                               long long *__restrict__ log_vals, uint64_t log_cap,
-                                                              const StepCmd *__restrict__ cmd) {
+                                                              const StepCmd *__restrict__ cmd, long long *__restrict__ sfreq) {
   const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n_words) return;
   if (cmd) {  // device-driven step: the pair comes from decide_kernel
@@ -307,6 +400,11 @@ __global__ __launch_bounds__(kTrainThreads) void apply_kernel(uint32_t *__restri
     }
   }
 #undef EMIT
+  if (sfreq && l == r) {  // twin pair: (n - j) merges happened in this word (see wp_move_freq)
+    const unsigned long long d = (unsigned long long)(n - j) * (unsigned long long)f;
+    atomicAdd(reinterpret_cast<unsigned long long *>(&sfreq[l]), (unsigned long long)0 - 2 * d);
+    atomicAdd(reinterpret_cast<unsigned long long *>(&sfreq[m]), d);
+  }
   wlen[w] = j;
   atomicAdd(&res->n_syms, (unsigned long long)0 - (unsigned long long)(n - j));
 }
@@ -357,6 +455,7 @@ struct swt_bpe_trainer {
   TrainResult h_res{};
   uint64_t pos_base = 0;
   bool hist_ready = false;
+  long long *d_sfreq = nullptr;  // WordPiece mode: symbol frequencies, dense by symbol id (kWpSymCap entries)
   // delta log (sharded training)
   bool logging = false;
   unsigned long long *d_log_keys = nullptr;
@@ -545,10 +644,49 @@ int swt_bpe_train_create_text(const uint8_t *text, const uint64_t *sent_off, uin
   return SWT_OK;
 }
 
+// wordpiece.py:44-63 on the device: the same split and Counter, then [word[0]] + ["##" + c ...] and the symbol frequencies.
+// The handle is used with the swt_bpe_train_* calls; `count` outputs carry the winning score's bit pattern.
+int swt_wp_train_create_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, swt_bpe_trainer **out) {
+  swt_bpe_trainer *t = nullptr;
+  int rc = swt_bpe_train_create_text(text, sent_off, n_sent, &t);
+  if (rc) return rc;
+  // the pair histogram was built on plain code points: rebuild it on the WordPiece symbols
+  table_free(t->T);
+  if (t->n_words)
+    hipLaunchKernelGGL(wp_symbolise_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff,
+                       t->n_words);
+  SWT_HIP(hipMemset(&t->d_res->n_used, 0, 8));
+  if ((rc = build_histogram(t))) { swt_bpe_train_destroy(t); return rc; }
+  SWT_HIP(hipMalloc((void **)&t->d_sfreq, kWpSymCap * 8));
+  SWT_HIP(hipMemset(t->d_sfreq, 0, kWpSymCap * 8));
+  unsigned int *d_flag = reinterpret_cast<unsigned int *>(t->d_halt);
+  SWT_HIP(hipMemset(d_flag, 0, 8));
+  if (t->n_words)
+    hipLaunchKernelGGL(sym_hist_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff, t->d_wlen,
+                       t->d_freq, t->n_words, t->d_sfreq, kWpSymCap, d_flag);
+  // the initial vocabulary (wordpiece.py:62-63) = the symbols that occur
+  DevBuf live;
+  const uint32_t live_cap = 2 * kWpCont;
+  if ((rc = live.reserve((size_t)live_cap * 4))) { swt_bpe_train_destroy(t); return rc; }
+  hipLaunchKernelGGL(wp_live_symbols_kernel, dim3(1024), dim3(256), 0, 0, (const long long *)t->d_sfreq, (uint64_t)kWpMergedBase,
+                     live.as<uint32_t>(), live_cap, d_flag + 1);
+  unsigned int h[2] = {0, 0};
+  SWT_HIP(hipMemcpy(h, d_flag, 8, hipMemcpyDeviceToHost));
+  if (h[0]) { swt_bpe_train_destroy(t); return fail(SWT_ERR_UNSUPPORTED, "symbol id out of range for a WordPiece trainer"); }
+  t->base_syms.resize(h[1]);
+  if (h[1]) SWT_HIP(hipMemcpy(t->base_syms.data(), live.p, (size_t)h[1] * 4, hipMemcpyDeviceToHost));
+  std::sort(t->base_syms.begin(), t->base_syms.end());
+  t->n_base = h[1];
+  SWT_HIP(hipMemset(d_flag, 0, 8));
+  live.release();
+  *out = t;
+  return SWT_OK;
+}
+
 void swt_bpe_train_destroy(swt_bpe_trainer *t) {
   if (!t) return;
   for (void *p : {(void *)t->d_sym, (void *)t->d_woff, (void *)t->d_wlen, (void *)t->d_freq, (void *)t->d_res, (void *)t->d_parts, (void *)t->d_cmd, (void *)t->d_steplog, (void *)t->d_halt,
-                  (void *)t->d_log_keys, (void *)t->d_log_vals})
+                  (void *)t->d_log_keys, (void *)t->d_log_vals, (void *)t->d_sfreq})
     if (p) (void)hipFree(p);
   table_free(t->T);
   t->tmp.release();
@@ -587,13 +725,14 @@ int swt_bpe_train_best(swt_bpe_trainer *t, uint32_t *left, uint32_t *right, uint
   const uint64_t cap = 1ull << t->T.bits;
   const unsigned g = grid_for(cap, 256 * 8, kArgBlocks);
   unsigned int *ticket = reinterpret_cast<unsigned int *>(t->d_parts + kArgBlocks);
-  hipLaunchKernelGGL(argmax_kernel, dim3(g), dim3(256), 0, 0, t->T.keys, t->T.cnt, cap, t->d_parts, ticket, t->d_res);
+  hipLaunchKernelGGL(argmax_kernel, dim3(g), dim3(256), 0, 0, t->T.keys, t->T.cnt, cap, t->d_parts, ticket, t->d_res,
+                     (const long long *)t->d_sfreq);
   if ((rc = sync_result(t))) return rc;
   if (t->h_res.n_tied >= 2 && t->n_words) {
     // bpe.py:102: only a tied maximum needs the scan for the earliest (word, position)
     hipLaunchKernelGGL(first_pos_kernel, dim3(grid_for(t->n_words, kTrainThreads, 1024)), dim3(kTrainThreads), 0, 0, t->d_sym,
                        t->d_woff, t->d_wlen, t->n_words, t->T, t->d_res, (StepCmd *)nullptr, (StepLog *)nullptr, 0u, 0u,
-                       (unsigned int *)nullptr);
+                       (unsigned int *)nullptr, t->d_sfreq);
     hipLaunchKernelGGL(winner_kernel, dim3(1), dim3(1), 0, 0, t->d_sym, t->d_res);
     if ((rc = sync_result(t))) return rc;
   }
@@ -616,6 +755,7 @@ int swt_bpe_train_best(swt_bpe_trainer *t, uint32_t *left, uint32_t *right, uint
 // New pairs one merge can create: two per occurrence (occurrences <= the pair's count, counts never grow), and never
 // more than (x, m) / (m, y) over the distinct symbols x, y plus (m, m).
 static uint64_t new_pairs_bound(const swt_bpe_trainer *t, uint64_t count_bound) {
+  if (t->d_sfreq) count_bound = 0;  // WordPiece: max_count holds a score, not a count
   const uint64_t by_symbols = 2 * (t->n_base + t->n_applied + 1) + 1;
   uint64_t by_count = count_bound ? 2 * count_bound : by_symbols;
   if (t->h_res.n_syms && 2 * t->h_res.n_syms < by_count) by_count = 2 * t->h_res.n_syms;
@@ -641,12 +781,17 @@ int swt_bpe_train_apply(swt_bpe_trainer *t, uint32_t left, uint32_t right, uint3
   const uint64_t occ = new_pairs_bound(t, t->h_res.max_count);
   if ((rc = ensure_room(t, occ))) return rc;
   if (t->logging) SWT_HIP(hipMemsetAsync(&t->d_res->n_log, 0, 8, 0));
+  if (t->d_sfreq) {
+    if (left >= kWpSymCap || right >= kWpSymCap || merged >= kWpSymCap)
+      return fail(SWT_ERR_UNSUPPORTED, "WordPiece symbol id beyond %llu", (unsigned long long)kWpSymCap);
+    hipLaunchKernelGGL(wp_move_freq_kernel, dim3(1), dim3(1), 0, 0, t->T, left, right, merged, t->d_sfreq);
+  }
   prof_begin(0);
   if (t->n_words)
     hipLaunchKernelGGL(apply_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff,
                        t->d_wlen, t->d_freq, t->n_words, left, right, merged, t->T, t->d_res,
                        t->logging ? t->d_log_keys : nullptr, t->logging ? t->d_log_vals : nullptr, t->log_cap,
-                       (const StepCmd *)nullptr);
+                       (const StepCmd *)nullptr, t->d_sfreq);
   prof_end(0);
   SWT_HIP(hipGetLastError());
   // n_used may have grown; the next best() refreshes h_res.  Be conservative until then.
@@ -661,6 +806,8 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
                       uint64_t *count, uint32_t *n_done) {
   if (!t || !left || !right || !count || !n_done) return fail(SWT_ERR_INVALID, "null argument");
   if (t->logging) return fail(SWT_ERR_STATE, "swt_bpe_train_run is for unsharded training (deltas are exchanged per step)");
+  if (t->d_sfreq && (uint64_t)first_merged + max_steps > kWpSymCap)
+    return fail(SWT_ERR_UNSUPPORTED, "WordPiece symbol id beyond %llu", (unsigned long long)kWpSymCap);
   int rc = ensure_device();
   if (rc) return rc;
   *n_done = 0;
@@ -682,14 +829,15 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
     const unsigned gw = grid_for(t->n_words ? t->n_words : 1, kTrainThreads * 8, 256);
     SWT_HIP(hipMemsetAsync(t->d_halt, 0, 8, 0));
     for (uint32_t i = 0; i < k; i++) {
-      hipLaunchKernelGGL(argmax_kernel, dim3(g), dim3(256), 0, 0, t->T.keys, t->T.cnt, cap, t->d_parts, ticket, t->d_res);
+      hipLaunchKernelGGL(argmax_kernel, dim3(g), dim3(256), 0, 0, t->T.keys, t->T.cnt, cap, t->d_parts, ticket, t->d_res,
+                         (const long long *)t->d_sfreq);
       hipLaunchKernelGGL(first_pos_kernel, dim3(gw), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff, t->d_wlen, t->n_words, t->T,
-                         t->d_res, t->d_cmd, t->d_steplog, i, first_merged + done + i, ticket2);
+                         t->d_res, t->d_cmd, t->d_steplog, i, first_merged + done + i, ticket2, t->d_sfreq);
       prof_begin(0);
       if (t->n_words)
         hipLaunchKernelGGL(apply_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff,
                            t->d_wlen, t->d_freq, t->n_words, 0u, 0u, 0u, t->T, t->d_res, (unsigned long long *)nullptr,
-                           (long long *)nullptr, (uint64_t)0, (const StepCmd *)t->d_cmd);
+                           (long long *)nullptr, (uint64_t)0, (const StepCmd *)t->d_cmd, t->d_sfreq);
       prof_end(0);
     }
     SWT_HIP(hipGetLastError());
@@ -704,7 +852,7 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
       good++;
     }
     t->n_applied += good;
-    if (good) t->h_res.max_count = hlog[good - 1].count;  // counts never grow: bound for the next batch
+    if (good && !t->d_sfreq) t->h_res.max_count = hlog[good - 1].count;  // counts never grow: bound for the next batch
     if (good < k) exhausted = true;  // bpe.py:98-99: no pair left (later steps of the batch were no-ops)
   }
   *n_done = done;

@@ -313,41 +313,95 @@ class FastBPE(NaiveBPE):
 # ------------------------------------------------------------------------------------------------------
 # WordPiece
 
+class _WpSymbols:
+    """WordPiece trainer symbol id <-> string: c -> ord(c); '##c' -> WP_CONT + ord(c); a merged string -> WP_MERGED_BASE + k
+    in order of first appearance (symbols are identified by their STRING, wordpiece.py:95-96,121)."""
+
+    def __init__(self):
+        self.strings: List[str] = []
+        self.index: Dict[str, int] = {}
+
+    def intern_merged(self, s: str) -> int:
+        k = self.index.get(s)
+        if k is None:
+            k = self.index[s] = len(self.strings)
+            self.strings.append(s)
+        return N.WP_MERGED_BASE + k
+
+    def string(self, sid: int) -> str:
+        if sid < N.WP_CONT:
+            return chr(sid)
+        if sid < N.WP_MERGED_BASE:
+            return "##" + chr(sid - N.WP_CONT)
+        return self.strings[sid - N.WP_MERGED_BASE]
+
+
 class NaiveWP(SubwordTokenizer):
-    """WordPiece by the likelihood score (wordpiece.py:8-208).  CPU Python, as in the reference: the north
-    star puts only FastWP's trie-match encode on the GPU."""
+    """WordPiece by the likelihood score (wordpiece.py:8-208).  `train` runs on the device: the
+    BPE trainer's stream, histogram and merge-apply with exact symbol frequencies and the score as the argmax key;
+    `encode_word`/`tokenize` keep the reference's longest-prefix loop in Python (FastWP is the device encoder)."""
 
     def __init__(self, tokenizer=None):
         super().__init__(tokenizer)
         self.vocab: set = set()
-        self.corpus_as_symbols: List[Tuple[List[str], int]] = []
+        self._trainer: Optional[N.BpeTrainer] = None
+        self._train_syms: Optional[_WpSymbols] = None
+        self._corpus_cache = None
 
-    # -- wordpiece.py:29-103
+    # -- wordpiece.py:29-103: the merge loop, on the device
     def train(self, corpus, max_vocab: int = 30_000):
         if not isinstance(corpus, list) or not all(isinstance(example, str) for example in corpus):
             raise TypeError("corpus must be a list of strings.")
         if not isinstance(max_vocab, int):
             raise TypeError("max_vocab must be an int.")
         self.reset()
-        words = Counter(w for sent in self.preprocessing(corpus) for w, _ in sent)
-        fresh = [([w[0]] + ["##" + ch for ch in w[1:]], f) for w, f in words.items()]
-        self.corpus_as_symbols.extend(fresh)
-        self.vocab |= {piece for pieces, _ in fresh for piece in pieces}
-        while len(self.vocab) < max_vocab:
-            pair_freq: Counter = Counter()
-            piece_freq: Counter = Counter()
-            for pieces, f in self.corpus_as_symbols:
-                for a, b in zip(pieces, pieces[1:]):
-                    pair_freq[(a, b)] += f
-            if not pair_freq:
-                break
-            for pieces, f in self.corpus_as_symbols:
-                for piece in pieces:
-                    piece_freq[piece] += f
-            score = {p: c / (piece_freq[p[0]] * piece_freq[p[1]]) for p, c in pair_freq.items()}
-            best = max(score, key=score.get)  # first maximum in insertion order (wordpiece.py:92)
-            self.vocab.add(best[0] + best[1][2:])
-            self.corpus_as_symbols = [(self._replace_pair(best, pieces), f) for pieces, f in self.corpus_as_symbols]
+        text, off = N.pack_utf8([example.lower() for example in corpus])
+        trainer = N.BpeTrainer.from_text_wordpiece(text, off)  # wordpiece.py:44-58 (split, Counter, '##' symbols)
+        syms = _WpSymbols()
+        self.vocab |= {syms.string(int(c)) for c in trainer.base_symbols()}  # wordpiece.py:62-63
+        applied: List[Tuple[int, int, int]] = []
+        done = set()
+        exhausted = False
+        while len(self.vocab) < max_vocab and not exhausted:  # wordpiece.py:69
+            # `want` iterations of wordpiece.py:70-102 back to back on the device; step i merges into WP_MERGED_BASE +
+            # (strings so far) + i, which is right as long as every merged string is new (wordpiece.py:96)
+            want = max_vocab - len(self.vocab)
+            first = N.WP_MERGED_BASE + len(syms.strings)
+            lefts, rights, _scores = trainer.run(want, first)
+            if len(lefts) < want:
+                exhausted = True  # wordpiece.py:75-76: no pair left
+            for i in range(len(lefts)):
+                left, right = int(lefts[i]), int(rights[i])
+                if (left, right) in done:
+                    raise RuntimeError("pair histogram inconsistent: %r selected twice" % ((left, right),))
+                done.add((left, right))
+                token = syms.string(left) + syms.string(right)[2:]  # wordpiece.py:95
+                merged = syms.intern_merged(token)
+                self.vocab.add(token)  # wordpiece.py:96
+                applied.append((left, right, merged))
+                if merged != first + i:
+                    # two different merges spelled the same string: the device went on with a fresh id; rebuild the state
+                    # with the shared one and carry on from here
+                    trainer.close()
+                    trainer = N.BpeTrainer.from_text_wordpiece(text, off)
+                    for l_, r_, m_ in applied:
+                        trainer.apply(l_, r_, m_)
+                    exhausted = False
+                    break
+        self._trainer, self._train_syms, self._corpus_cache = trainer, syms, None
+        self._merge_order = [(syms.string(l), syms.string(r)) for l, r, _ in applied]
+
+    @property
+    def corpus_as_symbols(self) -> List[Tuple[List[str], int]]:
+        """wordpiece.py:27,99-102: the unique words as symbol lists with their frequency (read back on demand)."""
+        if self._trainer is None:
+            return []
+        if self._corpus_cache is None:
+            ids, woff, freq = self._trainer.export()
+            st = self._train_syms
+            self._corpus_cache = ([st.string(int(x)) for x in ids], woff, freq)
+        strs, woff, freq = self._corpus_cache
+        return [(strs[int(woff[w]):int(woff[w + 1])], int(freq[w])) for w in range(len(woff) - 1)]
 
     # -- wordpiece.py:105-130
     def _replace_pair(self, pair, word):
@@ -391,7 +445,9 @@ class NaiveWP(SubwordTokenizer):
     # -- wordpiece.py:183-208
     def reset(self) -> None:
         self.vocab.clear()
-        self.corpus_as_symbols.clear()
+        if self._trainer is not None:
+            self._trainer.close()
+        self._trainer, self._train_syms, self._corpus_cache = None, None, None
 
     def save_resources(self, path: str) -> None:
         os.makedirs(path, exist_ok=True)

