@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the MI355X subword-tokenizer hot path, one JSON line on stdout.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bpe_encode|wp_encode|bpe_train]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bpe_encode|wp_encode|bpe_train|wp_train]
 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
 (one process per GPU; RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the environment).  Encode shards the corpus
@@ -333,23 +333,87 @@ def bench_bpe_train(args, torch, dist, rank, world, local):
     }
 
 
+def bench_wp_train(args, torch, dist, rank, world, local):
+    """NaiveWP.train (wordpiece.py:29-103) on S85k, `--max-vocab` default = initial symbols + 2000"""
+    from subword_tokenizers_amd import _native as N
+    from subword_tokenizers_amd import synth, tokenizers
+
+    if world != 1:
+        raise SystemExit("wp_train: single GPU only (the sharded exchange exists for BPE training)")
+    N.init(local)
+    sents = synth.s85k()
+    probe = tokenizers.NaiveWP()
+    probe.train(sents, 0)
+    base = len(probe.vocab)
+    probe.reset()
+    max_vocab = args.max_vocab or base + 2000
+    times = []
+    order = []
+    for it in range(args.warmup + args.steps):
+        if it == args.warmup:
+            N.profile_enable(True)
+            N.profile_read()
+        barrier_sync(torch, dist)
+        t0 = time.perf_counter()
+        tok = tokenizers.NaiveWP()
+        tok.train(sents, max_vocab)
+        order = list(tok._merge_order)
+        info = tok._trainer.info()
+        tok.reset()
+        barrier_sync(torch, dist)
+        if it >= args.warmup:
+            times.append(time.perf_counter() - t0)
+    kernel_ms, launches = N.profile_read()
+    N.profile_enable(False)
+    from oracle import oracle as O
+
+    sample = 60
+    tr = O.OracleWPTrainer(sents)
+    n0, w0 = tr.n_symbols, tr.n_words
+    t1 = time.perf_counter()
+    tr.run(max_vocab, sample)
+    cpu_s = time.perf_counter() - t1
+    if [tuple(m) for m in tr.merges_list] != [tuple(m) for m in order[:sample]]:
+        raise SystemExit("PARITY FAILURE: device merges differ from the oracle on the first %d merges" % sample)
+    algo = 16.0 * n0 + 8.0 * w0  # the reference's formulation: pair pass + symbol pass + rewrite read/write, per merge
+    per_launch_s = kernel_ms / 1e3 / max(launches, 1)
+    achieved = algo / per_launch_s / 1e9 if per_launch_s else 0.0
+    elapsed = sum(times)
+    return {
+        "metric": "WordPiece train seconds per 1k merges", "value": round(elapsed / len(times) / max(len(order), 1) * 1000, 4),
+        "unit": "s/1k-merges", "higher_is_better": False, "ms_per_step": round(elapsed / len(times) * 1e3, 3), "dtype": "u32+f64 score",
+        "config": {"workload": "NaiveWP.train on S85k to max_vocab=%d: %d initial symbols, %d merges, %d unique words, %d symbols"
+                               % (max_vocab, base, len(order), w0, n0), "parallelism": "single GPU"},
+        "scaling": "strong",
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "apply_kernel",
+                     "kernel_us": round(per_launch_s * 1e6, 2), "algorithmic_bytes_per_launch": int(algo),
+                     "launches_timed": int(launches),
+                     "note": "algorithmic bytes are those of the reference's full-rescan formulation at N_0"},
+        "cpu_baseline": {"value": round(cpu_s / sample * 1000, 3), "unit": "s/1k-merges", "cores": 1, "kind": "port",
+                         "sample": "first %d merges of the same run through oracle/swt_oracle.c (orc_wptrain_new + orc_train_run)" % sample},
+        "final_symbols": info["n_symbols"],
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="bpe_encode", choices=["bpe_encode", "wp_encode", "bpe_train"])
+    ap.add_argument("--workload", default="bpe_encode", choices=["bpe_encode", "wp_encode", "bpe_train", "wp_train"])
     ap.add_argument("--sentences", type=int, default=None, help="wp_encode: sentences per GPU (default 1,000,000)")
     ap.add_argument("--max-vocab", type=int, default=None, help="bpe_train: target vocabulary (default 8000)")
     args = ap.parse_args()
-    defaults = {"bpe_encode": (200, 20), "wp_encode": (20, 3), "bpe_train": (2, 1)}[args.workload]
+    defaults = {"bpe_encode": (200, 20), "wp_encode": (20, 3), "bpe_train": (2, 1), "wp_train": (2, 1)}[args.workload]
     if args.steps is None:
         args.steps = defaults[0]
     if args.warmup is None:
         args.warmup = defaults[1]
 
     torch, dist, rank, world, local = dist_setup(args.gpus)
-    fn = {"bpe_encode": bench_bpe_encode, "wp_encode": bench_wp_encode, "bpe_train": bench_bpe_train}[args.workload]
+    fn = {"bpe_encode": bench_bpe_encode, "wp_encode": bench_wp_encode, "bpe_train": bench_bpe_train,
+          "wp_train": bench_wp_train}[args.workload]
     res = fn(args, torch, dist, rank, world, local)
     line = {"metric": res.pop("metric"), "value": res.pop("value"), "unit": res.pop("unit"), "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"),
