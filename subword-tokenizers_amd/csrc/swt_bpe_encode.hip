@@ -20,6 +20,7 @@
 //          and only symbols next to a merge probe the table again -- one L2 round trip per round for the wave
 //     E/F  order-preserving ballot compaction to the tile's output run, per-sentence offsets
 // A word longer than a chunk falls to a one-lane global-memory path (correct, slow, pathological inputs only).
+#include "swt_dedup.h"
 #include "swt_tile.h"
 
 namespace swt {
@@ -505,504 +506,6 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
 }
 
 
-// ================================================================================================
-// Word-level dedup inside one call.  Natural text repeats its words (S85k: 1.5 M words, 83 k distinct), and
-// FastBPE.encode_word is a pure function of the word, so each distinct word is encoded once:
-//   wordref   one wave per tile: the word split of phase B/C, then one lane per word -- a single-symbol word is its own
-//             token; any other word is found or inserted in a global table (hash, then EXACT byte compare with the
-//             slot's representative occurrence; the inserter appends the word to a "unique words" text).  Every word
-//             start gets a 32-bit record (token, or table slot).
-//   encode    bpe_encode_kernel in raw-word mode over the unique words (each one is a "sentence")
-//   count / write   per tile: records -> token counts -> scan -> tokens copied from the unique words' results
-// Slots carry an 8-bit epoch, so the table is never cleared between calls.
-constexpr int kDTile = 1024;
-constexpr int kUTile = 128;     // smallest tile of the unique-word pass (chunk = 2 such tiles); measured: 64 -> 84 us, 128 -> 72 us, 256 -> 88 us
-constexpr uint64_t kUMaxTiles = 8192;  // its launch size: 256 CUs x 32 single-wave workgroups
-constexpr int kDCap = 2048;
-constexpr int kDBlocks = kDCap / 64;
-constexpr uint64_t kDedupMinBytes = 1u << 18;
-constexpr unsigned long long kDOffMask = (1ull << 40) - 1ull;
-constexpr uint32_t kRefSlot = 0x80000000u;
-
-typedef uint64_t u64u __attribute__((aligned(1)));  // unaligned 8-byte access (one global_load / ds_read on gfx950)
-
-struct DedupTab {
-  unsigned long long *slot;      // epoch:8 | tag:8 | byte length:8 | representative offset:40
-  unsigned long long *rec;       // per slot: the inserter leaves the byte length; the unique-word encode replaces it by
-                                 // token count:32 | place of the tokens in its scratch:32
-  uint64_t n_bytes;              // size of the text (wide compares stay inside it)
-  uint32_t diag;                 // diagnostics: bit 0 tallies CAS successes / failures behind `overflow`
-  uint32_t bits;
-  uint32_t epoch;
-  // New words are NOT numbered with a global counter (one hot address serialises every returning atomic of the chip:
-  // that alone cost 170 us of a 230 us kernel).  The tile that inserted a word lists it; a scan over the tiles'
-  // (count, bytes) numbers the words afterwards (bpe_ureg_kernel).
-  unsigned long long *newlist;   // slot:32 | position:32 (the inserter leaves the byte length in rec[slot]); a tile's entries start at [span_base >> 1]
-  unsigned long long *tile_new;  // per tile: new words:32 | their bytes:32 (a dedup call holds at most 2^30 bytes)
-  unsigned int *overflow;
-};
-
-// the same function as the wide form in dd_find_or_insert_lds, byte by byte (words in global memory)
-__device__ __forceinline__ unsigned long long dd_pack8(const uint8_t *p, uint32_t n) {
-  unsigned long long w = 0;
-  for (uint32_t i = 0; i < n && i < 8; i++) w |= (unsigned long long)p[i] << (8 * i);
-  return w;
-}
-__device__ __forceinline__ unsigned long long dd_hash(const uint8_t *p, uint32_t n) {
-  const unsigned long long w0 = dd_pack8(p, n), w1 = n > 8 ? dd_pack8(p + 8, n - 8) : 0ull;
-  unsigned long long h = (w0 ^ 0x9E3779B97F4A7C15ull) * 0xff51afd7ed558ccdull;
-  h ^= h >> 32;
-  h = (h ^ w1 ^ ((unsigned long long)n << 56)) * 0xc4ceb9fe1a85ec53ull;
-  for (uint32_t i = 16; i < n; i += 8) {
-    h ^= h >> 29;
-    h = (h ^ dd_pack8(p + i, n - i)) * 0x9E3779B97F4A7C15ull;
-  }
-  h ^= h >> 29; h *= 0x94d049bb133111ebull; h ^= h >> 32;
-  return h;
-}
-
-__device__ uint32_t dd_find_or_insert(const DedupTab &D, const uint8_t *__restrict__ text, const uint8_t *mine, uint32_t len,
-                                      uint64_t gpos, bool &is_new) {
-  is_new = false;
-  const unsigned long long h = dd_hash(mine, len);
-  const uint32_t mask = (1u << D.bits) - 1u;
-  const uint32_t lf = len < 255u ? len : 255u;
-  const unsigned long long head = ((unsigned long long)D.epoch << 56) | (((h >> 40) & 0xFFull) << 48) | ((unsigned long long)lf << 40);
-  uint32_t idx = (uint32_t)h & mask;
-  for (;;) {
-    unsigned long long v = __hip_atomic_load(&D.slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((uint32_t)(v >> 56) != D.epoch) {  // free in this call (never used, or left over from an earlier call)
-      const unsigned long long prev = atomicCAS(&D.slot[idx], v, head | gpos);
-      if (prev == v) {
-        is_new = true;
-        return idx;
-      }
-      v = prev;
-      if ((uint32_t)(v >> 56) != D.epoch) continue;  // changed to another stale value?  look again
-    }
-    if (lf != 255u && (v & ~kDOffMask) == head) {
-      const uint8_t *rep = text + (v & kDOffMask);
-      bool same = true;
-      for (uint32_t i = 0; i < len; i++)
-        if (rep[i] != mine[i]) { same = false; break; }
-      if (same) return idx;
-    }
-    idx = (idx + 1) & mask;
-  }
-}
-
-// The common case: the word sits in LDS.  Its first 16 bytes are taken with two unaligned 8-byte reads, hashed as two
-// words, and compared with the representative's bytes by two unaligned global loads (one L2 trip), not byte by byte.
-__device__ __forceinline__ uint32_t dd_find_or_insert_lds(const DedupTab &D, const uint8_t *__restrict__ text, const uint8_t *mine,
-                                                          uint32_t len, uint64_t gpos, bool &is_new) {
-  is_new = false;
-  unsigned long long w0 = *reinterpret_cast<const u64u *>(mine), w1 = *reinterpret_cast<const u64u *>(mine + 8);
-  if (len < 8) { w0 &= (1ull << (8 * len)) - 1ull; w1 = 0; }
-  else if (len < 16) w1 &= (1ull << (8 * (len - 8))) - 1ull;
-  unsigned long long h = (w0 ^ 0x9E3779B97F4A7C15ull) * 0xff51afd7ed558ccdull;
-  h ^= h >> 32;
-  h = (h ^ w1 ^ ((unsigned long long)len << 56)) * 0xc4ceb9fe1a85ec53ull;
-  for (uint32_t i = 16; i < len; i += 8) {
-    unsigned long long wk = *reinterpret_cast<const u64u *>(mine + i);  // txt[] has 16 bytes of slack behind the chunk
-    if (len - i < 8) wk &= (1ull << (8 * (len - i))) - 1ull;
-    h ^= h >> 29;
-    h = (h ^ wk) * 0x9E3779B97F4A7C15ull;
-  }
-  h ^= h >> 29; h *= 0x94d049bb133111ebull; h ^= h >> 32;
-  const uint32_t mask = (1u << D.bits) - 1u;
-  const uint32_t lf = len < 255u ? len : 255u;
-  const unsigned long long head = ((unsigned long long)D.epoch << 56) | (((h >> 40) & 0xFFull) << 48) | ((unsigned long long)lf << 40);
-  uint32_t idx = (uint32_t)h & mask;
-  for (;;) {
-    unsigned long long v = __hip_atomic_load(&D.slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((uint32_t)(v >> 56) != D.epoch) {  // free in this call (never used, or left over from an earlier call)
-      const unsigned long long prev = atomicCAS(&D.slot[idx], v, head | gpos);
-      if (D.diag & 1u) atomicAdd(&D.overflow[prev == v ? 1 : 2], 1u);
-      if (prev == v) {
-        is_new = true;  // listed by the caller
-        return idx;
-      }
-      v = prev;
-      if ((uint32_t)(v >> 56) != D.epoch) continue;
-    }
-    if (lf != 255u && (v & ~kDOffMask) == head) {
-      const uint64_t ro = v & kDOffMask;
-      const uint8_t *rep = text + ro;
-      bool same;
-      if (ro + 16 <= D.n_bytes) {
-        unsigned long long r0 = *reinterpret_cast<const u64u *>(rep), r1 = *reinterpret_cast<const u64u *>(rep + 8);
-        if (len < 8) { r0 &= (1ull << (8 * len)) - 1ull; r1 = 0; }
-        else if (len < 16) r1 &= (1ull << (8 * (len - 8))) - 1ull;
-        same = r0 == w0 && r1 == w1;
-        for (uint32_t i = 16; i < len && same; i++) same = rep[i] == mine[i];
-      } else {
-        same = true;
-        for (uint32_t i = 0; i < len; i++)
-          if (rep[i] != mine[i]) { same = false; break; }
-      }
-      if (same) return idx;
-    }
-    idx = (idx + 1) & mask;
-  }
-}
-
-struct WordrefLds {
-  __attribute__((aligned(16))) uint8_t txt[kDCap + 16];
-  uint16_t wl[kDCap];
-  unsigned long long sbits[kDBlocks + 1];
-  unsigned long long endm[kDBlocks + 1];
-  __attribute__((aligned(16))) uint8_t cls_lo[kClsLds];
-  unsigned long long wst[kDBlocks + 1];  // word starts per 64-byte block, and how many came before the block
-  uint32_t nwb[kDBlocks + 1];
-  uint64_t giant_end;
-  uint32_t giant_new, giant_word;
-};
-
-__global__ __launch_bounds__(64) void bpe_wordref_kernel(const uint8_t *__restrict__ text, uint64_t n_bytes,
-                                                         const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
-                                                         const uint8_t *__restrict__ cls_tab, DedupTab D, uint32_t *__restrict__ wref,
-                                                         uint32_t *__restrict__ sent_word, uint32_t *__restrict__ tile_words,
-                                                         uint32_t dbg) {
-  __shared__ WordrefLds L;
-  const int lane = threadIdx.x;
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  const uint64_t t = blockIdx.x;
-  const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
-  if (s_lo == s_hi) {
-    if (lane == 0) { D.tile_new[t] = 0ull; tile_words[t] = 0u; }
-    return;
-  }
-  reinterpret_cast<uint4 *>(L.cls_lo)[lane] = reinterpret_cast<const uint4 *>(cls_tab)[lane];
-  const uint64_t span_base = sent_off[s_lo], span_end = sent_off[s_hi];
-  uint64_t s_next = s_lo;
-  uint64_t cb = span_base;
-  unsigned long long *const my_list = D.newlist + (span_base >> 1);  // room for one entry per two bytes of the span
-  uint32_t *const my_rec = wref + span_base;  // the tile's word records, dense, in text order (at most one per byte)
-  uint32_t n_new = 0, words_done = 0;  // wave-uniform
-  unsigned long long my_bytes = 0;     // per lane, summed at the end
-  for (;;) {
-    const uint64_t abase = cb & ~15ull;
-    const uint32_t off0 = (uint32_t)(cb - abase);
-    const uint64_t avail = span_end - abase;
-    const bool last = avail <= (uint64_t)kDCap;
-    const uint32_t staged = last ? (uint32_t)avail : (uint32_t)kDCap;
-    const uint32_t nblk = (staged + 63) >> 6;
-    for (uint32_t c = lane * 16; c < staged; c += 64 * 16) {
-      const uint64_t g = abase + c;
-      if (g + 16 <= n_bytes && ((reinterpret_cast<uintptr_t>(text + g) & 15) == 0)) {
-        *reinterpret_cast<uint4 *>(&L.txt[c]) = *reinterpret_cast<const uint4 *>(text + g);
-      } else {
-        for (int i = 0; i < 16; i++) L.txt[c + i] = (g + i < n_bytes) ? text[g + i] : (uint8_t)' ';
-      }
-    }
-    if (lane <= kDBlocks) L.sbits[lane] = 0ull;
-    __syncthreads();
-    for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
-      const uint64_t o = sent_off[s];
-      if (o >= abase + staged) break;
-      if (o >= cb) atomicOr(&L.sbits[(o - abase) >> 6], 1ull << ((o - abase) & 63));
-    }
-    __syncthreads();
-    uint32_t nw = 0;
-    bool prev_wb = true;
-    int cut = -1;
-    for (uint32_t blk = 0; blk < nblk; blk++) {
-      const uint32_t p = blk * 64 + lane;
-      const bool inr = p >= off0 && p < staged;
-      const uint8_t b = inr ? L.txt[p] : (uint8_t)' ';
-      const bool lead = !utf8_is_cont(b);
-      uint32_t cp = b;
-      if (b >= 0xC0) {
-        int len = utf8_len(b);
-        if (p + len > staged) len = (int)(staged - p);
-        if (len > 1) {
-          cp = b & (0xFF >> (len + 1));
-          for (int i = 1; i < len; i++) cp = (cp << 6) | (L.txt[p + i] & 0x3F);
-        }
-      }
-      uint8_t c = kClsWs;
-      if (inr && lead) c = cp < (uint32_t)kClsLds ? L.cls_lo[cp] : (cp < kNumCodePoints ? cls_tab[cp] : (uint8_t)0);
-      const unsigned long long INR = __ballot(inr);
-      const unsigned long long LEAD = __ballot(lead);
-      const unsigned long long WSm = __ballot(lead && (c & kClsWs));
-      const unsigned long long PNm = __ballot(lead && (c & kClsPunct));
-      const unsigned long long CONT = ~LEAD;
-      unsigned long long WB = WSm | PNm | ((prev_wb && (CONT & 1ull)) ? 1ull : 0ull);
-      WB |= (WB << 1) & CONT;
-      WB |= (WB << 1) & CONT;
-      WB |= (WB << 1) & CONT;
-      const unsigned long long SS = L.sbits[blk];
-      const unsigned long long first_bit = blk == 0 ? (1ull << off0) : 0ull;
-      const unsigned long long before = (WB << 1) | (prev_wb ? 1ull : 0ull) | SS | first_bit;
-      const unsigned long long SYM = LEAD & ~WSm & INR;
-      const unsigned long long WSTART = SYM & (PNm | before);
-      const unsigned long long CUT = LEAD & (WSm | PNm | SS) & __ballot(inr && p > off0 && p + 4 <= staged);
-      if (CUT) cut = (int)(blk * 64 + 63 - __builtin_clzll(CUT));
-      if (lane == 0) {
-        L.endm[blk] = WSm | WSTART | ~INR;
-        L.wst[blk] = WSTART;
-        L.nwb[blk] = nw;
-      }
-      if ((WSTART >> lane) & 1ull) L.wl[nw + __popcll(WSTART & lt)] = (uint16_t)p;
-      nw += __popcll(WSTART);
-      prev_wb = (WB >> 63) & 1ull;
-    }
-    __syncthreads();
-    uint32_t ce = staged;
-    if (!last) {
-      if (cut < 0) {
-        // a single word longer than the chunk (or a lone separator in front of one): one lane, global memory
-        if (lane == 0) {
-          uint64_t s = s_next;
-          while (s < s_hi && sent_off[s] <= cb) s++;
-          const uint64_t send = sent_off[s];
-          uint64_t e = cb;
-          bool first = true, has_word = true;
-          uint32_t nchar = 0, cp0 = 0;
-          while (e < send) {
-            const uint8_t b = text[e];
-            int len = utf8_len(b);
-            if (e + len > send) len = (int)(send - e);
-            uint32_t cp = b;
-            if (b >= 0x80 && len > 1) {
-              cp = b & (0xFF >> (len + 1));
-              for (int i = 1; i < len; i++) cp = (cp << 6) | (text[e + i] & 0x3F);
-            }
-            const uint8_t c = utf8_is_cont(b) ? kClsWs : (cp < kNumCodePoints ? cls_tab[cp] : (uint8_t)0);
-            if (c & kClsWs) { if (first) { e += len; has_word = false; } break; }
-            if (c & kClsPunct) { if (first) { e += len; nchar = 1; cp0 = cp; } break; }
-            if (first) cp0 = cp;
-            nchar++;
-            e += len;
-            first = false;
-          }
-          L.giant_new = 0;
-          L.giant_word = 0;
-          if (has_word && e > cb) {
-            L.giant_word = 1;
-            if (nchar == 1) {
-              my_rec[words_done] = cp0;
-            } else {
-              bool fresh;
-              const uint64_t wl = e - cb;
-              const uint32_t idx = dd_find_or_insert(D, text, text + cb, (uint32_t)wl, cb, fresh);
-              my_rec[words_done] = kRefSlot | idx;
-              if (fresh) {
-                D.rec[idx] = wl;
-                my_list[n_new] = ((unsigned long long)idx << 32) | cb;
-                my_bytes += wl;
-                L.giant_new = 1;
-              }
-            }
-          }
-          L.giant_end = e;
-        }
-        __syncthreads();
-        const uint32_t wd_before = words_done;
-        cb = L.giant_end;
-        n_new += L.giant_new;
-        words_done += L.giant_word;
-        uint32_t gone = 0;
-        for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
-          if (sent_off[s] >= cb) break;
-          sent_word[s] = wd_before;
-          gone++;
-        }
-        for (int d = 32; d >= 1; d >>= 1) gone += __shfl_xor(gone, d);
-        s_next += gone;
-        __syncthreads();
-        if (cb >= span_end) break;
-        continue;
-      }
-      ce = (uint32_t)cut;
-    }
-    // one lane per word
-    const uint32_t wd0 = words_done;
-    if (!(dbg & 1))
-    for (uint32_t k0 = 0; k0 < nw; k0 += 64) {
-      const uint32_t k = k0 + lane;
-      const uint32_t s = k < nw ? L.wl[k] : 0xFFFFu;
-      const bool mine_w = k < nw && s < ce;
-      bool is_new = false;
-      uint32_t idx = 0, wlen = 0;
-      if (mine_w) {
-        uint32_t w = s >> 6;
-        unsigned long long m = (s & 63) == 63 ? 0ull : (L.endm[w] & ~((2ull << (s & 63)) - 1ull));
-        while (!m && w + 1 < nblk) m = L.endm[++w];
-        uint32_t e = m ? w * 64 + (uint32_t)__builtin_ctzll(m) : ce;
-        if (e > ce) e = ce;
-        wlen = e - s;
-        const uint8_t b0 = L.txt[s];
-        const uint32_t l0 = (uint32_t)utf8_len(b0);
-        uint32_t r;
-        if (wlen <= l0) {  // a single symbol: it is its own token
-          uint32_t cp = b0;
-          if (b0 >= 0xC0 && wlen > 1) {
-            cp = b0 & (0xFF >> (wlen + 1));
-            for (uint32_t i = 1; i < wlen; i++) cp = (cp << 6) | (L.txt[s + i] & 0x3F);
-          }
-          r = cp;
-        } else {
-          idx = dd_find_or_insert_lds(D, text, &L.txt[s], wlen, abase + s, is_new);
-          r = kRefSlot | idx;
-        }
-        my_rec[wd0 + k] = r;  // the words before the cut are a prefix of the list
-      }
-      const unsigned long long NEWm = __ballot(is_new);
-      if (is_new) {
-        D.rec[idx] = wlen;
-        my_list[n_new + __popcll(NEWm & lt)] = ((unsigned long long)idx << 32) | (abase + s);
-        my_bytes += wlen;
-      }
-      n_new += (uint32_t)__popcll(NEWm);
-      words_done += (uint32_t)__popcll(__ballot(mine_w));
-    }
-    // sentences that start in what this chunk consumed: how many of the tile's words come before them
-    cb = abase + ce;
-    uint32_t gone = 0;
-    for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
-      const uint64_t o = sent_off[s];
-      if (!last && o >= cb) break;
-      const uint32_t rel = (uint32_t)(o - abase);
-      sent_word[s] = rel >= staged ? words_done : wd0 + L.nwb[rel >> 6] + (uint32_t)__popcll(L.wst[rel >> 6] & ((1ull << (rel & 63)) - 1ull));
-      gone++;
-    }
-    if (last) break;
-    for (int d = 32; d >= 1; d >>= 1) gone += __shfl_xor(gone, d);
-    s_next += gone;
-    __syncthreads();
-  }
-  for (int d = 32; d >= 1; d >>= 1) my_bytes += __shfl_xor(my_bytes, d);
-  if (lane == 0) {
-    D.tile_new[t] = ((unsigned long long)n_new << 32) | my_bytes;
-    tile_words[t] = words_done;
-  }
-}
-
-// Numbers the new words of every tile (scan of tile_new) and copies them into the unique-word text.
-__global__ __launch_bounds__(64) void bpe_ureg_kernel(const uint8_t *__restrict__ text, const uint64_t *__restrict__ sent_off,
-                                                      const uint64_t *__restrict__ plan, DedupTab D,
-                                                      const unsigned long long *__restrict__ new_local,
-                                                      const unsigned long long *__restrict__ new_blk_base,
-                                                      const unsigned long long *__restrict__ d_total, uint32_t *__restrict__ uslot,
-                                                      uint64_t *__restrict__ uoff, uint8_t *__restrict__ utext) {
-  const int lane = threadIdx.x;
-  const uint64_t t = blockIdx.x;
-  const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
-  if (t == 0 && lane == 0) uoff[*d_total >> 32] = *d_total & 0xFFFFFFFFull;  // the end of the last unique word
-  if (s_lo == s_hi) return;
-  const uint32_t n_new = (uint32_t)(D.tile_new[t] >> 32);
-  if (!n_new) return;
-  const unsigned long long base = new_blk_base[t >> 10] + new_local[t];
-  const uint64_t u0 = base >> 32;
-  uint64_t b0 = base & 0xFFFFFFFFull;
-  const unsigned long long *my_list = D.newlist + (sent_off[s_lo] >> 1);
-  for (uint32_t k0 = 0; k0 < n_new; k0 += 64) {
-    const uint32_t k = k0 + lane;
-    const unsigned long long e = k < n_new ? my_list[k] : 0ull;
-    const uint32_t idx = (uint32_t)(e >> 32);
-    const uint64_t pos = e & 0xFFFFFFFFull;
-    const uint32_t len = k < n_new ? (uint32_t)D.rec[idx] : 0u;
-    uint32_t x = len;
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t y = __shfl_up(x, d);
-      if (lane >= d) x += y;
-    }
-    if (k < n_new) {
-      const uint64_t bo = b0 + (x - len);
-      uoff[u0 + k] = bo;
-      uslot[u0 + k] = idx;
-      for (uint32_t i = 0; i < len; i++) utext[bo + i] = text[pos + i];
-    }
-    b0 += __shfl(x, 63);
-  }
-}
-
-__device__ __forceinline__ uint32_t ref_count(uint32_t v, const unsigned long long *__restrict__ rec, uint64_t &src) {
-  src = 0;
-  if (!(v & kRefSlot)) return 1;
-  const unsigned long long r = rec[v & ~kRefSlot];
-  src = r & 0xFFFFFFFFull;
-  return (uint32_t)(r >> 32);
-}
-
-// tokens per tile (a tile's word records are the first tile_words[t] entries behind wref[span_base])
-__global__ __launch_bounds__(64) void bpe_refcount_kernel(const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
-                                                          const uint32_t *__restrict__ wref, const uint32_t *__restrict__ tile_words,
-                                                          const unsigned long long *__restrict__ rec, uint32_t *__restrict__ tile_tok) {
-  const uint64_t t = blockIdx.x;
-  const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
-  uint32_t total = 0;
-  if (s_lo != s_hi) {
-    const uint32_t *my_rec = wref + sent_off[s_lo];
-    const uint32_t n_w = tile_words[t];
-    for (uint32_t k = threadIdx.x; k < n_w; k += 64) {
-      uint64_t src;
-      total += ref_count(my_rec[k], rec, src);
-    }
-    for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
-  }
-  if (threadIdx.x == 0) tile_tok[t] = total;
-}
-
-// final tokens + sentence offsets
-__global__ __launch_bounds__(64) void bpe_refwrite_kernel(const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
-                                                          uint64_t n_tiles, uint64_t n_sent, const uint32_t *__restrict__ wref,
-                                                          const uint32_t *__restrict__ tile_words, const uint32_t *__restrict__ sent_word,
-                                                          const unsigned long long *__restrict__ rec,
-                                                          const uint32_t *__restrict__ u_ids, const uint32_t *__restrict__ tile_base,
-                                                          const unsigned long long *__restrict__ blk_base,
-                                                          const uint64_t *__restrict__ n_tokens, uint32_t *__restrict__ out_ids,
-                                                          uint64_t *__restrict__ out_off) {
-  __shared__ uint32_t pre[kDCap];
-  const int lane = threadIdx.x;
-  const uint64_t t = blockIdx.x;
-  const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
-  if (t == n_tiles - 1 && lane == 0) out_off[n_sent] = *n_tokens;
-  if (s_lo == s_hi) return;
-  const uint64_t base = blk_base[t >> 10] + tile_base[t];
-  const uint32_t *my_rec = wref + sent_off[s_lo];
-  const uint32_t n_w = tile_words[t];
-  uint64_t s_next = s_lo;
-  uint32_t run = 0;
-  for (uint32_t k0 = 0;; k0 += kDCap) {
-    const uint32_t k1 = n_w - k0 > (uint32_t)kDCap ? k0 + kDCap : n_w;
-    for (uint32_t j0 = k0; j0 < k1; j0 += 64) {
-      const uint32_t j = j0 + lane;
-      uint64_t src = 0;
-      uint32_t v = 0, n = 0;
-      if (j < k1) {
-        v = my_rec[j];
-        n = ref_count(v, rec, src);
-      }
-      uint32_t x = n;
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-      }
-      const uint32_t ex = run + x - n;
-      if (j < k1) pre[j - k0] = ex;
-      if (n == 1 && !(v & kRefSlot)) out_ids[base + ex] = v;
-      else for (uint32_t i = 0; i < n; i++) out_ids[base + ex + i] = u_ids[src + i];
-      run += __shfl(x, 63);
-    }
-    __syncthreads();
-    // sentences whose first word lies in [k0, k1) -- and, on the last chunk, those behind the last word
-    const bool lastc = k1 == n_w;
-    uint32_t mine = 0;
-    for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
-      const uint32_t w = sent_word[s];
-      if (w > k1 || (w == k1 && !lastc)) break;
-      out_off[s] = base + (w < k1 ? pre[w - k0] : run);
-      mine++;
-    }
-    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
-    s_next += mine;
-    __syncthreads();
-    if (lastc) break;
-  }
-}
-
 }  // namespace swt
 
 using namespace swt;
@@ -1019,8 +522,7 @@ struct swt_bpe_table {
   DevBuf in_text, in_off, out_ids, out_off, n_tok;  // staging for the host-buffer entry point
   // word-level dedup inside one call
   TileWorkspace ws2;          // workspaces of the encode over the unique words
-  DevBuf dd_slot, dd_rec, dd_uslot, dd_utext, dd_uoff, dd_misc, dd_newlist, dd_tile_new, dd_new_local, dd_new_blk, dd_tile_words;
-  uint32_t dd_bits = 0, dd_epoch = 0;
+  DedupEngine dd;
 };
 
 static int bpe_upload(swt_bpe_table *t) {
@@ -1097,9 +599,8 @@ void swt_bpe_table_destroy(swt_bpe_table *t) {
   if (t->d_merged) (void)hipFree(t->d_merged);
   t->ws.release();
   t->ws2.release();
-  for (DevBuf *b : {&t->in_text, &t->in_off, &t->out_ids, &t->out_off, &t->n_tok, &t->dd_slot, &t->dd_rec, &t->dd_uslot, &t->dd_utext, &t->dd_uoff,
-                    &t->dd_misc, &t->dd_newlist, &t->dd_tile_new, &t->dd_new_local, &t->dd_new_blk, &t->dd_tile_words})
-    b->release();
+  t->dd.release();
+  for (DevBuf *b : {&t->in_text, &t->in_off, &t->out_ids, &t->out_off, &t->n_tok}) b->release();
   delete t;
 }
 
@@ -1136,95 +637,32 @@ static int bpe_encode_direct(swt_bpe_table *t, TileWorkspace &ws, const uint8_t 
   return SWT_OK;
 }
 
-// The dedup path: nine launches, no host round trip (the number of unique words stays on the device: the unique-word
-// encode is launched over as many tiles as the whole text could need and the tiles behind the real ones find an empty
-// plan).  Returns 1 when the batch is too large for the 32-bit fields of this path (the caller takes the direct path).
+// The dedup path (swt_dedup.h): nine launches, no host round trip -- the number of unique words stays on the device, so
+// the unique-word encode has a fixed number of workgroups and its tile size follows on the device (plan_dev_kernel).
+// Returns 1 when the batch is too large for the 32-bit fields of this path (the caller takes the direct path).
+constexpr int kUTile = 128;            // smallest tile of the unique-word pass (chunk = 2 such tiles); measured: 64 -> 84 us, 128 -> 72 us, 256 -> 88 us
+constexpr uint64_t kUMaxTiles = 8192;  // its launch size: 256 CUs x 32 single-wave workgroups
 static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off, uint64_t n_sent,
                             uint32_t *d_out_ids, uint64_t *d_out_off, uint64_t *d_n_tokens, const uint8_t *d_cls, hipStream_t st) {
   int rc;
-  const uint64_t n_tiles = tile_count(n_bytes, kDTile);
-  if (n_bytes > (1ull << 30)) return 1;
-  if ((rc = t->ws.reserve(n_bytes, n_sent, n_tiles))) return rc;
-  // table: one slot per two bytes of text is always enough (a tabled word has at least two bytes); never cleared
-  uint32_t bits = 16;
-  while ((1ull << bits) < n_bytes + 16 && bits < 30) bits++;
-  if (bits > t->dd_bits) {
-    t->dd_slot.release();
-    t->dd_rec.release();
-    if ((rc = t->dd_slot.reserve(((size_t)1 << bits) * 8)) || (rc = t->dd_rec.reserve(((size_t)1 << bits) * 8))) return rc;
-    SWT_HIP(hipMemsetAsync(t->dd_slot.p, 0, ((size_t)1 << bits) * 8, st));
-    t->dd_bits = bits;
-    t->dd_epoch = 0;
-  }
-  if (++t->dd_epoch >= 256) {
-    SWT_HIP(hipMemsetAsync(t->dd_slot.p, 0, ((size_t)1 << t->dd_bits) * 8, st));
-    t->dd_epoch = 1;
-  }
-  const uint64_t max_uniq = n_bytes / 2 + 2;                 // a tabled word has at least two bytes
-  // the unique-word pass: few words, so short tiles (more waves, each with fewer serial steps per merge round)
-  // (the launch has a fixed number of workgroups, at most one resident wave set of the chip; the tile size follows on the device)
   const uint32_t tile2 = debug_knob(3) == 256 ? 256u : (debug_knob(3) == 64 ? 64u : (uint32_t)kUTile);
-  uint64_t n_tiles2 = tile_count(n_bytes, tile2);            // the unique words together are no longer than the text
+  uint64_t n_tiles2 = tile_count(n_bytes, tile2);  // the unique words together are no longer than the text
   if (n_tiles2 > kUMaxTiles) n_tiles2 = kUMaxTiles;
-  const uint64_t nb_new = (n_tiles + 1023) / 1024;
-  if ((rc = t->dd_utext.reserve(n_bytes + 64)) || (rc = t->dd_uoff.reserve((max_uniq + 2) * 8)) || (rc = t->dd_misc.reserve(64)) ||
-      (rc = t->dd_uslot.reserve((max_uniq + 2) * 4)) || (rc = t->dd_newlist.reserve((n_bytes / 2 + 2) * 8)) ||
-      (rc = t->dd_tile_new.reserve((n_tiles + 1) * 8)) || (rc = t->dd_new_local.reserve((n_tiles + 1) * 8)) ||
-      (rc = t->dd_tile_words.reserve((n_tiles + 1) * 4)) || (rc = t->ws2.reserve(n_bytes, max_uniq, n_tiles2)))
-    return rc;
-  if (t->dd_new_blk.cap < (2 * nb_new + 2) * 8) {
-    if ((rc = t->dd_new_blk.reserve((2 * nb_new + 2) * 8))) return rc;
-    SWT_HIP(hipMemsetAsync(t->dd_new_blk.p, 0, t->dd_new_blk.cap, st));  // the scan's ticket starts at zero (and leaves it so)
-  }
-  unsigned long long *d_misc = t->dd_misc.as<unsigned long long>();  // [0] unique words:32 | their bytes:32, [1..2] diagnostics
-  DedupTab D;
-  D.slot = t->dd_slot.as<unsigned long long>();
-  D.rec = t->dd_rec.as<unsigned long long>();
-  D.n_bytes = n_bytes;
-  D.diag = (debug_knob(2) & 4) ? 1u : 0u;
-  D.bits = t->dd_bits;
-  D.epoch = t->dd_epoch;
-  D.newlist = t->dd_newlist.as<unsigned long long>();
-  D.tile_new = t->dd_tile_new.as<unsigned long long>();
-  D.overflow = reinterpret_cast<unsigned int *>(d_misc + 1);
-  if (D.diag) SWT_HIP(hipMemsetAsync(d_misc, 0, 32, st));
-  uint32_t *wref = t->ws.scratch.as<uint32_t>();
-  uint64_t *plan1 = t->ws.plan.as<uint64_t>();
-  unsigned long long *new_local = t->dd_new_local.as<unsigned long long>(), *new_blk = t->dd_new_blk.as<unsigned long long>();
+  if (n_bytes > kDedupMaxBytes) return 1;
+  if ((rc = t->ws2.reserve(n_bytes, n_bytes / 2 + 2, n_tiles2))) return rc;
   prof_begin(st, 2);
-  launch_plan(d_sent_off, n_sent, n_tiles, kDTile, plan1, st);
-  prof_begin(st, 3);
-  hipLaunchKernelGGL(bpe_wordref_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off, plan1, d_cls, D, wref,
-                     t->ws.sent_local.as<uint32_t>(), t->dd_tile_words.as<uint32_t>(), (uint32_t)debug_knob(2));
-  prof_end(st, 3);
-  launch_scan_u64(n_tiles, D.tile_new, new_local, new_blk, reinterpret_cast<uint64_t *>(d_misc), st);
-  hipLaunchKernelGGL(bpe_ureg_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, d_sent_off, plan1, D, new_local,
-                     new_blk + 1 + nb_new, d_misc, t->dd_uslot.as<uint32_t>(), t->dd_uoff.as<uint64_t>(), t->dd_utext.as<uint8_t>());
-  // encode the unique words once (raw-word mode: each one is a "sentence"); their token runs stay in ws2.scratch
-  launch_plan_dev(t->dd_uoff.as<uint64_t>(), d_misc, n_tiles2, tile2, t->ws2.plan.as<uint64_t>(), st);
+  if ((rc = dedup_front(t->dd, t->ws, d_text, n_bytes, d_sent_off, n_sent, d_cls, kDedupBpe, st))) return rc;
+  // encode the unique words once (raw-word mode: each one is a "sentence"); their token runs stay in ws2.scratch and
+  // phase F of the kernel leaves count | place in rec[slot]
+  launch_plan_dev(t->dd.uoff.as<uint64_t>(), t->dd.total_ptr(), n_tiles2, tile2, t->ws2.plan.as<uint64_t>(), st);
   prof_begin(st);
-  launch_encode_kernel(t, n_tiles2, t->ws2, t->dd_utext.as<uint8_t>(), n_bytes, t->dd_uoff.as<uint64_t>(), nullptr,
-                       t->dd_uslot.as<uint32_t>(), D.rec, st, (int)(2 * tile2));
+  launch_encode_kernel(t, n_tiles2, t->ws2, t->dd.utext.as<uint8_t>(), n_bytes, t->dd.uoff.as<uint64_t>(), nullptr,
+                       t->dd.uslot.as<uint32_t>(), t->dd.rec_ptr(), st, (int)(2 * tile2));
   prof_end(st);
-  // records -> counts -> scan -> tokens
-  hipLaunchKernelGGL(bpe_refcount_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, plan1, wref,
-                     t->dd_tile_words.as<uint32_t>(), D.rec, t->ws.tile_tok.as<uint32_t>());
-  const uint64_t nb = (n_tiles + 1023) / 1024;
-  launch_scan_only(n_tiles, t->ws, d_n_tokens, st);
-  hipLaunchKernelGGL(bpe_refwrite_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, plan1, n_tiles, n_sent, wref,
-                     t->dd_tile_words.as<uint32_t>(), t->ws.sent_local.as<uint32_t>(), D.rec, t->ws2.scratch.as<uint32_t>(),
-                     t->ws.tile_base.as<uint32_t>(), t->ws.blk.as<unsigned long long>() + 1 + nb, d_n_tokens, d_out_ids, d_out_off);
+  rc = dedup_back(t->dd, t->ws, d_sent_off, n_sent, n_bytes, t->ws2.scratch.as<uint32_t>(), kDedupBpe, nullptr, d_out_ids, d_out_off,
+                  d_n_tokens, st);
   prof_end(st, 2);
-  SWT_HIP(hipGetLastError());
-  if (D.diag) {
-    unsigned long long h[3] = {0, 0, 0};
-    SWT_HIP(hipMemcpyAsync(h, d_misc, 24, hipMemcpyDeviceToHost, st));
-    SWT_HIP(hipStreamSynchronize(st));
-    const unsigned int *c = reinterpret_cast<const unsigned int *>(h + 1);
-    fprintf(stderr, "[swt] dedup: %llu unique words, %llu bytes; CAS %u inserted, %u lost to another lane\n", h[0] >> 32,
-            h[0] & 0xFFFFFFFFull, c[1], c[2]);
-  }
-  return SWT_OK;
+  return rc;
 }
 
 int swt_bpe_encode_dev(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off,

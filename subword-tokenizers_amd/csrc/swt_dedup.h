@@ -1,0 +1,47 @@
+// swt_dedup.h -- word-level dedup inside one encode call, shared by the FastBPE and the FastWP encoder.
+//
+// Natural text repeats its words (S85k: 1.5 M words, 79 k distinct).  Both encoders are pure functions of a WORD of the
+// text -- FastBPE.encode_word of a pre-tokenizer word (bpe.py:205-249); FastWP's segment loop of a whitespace-delimited
+// chunk, as long as no vocabulary token contains whitespace (wordpiece.py:251-269: a segment never reads past the
+// whitespace that ends its chunk) -- so each DISTINCT word of a call is encoded once:
+//   front   plan, wordref (one wave per 1-KiB tile: the split, then one lane per word -- hash, table lookup with an EXACT
+//           byte compare against the slot's representative occurrence, or insert), scan, ureg (the words a tile inserted
+//           are copied to the unique-word text in tile order)
+//   (the caller encodes the unique words and leaves count:32 | place:32 of each one's token run in rec[slot])
+//   back    refcount (tokens per tile from the word records), scan, refwrite (tokens + sentence offsets)
+// Slots carry an 8-bit epoch, so the table is never cleared between calls; nothing here returns to the host.
+#pragma once
+#include "swt_common.h"
+#include "swt_tile.h"
+
+namespace swt {
+
+constexpr uint64_t kDedupMinBytes = 1u << 18;   // smaller batches are not worth the extra launches
+constexpr uint64_t kDedupMaxBytes = 1ull << 30;  // 32-bit fields of the records
+constexpr uint32_t kRecFailed = 0xFFFFFFFFu;     // count field of rec[]: the word cannot be encoded (FastWP non-termination)
+
+enum DedupMode {
+  kDedupBpe = 0,  // words of the BertPreTokenizer split (utils.py:27); a one-symbol word is its own token
+  kDedupWp = 1,   // chunks between str.isspace characters (wordpiece.py:268); a sentence with a failed chunk yields no tokens
+};
+
+struct DedupEngine {
+  DevBuf slot, rec, uslot, utext, uoff, misc, newlist, tile_new, new_local, new_blk, tile_words;
+  uint32_t bits = 0, epoch = 0;
+  void release();
+  unsigned long long *rec_ptr() const { return rec.as<unsigned long long>(); }
+  const unsigned long long *total_ptr() const { return misc.as<unsigned long long>(); }  // unique words:32 | their bytes:32
+};
+
+// Front half.  On return (stream order): ws.scratch = dense word records per tile, ws.sent_local = words of the tile before
+// each sentence, E.tile_words, E.utext / E.uoff / E.uslot = the unique words, E.misc[0] = their number and bytes.
+// Returns 1 when the batch does not fit this path (the caller encodes directly).
+int dedup_front(DedupEngine &E, TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off, uint64_t n_sent,
+                const uint8_t *d_cls, DedupMode mode, hipStream_t st);
+
+// Back half.  d_unique_tokens = the buffer the rec[] places point into.  kDedupWp also writes d_status per sentence.
+int dedup_back(DedupEngine &E, TileWorkspace &ws, const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_bytes,
+               const uint32_t *d_unique_tokens, DedupMode mode, uint8_t *d_status, uint32_t *d_out_ids, uint64_t *d_out_off,
+               uint64_t *d_n_tokens, hipStream_t st);
+
+}  // namespace swt

@@ -1,0 +1,714 @@
+// swt_dedup.hip -- word-level dedup inside one encode call (see swt_dedup.h), the kernels and the two host halves.
+#include "swt_dedup.h"
+
+namespace swt {
+
+constexpr uint8_t kClsWs = SWT_CLS_BERT_WS, kClsPunct = SWT_CLS_BERT_PUNCT, kClsPySpace = SWT_CLS_PY_SPACE;
+constexpr int kClsLds = 1024;  // code points whose class is served from LDS (64 lanes x 16 B)
+constexpr int kDTile = 1024;
+constexpr int kDCap = 2048;
+constexpr int kDBlocks = kDCap / 64;
+constexpr unsigned long long kDOffMask = (1ull << 40) - 1ull;
+constexpr uint32_t kRefSlot = 0x80000000u;
+
+typedef uint64_t u64u __attribute__((aligned(1)));  // unaligned 8-byte access (one global_load / ds_read on gfx950)
+
+struct DedupTab {
+  unsigned long long *slot;      // epoch:8 | tag:8 | byte length:8 | representative offset:40
+  unsigned long long *rec;       // per slot: the inserter leaves the byte length; the unique-word encode replaces it by
+                                 // token count:32 | place of the tokens in its scratch:32
+  uint64_t n_bytes;              // size of the text (wide compares stay inside it)
+  uint32_t diag;                 // diagnostics: bit 0 tallies CAS successes / failures behind `overflow`
+  uint32_t bits;
+  uint32_t epoch;
+  // New words are NOT numbered with a global counter (one hot address serialises every returning atomic of the chip:
+  // that alone cost 170 us of a 230 us kernel).  The tile that inserted a word lists it; a scan over the tiles'
+  // (count, bytes) numbers the words afterwards (bpe_ureg_kernel).
+  unsigned long long *newlist;   // slot:32 | position:32 (the inserter leaves the byte length in rec[slot]); a tile's entries start at [span_base >> 1]
+  unsigned long long *tile_new;  // per tile: new words:32 | their bytes:32 (a dedup call holds at most 2^30 bytes)
+  unsigned int *overflow;
+};
+
+// the same function as the wide form in dd_find_or_insert_lds, byte by byte (words in global memory)
+__device__ __forceinline__ unsigned long long dd_pack8(const uint8_t *p, uint32_t n) {
+  unsigned long long w = 0;
+  for (uint32_t i = 0; i < n && i < 8; i++) w |= (unsigned long long)p[i] << (8 * i);
+  return w;
+}
+__device__ __forceinline__ unsigned long long dd_hash(const uint8_t *p, uint32_t n) {
+  const unsigned long long w0 = dd_pack8(p, n), w1 = n > 8 ? dd_pack8(p + 8, n - 8) : 0ull;
+  unsigned long long h = (w0 ^ 0x9E3779B97F4A7C15ull) * 0xff51afd7ed558ccdull;
+  h ^= h >> 32;
+  h = (h ^ w1 ^ ((unsigned long long)n << 56)) * 0xc4ceb9fe1a85ec53ull;
+  for (uint32_t i = 16; i < n; i += 8) {
+    h ^= h >> 29;
+    h = (h ^ dd_pack8(p + i, n - i)) * 0x9E3779B97F4A7C15ull;
+  }
+  h ^= h >> 29; h *= 0x94d049bb133111ebull; h ^= h >> 32;
+  return h;
+}
+
+__device__ uint32_t dd_find_or_insert(const DedupTab &D, const uint8_t *__restrict__ text, const uint8_t *mine, uint32_t len,
+                                      uint64_t gpos, bool &is_new) {
+  is_new = false;
+  const unsigned long long h = dd_hash(mine, len);
+  const uint32_t mask = (1u << D.bits) - 1u;
+  const uint32_t lf = len < 255u ? len : 255u;
+  const unsigned long long head = ((unsigned long long)D.epoch << 56) | (((h >> 40) & 0xFFull) << 48) | ((unsigned long long)lf << 40);
+  uint32_t idx = (uint32_t)h & mask;
+  for (;;) {
+    unsigned long long v = __hip_atomic_load(&D.slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(v >> 56) != D.epoch) {  // free in this call (never used, or left over from an earlier call)
+      const unsigned long long prev = atomicCAS(&D.slot[idx], v, head | gpos);
+      if (prev == v) {
+        is_new = true;
+        return idx;
+      }
+      v = prev;
+      if ((uint32_t)(v >> 56) != D.epoch) continue;  // changed to another stale value?  look again
+    }
+    if (lf != 255u && (v & ~kDOffMask) == head) {
+      const uint8_t *rep = text + (v & kDOffMask);
+      bool same = true;
+      for (uint32_t i = 0; i < len; i++)
+        if (rep[i] != mine[i]) { same = false; break; }
+      if (same) return idx;
+    }
+    idx = (idx + 1) & mask;
+  }
+}
+
+// The common case: the word sits in LDS.  Its first 16 bytes are taken with two unaligned 8-byte reads, hashed as two
+// words, and compared with the representative's bytes by two unaligned global loads (one L2 trip), not byte by byte.
+__device__ __forceinline__ uint32_t dd_find_or_insert_lds(const DedupTab &D, const uint8_t *__restrict__ text, const uint8_t *mine,
+                                                          uint32_t len, uint64_t gpos, bool &is_new) {
+  is_new = false;
+  unsigned long long w0 = *reinterpret_cast<const u64u *>(mine), w1 = *reinterpret_cast<const u64u *>(mine + 8);
+  if (len < 8) { w0 &= (1ull << (8 * len)) - 1ull; w1 = 0; }
+  else if (len < 16) w1 &= (1ull << (8 * (len - 8))) - 1ull;
+  unsigned long long h = (w0 ^ 0x9E3779B97F4A7C15ull) * 0xff51afd7ed558ccdull;
+  h ^= h >> 32;
+  h = (h ^ w1 ^ ((unsigned long long)len << 56)) * 0xc4ceb9fe1a85ec53ull;
+  for (uint32_t i = 16; i < len; i += 8) {
+    unsigned long long wk = *reinterpret_cast<const u64u *>(mine + i);  // txt[] has 16 bytes of slack behind the chunk
+    if (len - i < 8) wk &= (1ull << (8 * (len - i))) - 1ull;
+    h ^= h >> 29;
+    h = (h ^ wk) * 0x9E3779B97F4A7C15ull;
+  }
+  h ^= h >> 29; h *= 0x94d049bb133111ebull; h ^= h >> 32;
+  const uint32_t mask = (1u << D.bits) - 1u;
+  const uint32_t lf = len < 255u ? len : 255u;
+  const unsigned long long head = ((unsigned long long)D.epoch << 56) | (((h >> 40) & 0xFFull) << 48) | ((unsigned long long)lf << 40);
+  uint32_t idx = (uint32_t)h & mask;
+  for (;;) {
+    unsigned long long v = __hip_atomic_load(&D.slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(v >> 56) != D.epoch) {  // free in this call (never used, or left over from an earlier call)
+      const unsigned long long prev = atomicCAS(&D.slot[idx], v, head | gpos);
+      if (D.diag & 1u) atomicAdd(&D.overflow[prev == v ? 1 : 2], 1u);
+      if (prev == v) {
+        is_new = true;  // listed by the caller
+        return idx;
+      }
+      v = prev;
+      if ((uint32_t)(v >> 56) != D.epoch) continue;
+    }
+    if (lf != 255u && (v & ~kDOffMask) == head) {
+      const uint64_t ro = v & kDOffMask;
+      const uint8_t *rep = text + ro;
+      bool same;
+      if (ro + 16 <= D.n_bytes) {
+        unsigned long long r0 = *reinterpret_cast<const u64u *>(rep), r1 = *reinterpret_cast<const u64u *>(rep + 8);
+        if (len < 8) { r0 &= (1ull << (8 * len)) - 1ull; r1 = 0; }
+        else if (len < 16) r1 &= (1ull << (8 * (len - 8))) - 1ull;
+        same = r0 == w0 && r1 == w1;
+        for (uint32_t i = 16; i < len && same; i++) same = rep[i] == mine[i];
+      } else {
+        same = true;
+        for (uint32_t i = 0; i < len; i++)
+          if (rep[i] != mine[i]) { same = false; break; }
+      }
+      if (same) return idx;
+    }
+    idx = (idx + 1) & mask;
+  }
+}
+
+struct WordrefLds {
+  __attribute__((aligned(16))) uint8_t txt[kDCap + 16];
+  uint16_t wl[kDCap];
+  unsigned long long sbits[kDBlocks + 1];
+  unsigned long long endm[kDBlocks + 1];
+  __attribute__((aligned(16))) uint8_t cls_lo[kClsLds];
+  unsigned long long wst[kDBlocks + 1];  // word starts per 64-byte block, and how many came before the block
+  uint32_t nwb[kDBlocks + 1];
+  uint64_t giant_end;
+  uint32_t giant_new, giant_word;
+};
+
+// Mode kDedupBpe: words end at BertPreTokenizer whitespace, every punctuation code point is a word of its own, and a
+// one-symbol word is recorded as its own token.  Mode kDedupWp: words are the chunks between str.isspace characters and
+// every one of them goes through the table.
+template <int Mode>
+__global__ __launch_bounds__(64) void wordref_kernel(const uint8_t *__restrict__ text, uint64_t n_bytes,
+                                                     const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
+                                                     const uint8_t *__restrict__ cls_tab, DedupTab D, uint32_t *__restrict__ wref,
+                                                     uint32_t *__restrict__ sent_word, uint32_t *__restrict__ tile_words,
+                                                     uint32_t dbg) {
+  constexpr uint8_t kWsBit = Mode == kDedupWp ? kClsPySpace : kClsWs;
+  constexpr bool kPunctSplits = Mode == kDedupBpe;
+  __shared__ WordrefLds L;
+  const int lane = threadIdx.x;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const uint64_t t = blockIdx.x;
+  const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
+  if (s_lo == s_hi) {
+    if (lane == 0) { D.tile_new[t] = 0ull; tile_words[t] = 0u; }
+    return;
+  }
+  reinterpret_cast<uint4 *>(L.cls_lo)[lane] = reinterpret_cast<const uint4 *>(cls_tab)[lane];
+  const uint64_t span_base = sent_off[s_lo], span_end = sent_off[s_hi];
+  uint64_t s_next = s_lo;
+  uint64_t cb = span_base;
+  // room for one entry per tabled word of the span: such a word has two bytes (BPE), or one byte (WP: "a" next to a sentence end)
+  unsigned long long *const my_list = D.newlist + (Mode == kDedupWp ? span_base : (span_base >> 1));
+  uint32_t *const my_rec = wref + span_base;  // the tile's word records, dense, in text order (at most one per byte)
+  uint32_t n_new = 0, words_done = 0;  // wave-uniform
+  unsigned long long my_bytes = 0;     // per lane, summed at the end
+  for (;;) {
+    const uint64_t abase = cb & ~15ull;
+    const uint32_t off0 = (uint32_t)(cb - abase);
+    const uint64_t avail = span_end - abase;
+    const bool last = avail <= (uint64_t)kDCap;
+    const uint32_t staged = last ? (uint32_t)avail : (uint32_t)kDCap;
+    const uint32_t nblk = (staged + 63) >> 6;
+    for (uint32_t c = lane * 16; c < staged; c += 64 * 16) {
+      const uint64_t g = abase + c;
+      if (g + 16 <= n_bytes && ((reinterpret_cast<uintptr_t>(text + g) & 15) == 0)) {
+        *reinterpret_cast<uint4 *>(&L.txt[c]) = *reinterpret_cast<const uint4 *>(text + g);
+      } else {
+        for (int i = 0; i < 16; i++) L.txt[c + i] = (g + i < n_bytes) ? text[g + i] : (uint8_t)' ';
+      }
+    }
+    if (lane <= kDBlocks) L.sbits[lane] = 0ull;
+    __syncthreads();
+    for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
+      const uint64_t o = sent_off[s];
+      if (o >= abase + staged) break;
+      if (o >= cb) atomicOr(&L.sbits[(o - abase) >> 6], 1ull << ((o - abase) & 63));
+    }
+    __syncthreads();
+    uint32_t nw = 0;
+    bool prev_wb = true;
+    int cut = -1;
+    for (uint32_t blk = 0; blk < nblk; blk++) {
+      const uint32_t p = blk * 64 + lane;
+      const bool inr = p >= off0 && p < staged;
+      const uint8_t b = inr ? L.txt[p] : (uint8_t)' ';
+      const bool lead = !utf8_is_cont(b);
+      uint32_t cp = b;
+      if (b >= 0xC0) {
+        int len = utf8_len(b);
+        if (p + len > staged) len = (int)(staged - p);
+        if (len > 1) {
+          cp = b & (0xFF >> (len + 1));
+          for (int i = 1; i < len; i++) cp = (cp << 6) | (L.txt[p + i] & 0x3F);
+        }
+      }
+      uint8_t c = kWsBit;
+      if (inr && lead) c = cp < (uint32_t)kClsLds ? L.cls_lo[cp] : (cp < kNumCodePoints ? cls_tab[cp] : (uint8_t)0);
+      const unsigned long long INR = __ballot(inr);
+      const unsigned long long LEAD = __ballot(lead);
+      const unsigned long long WSm = __ballot(lead && (c & kWsBit));
+      const unsigned long long PNm = kPunctSplits ? __ballot(lead && (c & kClsPunct)) : 0ull;
+      const unsigned long long CONT = ~LEAD;
+      unsigned long long WB = WSm | PNm | ((prev_wb && (CONT & 1ull)) ? 1ull : 0ull);
+      WB |= (WB << 1) & CONT;
+      WB |= (WB << 1) & CONT;
+      WB |= (WB << 1) & CONT;
+      const unsigned long long SS = L.sbits[blk];
+      const unsigned long long first_bit = blk == 0 ? (1ull << off0) : 0ull;
+      const unsigned long long before = (WB << 1) | (prev_wb ? 1ull : 0ull) | SS | first_bit;
+      const unsigned long long SYM = LEAD & ~WSm & INR;
+      const unsigned long long WSTART = SYM & (PNm | before);
+      const unsigned long long CUT = LEAD & (WSm | PNm | SS) & __ballot(inr && p > off0 && p + 4 <= staged);
+      if (CUT) cut = (int)(blk * 64 + 63 - __builtin_clzll(CUT));
+      if (lane == 0) {
+        L.endm[blk] = WSm | WSTART | ~INR;
+        L.wst[blk] = WSTART;
+        L.nwb[blk] = nw;
+      }
+      if ((WSTART >> lane) & 1ull) L.wl[nw + __popcll(WSTART & lt)] = (uint16_t)p;
+      nw += __popcll(WSTART);
+      prev_wb = (WB >> 63) & 1ull;
+    }
+    __syncthreads();
+    uint32_t ce = staged;
+    if (!last) {
+      if (cut < 0) {
+        // a single word longer than the chunk (or a lone separator in front of one): one lane, global memory
+        if (lane == 0) {
+          uint64_t s = s_next;
+          while (s < s_hi && sent_off[s] <= cb) s++;
+          const uint64_t send = sent_off[s];
+          uint64_t e = cb;
+          bool first = true, has_word = true;
+          uint32_t nchar = 0, cp0 = 0;
+          while (e < send) {
+            const uint8_t b = text[e];
+            int len = utf8_len(b);
+            if (e + len > send) len = (int)(send - e);
+            uint32_t cp = b;
+            if (b >= 0x80 && len > 1) {
+              cp = b & (0xFF >> (len + 1));
+              for (int i = 1; i < len; i++) cp = (cp << 6) | (text[e + i] & 0x3F);
+            }
+            const uint8_t c = utf8_is_cont(b) ? kWsBit : (cp < kNumCodePoints ? cls_tab[cp] : (uint8_t)0);
+            if (c & kWsBit) { if (first) { e += len; has_word = false; } break; }
+            if (kPunctSplits && (c & kClsPunct)) { if (first) { e += len; nchar = 1; cp0 = cp; } break; }
+            if (first) cp0 = cp;
+            nchar++;
+            e += len;
+            first = false;
+          }
+          L.giant_new = 0;
+          L.giant_word = 0;
+          if (has_word && e > cb) {
+            L.giant_word = 1;
+            if (Mode == kDedupBpe && nchar == 1) {
+              my_rec[words_done] = cp0;
+            } else {
+              bool fresh;
+              const uint64_t wl = e - cb;
+              const uint32_t idx = dd_find_or_insert(D, text, text + cb, (uint32_t)wl, cb, fresh);
+              my_rec[words_done] = kRefSlot | idx;
+              if (fresh) {
+                D.rec[idx] = wl;
+                my_list[n_new] = ((unsigned long long)idx << 32) | cb;
+                my_bytes += wl;
+                L.giant_new = 1;
+              }
+            }
+          }
+          L.giant_end = e;
+        }
+        __syncthreads();
+        const uint32_t wd_before = words_done;
+        cb = L.giant_end;
+        n_new += L.giant_new;
+        words_done += L.giant_word;
+        uint32_t gone = 0;
+        for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
+          if (sent_off[s] >= cb) break;
+          sent_word[s] = wd_before;
+          gone++;
+        }
+        for (int d = 32; d >= 1; d >>= 1) gone += __shfl_xor(gone, d);
+        s_next += gone;
+        __syncthreads();
+        if (cb >= span_end) break;
+        continue;
+      }
+      ce = (uint32_t)cut;
+    }
+    // one lane per word
+    const uint32_t wd0 = words_done;
+    if (!(dbg & 1))
+    for (uint32_t k0 = 0; k0 < nw; k0 += 64) {
+      const uint32_t k = k0 + lane;
+      const uint32_t s = k < nw ? L.wl[k] : 0xFFFFu;
+      const bool mine_w = k < nw && s < ce;
+      bool is_new = false;
+      uint32_t idx = 0, wlen = 0;
+      if (mine_w) {
+        uint32_t w = s >> 6;
+        unsigned long long m = (s & 63) == 63 ? 0ull : (L.endm[w] & ~((2ull << (s & 63)) - 1ull));
+        while (!m && w + 1 < nblk) m = L.endm[++w];
+        uint32_t e = m ? w * 64 + (uint32_t)__builtin_ctzll(m) : ce;
+        if (e > ce) e = ce;
+        wlen = e - s;
+        const uint8_t b0 = L.txt[s];
+        const uint32_t l0 = (uint32_t)utf8_len(b0);
+        uint32_t r;
+        if (Mode == kDedupBpe && wlen <= l0) {  // a single symbol: it is its own token
+          uint32_t cp = b0;
+          if (b0 >= 0xC0 && wlen > 1) {
+            cp = b0 & (0xFF >> (wlen + 1));
+            for (uint32_t i = 1; i < wlen; i++) cp = (cp << 6) | (L.txt[s + i] & 0x3F);
+          }
+          r = cp;
+        } else {
+          idx = dd_find_or_insert_lds(D, text, &L.txt[s], wlen, abase + s, is_new);
+          r = kRefSlot | idx;
+        }
+        my_rec[wd0 + k] = r;  // the words before the cut are a prefix of the list
+      }
+      const unsigned long long NEWm = __ballot(is_new);
+      if (is_new) {
+        D.rec[idx] = wlen;
+        my_list[n_new + __popcll(NEWm & lt)] = ((unsigned long long)idx << 32) | (abase + s);
+        my_bytes += wlen;
+      }
+      n_new += (uint32_t)__popcll(NEWm);
+      words_done += (uint32_t)__popcll(__ballot(mine_w));
+    }
+    // sentences that start in what this chunk consumed: how many of the tile's words come before them
+    cb = abase + ce;
+    uint32_t gone = 0;
+    for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
+      const uint64_t o = sent_off[s];
+      if (!last && o >= cb) break;
+      const uint32_t rel = (uint32_t)(o - abase);
+      sent_word[s] = rel >= staged ? words_done : wd0 + L.nwb[rel >> 6] + (uint32_t)__popcll(L.wst[rel >> 6] & ((1ull << (rel & 63)) - 1ull));
+      gone++;
+    }
+    if (last) break;
+    for (int d = 32; d >= 1; d >>= 1) gone += __shfl_xor(gone, d);
+    s_next += gone;
+    __syncthreads();
+  }
+  for (int d = 32; d >= 1; d >>= 1) my_bytes += __shfl_xor(my_bytes, d);
+  if (lane == 0) {
+    D.tile_new[t] = ((unsigned long long)n_new << 32) | my_bytes;
+    tile_words[t] = words_done;
+  }
+}
+
+// Numbers the new words of every tile (scan of tile_new) and copies them into the unique-word text.
+template <int Mode>
+__global__ __launch_bounds__(64) void ureg_kernel(const uint8_t *__restrict__ text, const uint64_t *__restrict__ sent_off,
+                                                      const uint64_t *__restrict__ plan, DedupTab D,
+                                                      const unsigned long long *__restrict__ new_local,
+                                                      const unsigned long long *__restrict__ new_blk_base,
+                                                      const unsigned long long *__restrict__ d_total, uint32_t *__restrict__ uslot,
+                                                      uint64_t *__restrict__ uoff, uint8_t *__restrict__ utext) {
+  const int lane = threadIdx.x;
+  const uint64_t t = blockIdx.x;
+  const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
+  if (t == 0 && lane == 0) uoff[*d_total >> 32] = *d_total & 0xFFFFFFFFull;  // the end of the last unique word
+  if (s_lo == s_hi) return;
+  const uint32_t n_new = (uint32_t)(D.tile_new[t] >> 32);
+  if (!n_new) return;
+  const unsigned long long base = new_blk_base[t >> 10] + new_local[t];
+  const uint64_t u0 = base >> 32;
+  uint64_t b0 = base & 0xFFFFFFFFull;
+  const unsigned long long *my_list = D.newlist + (Mode == kDedupWp ? sent_off[s_lo] : (sent_off[s_lo] >> 1));
+  for (uint32_t k0 = 0; k0 < n_new; k0 += 64) {
+    const uint32_t k = k0 + lane;
+    const unsigned long long e = k < n_new ? my_list[k] : 0ull;
+    const uint32_t idx = (uint32_t)(e >> 32);
+    const uint64_t pos = e & 0xFFFFFFFFull;
+    const uint32_t len = k < n_new ? (uint32_t)D.rec[idx] : 0u;
+    uint32_t x = len;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    if (k < n_new) {
+      const uint64_t bo = b0 + (x - len);
+      uoff[u0 + k] = bo;
+      uslot[u0 + k] = idx;
+      for (uint32_t i = 0; i < len; i++) utext[bo + i] = text[pos + i];
+    }
+    b0 += __shfl(x, 63);
+  }
+}
+
+__device__ __forceinline__ uint32_t ref_count(uint32_t v, const unsigned long long *__restrict__ rec, uint64_t &src) {
+  src = 0;
+  if (!(v & kRefSlot)) return 1;
+  const unsigned long long r = rec[v & ~kRefSlot];
+  src = r & 0xFFFFFFFFull;
+  return (uint32_t)(r >> 32);
+}
+
+// tokens per tile (a tile's word records are the first tile_words[t] entries behind wref[span_base])
+__global__ __launch_bounds__(64) void refcount_kernel(const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
+                                                          const uint32_t *__restrict__ wref, const uint32_t *__restrict__ tile_words,
+                                                          const unsigned long long *__restrict__ rec, uint32_t *__restrict__ tile_tok) {
+  const uint64_t t = blockIdx.x;
+  const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
+  uint32_t total = 0;
+  if (s_lo != s_hi) {
+    const uint32_t *my_rec = wref + sent_off[s_lo];
+    const uint32_t n_w = tile_words[t];
+    for (uint32_t k = threadIdx.x; k < n_w; k += 64) {
+      uint64_t src;
+      total += ref_count(my_rec[k], rec, src);
+    }
+    for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
+  }
+  if (threadIdx.x == 0) tile_tok[t] = total;
+}
+
+// final tokens + sentence offsets
+__global__ __launch_bounds__(64) void refwrite_kernel(const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
+                                                          uint64_t n_tiles, uint64_t n_sent, const uint32_t *__restrict__ wref,
+                                                          const uint32_t *__restrict__ tile_words, const uint32_t *__restrict__ sent_word,
+                                                          const unsigned long long *__restrict__ rec,
+                                                          const uint32_t *__restrict__ u_ids, const uint32_t *__restrict__ tile_base,
+                                                          const unsigned long long *__restrict__ blk_base,
+                                                          const uint64_t *__restrict__ n_tokens, uint32_t *__restrict__ out_ids,
+                                                          uint64_t *__restrict__ out_off) {
+  __shared__ uint32_t pre[kDCap];
+  const int lane = threadIdx.x;
+  const uint64_t t = blockIdx.x;
+  const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
+  if (t == n_tiles - 1 && lane == 0) out_off[n_sent] = *n_tokens;
+  if (s_lo == s_hi) return;
+  const uint64_t base = blk_base[t >> 10] + tile_base[t];
+  const uint32_t *my_rec = wref + sent_off[s_lo];
+  const uint32_t n_w = tile_words[t];
+  uint64_t s_next = s_lo;
+  uint32_t run = 0;
+  for (uint32_t k0 = 0;; k0 += kDCap) {
+    const uint32_t k1 = n_w - k0 > (uint32_t)kDCap ? k0 + kDCap : n_w;
+    for (uint32_t j0 = k0; j0 < k1; j0 += 64) {
+      const uint32_t j = j0 + lane;
+      uint64_t src = 0;
+      uint32_t v = 0, n = 0;
+      if (j < k1) {
+        v = my_rec[j];
+        n = ref_count(v, rec, src);
+      }
+      uint32_t x = n;
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+      }
+      const uint32_t ex = run + x - n;
+      if (j < k1) pre[j - k0] = ex;
+      if (n == 1 && !(v & kRefSlot)) out_ids[base + ex] = v;
+      else for (uint32_t i = 0; i < n; i++) out_ids[base + ex + i] = u_ids[src + i];
+      run += __shfl(x, 63);
+    }
+    __syncthreads();
+    // sentences whose first word lies in [k0, k1) -- and, on the last chunk, those behind the last word
+    const bool lastc = k1 == n_w;
+    uint32_t mine = 0;
+    for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
+      const uint32_t w = sent_word[s];
+      if (w > k1 || (w == k1 && !lastc)) break;
+      out_off[s] = base + (w < k1 ? pre[w - k0] : run);
+      mine++;
+    }
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    s_next += mine;
+    __syncthreads();
+    if (lastc) break;
+  }
+}
+
+
+// ---- FastWP back half: a sentence with a failed chunk (the reference never returns on it) yields NO tokens and a status,
+// so the counts are summed per sentence.  One kernel, two uses: Write = false leaves the tile's token total, Write = true
+// copies the tokens and writes sentence offsets and statuses.
+template <bool Write>
+__device__ void wp_refs_serial(const uint64_t *__restrict__ sent_off, uint64_t s_lo, uint64_t s_hi, const uint32_t *__restrict__ my_rec,
+                               uint32_t n_w, const uint32_t *__restrict__ sent_word, const unsigned long long *__restrict__ rec,
+                               const uint32_t *__restrict__ u_ids, uint64_t base, uint32_t *__restrict__ tile_tok_out,
+                               uint32_t *__restrict__ out_ids, uint64_t *__restrict__ out_off, uint8_t *__restrict__ status) {
+  // a tile with more words than the LDS holds (a giant sentence): one lane, sentence by sentence
+  uint32_t run = 0;
+  for (uint64_t s = s_lo; s < s_hi; s++) {
+    const uint32_t w0 = sent_word[s], w1 = s + 1 < s_hi ? sent_word[s + 1] : n_w;
+    bool bad = false;
+    uint32_t tot = 0;
+    for (uint32_t w = w0; w < w1; w++) {
+      const uint32_t c = (uint32_t)(rec[my_rec[w] & ~kRefSlot] >> 32);
+      bad |= c == kRecFailed;
+      tot += c;
+    }
+    if (Write) {
+      out_off[s] = base + run;
+      status[s] = bad ? (uint8_t)SWT_WP_NONTERMINATING : (uint8_t)SWT_WP_OK;
+      if (!bad)
+        for (uint32_t w = w0; w < w1; w++) {
+          const unsigned long long r = rec[my_rec[w] & ~kRefSlot];
+          const uint32_t c = (uint32_t)(r >> 32);
+          const uint64_t src = r & 0xFFFFFFFFull;
+          for (uint32_t i = 0; i < c; i++) out_ids[base + run + i] = u_ids[src + i];
+          run += c;
+        }
+    } else if (!bad) {
+      run += tot;
+    }
+  }
+  if (!Write) *tile_tok_out = run;
+}
+
+template <bool Write>
+__global__ __launch_bounds__(64) void wp_refs_kernel(const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
+                                                     uint64_t n_tiles, uint64_t n_sent, const uint32_t *__restrict__ wref,
+                                                     const uint32_t *__restrict__ tile_words, const uint32_t *__restrict__ sent_word,
+                                                     const unsigned long long *__restrict__ rec, const uint32_t *__restrict__ u_ids,
+                                                     const uint32_t *__restrict__ tile_base, const unsigned long long *__restrict__ blk_base,
+                                                     const uint64_t *__restrict__ n_tokens, uint32_t *__restrict__ tile_tok,
+                                                     uint32_t *__restrict__ out_ids, uint64_t *__restrict__ out_off,
+                                                     uint8_t *__restrict__ status) {
+  __shared__ uint32_t cnt[kDCap];  // per word: token count (0 for the words of a failed sentence), then its exclusive prefix
+  const int lane = threadIdx.x;
+  const uint64_t t = blockIdx.x;
+  const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
+  if (Write && t == n_tiles - 1 && lane == 0) out_off[n_sent] = *n_tokens;
+  if (s_lo == s_hi) {
+    if (!Write && lane == 0) tile_tok[t] = 0;
+    return;
+  }
+  const uint64_t base = Write ? blk_base[t >> 10] + tile_base[t] : 0ull;
+  const uint32_t *my_rec = wref + sent_off[s_lo];
+  const uint32_t n_w = tile_words[t];
+  if (n_w > (uint32_t)kDCap) {
+    if (lane == 0) wp_refs_serial<Write>(sent_off, s_lo, s_hi, my_rec, n_w, sent_word, rec, u_ids, base, tile_tok + t, out_ids, out_off, status);
+    return;
+  }
+  for (uint32_t k = lane; k < n_w; k += 64) cnt[k] = (uint32_t)(rec[my_rec[k] & ~kRefSlot] >> 32);
+  __syncthreads();
+  for (uint64_t s = s_lo + lane; s < s_hi; s += 64) {
+    const uint32_t w0 = sent_word[s], w1 = s + 1 < s_hi ? sent_word[s + 1] : n_w;
+    bool bad = false;
+    for (uint32_t w = w0; w < w1; w++) bad |= cnt[w] == kRecFailed;
+    if (bad)
+      for (uint32_t w = w0; w < w1; w++) cnt[w] = 0u;
+    if (Write) status[s] = bad ? (uint8_t)SWT_WP_NONTERMINATING : (uint8_t)SWT_WP_OK;
+  }
+  __syncthreads();
+  uint32_t run = 0;
+  for (uint32_t k0 = 0; k0 < n_w; k0 += 64) {
+    const uint32_t k = k0 + lane;
+    const uint32_t n = k < n_w ? cnt[k] : 0u;
+    uint32_t x = n;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    const uint32_t ex = run + x - n;
+    if (k < n_w) cnt[k] = ex;
+    if (Write && n) {
+      const uint64_t src = rec[my_rec[k] & ~kRefSlot] & 0xFFFFFFFFull;
+      for (uint32_t i = 0; i < n; i++) out_ids[base + ex + i] = u_ids[src + i];
+    }
+    run += __shfl(x, 63);
+  }
+  __syncthreads();
+  if (!Write) {
+    if (lane == 0) tile_tok[t] = run;
+    return;
+  }
+  for (uint64_t s = s_lo + lane; s < s_hi; s += 64) {
+    const uint32_t w0 = sent_word[s];
+    out_off[s] = base + (w0 < n_w ? cnt[w0] : run);
+  }
+}
+
+
+void DedupEngine::release() {
+  for (DevBuf *b : {&slot, &rec, &uslot, &utext, &uoff, &misc, &newlist, &tile_new, &new_local, &new_blk, &tile_words}) b->release();
+  bits = epoch = 0;
+}
+
+int dedup_front(DedupEngine &E, TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off, uint64_t n_sent,
+                const uint8_t *d_cls, DedupMode mode, hipStream_t st) {
+  int rc;
+  if (n_bytes > kDedupMaxBytes) return 1;
+  const uint64_t n_tiles = tile_count(n_bytes, kDTile);
+  if ((rc = ws.reserve(n_bytes, n_sent, n_tiles))) return rc;
+  // table: one slot per byte of text is always enough; never cleared (epoch)
+  uint32_t bits = 16;
+  while ((1ull << bits) < n_bytes + 16 && bits < 30) bits++;
+  if (bits > E.bits) {
+    E.slot.release();
+    E.rec.release();
+    if ((rc = E.slot.reserve(((size_t)1 << bits) * 8)) || (rc = E.rec.reserve(((size_t)1 << bits) * 8))) return rc;
+    SWT_HIP(hipMemsetAsync(E.slot.p, 0, ((size_t)1 << bits) * 8, st));
+    E.bits = bits;
+    E.epoch = 0;
+  }
+  if (++E.epoch >= 256) {
+    SWT_HIP(hipMemsetAsync(E.slot.p, 0, ((size_t)1 << E.bits) * 8, st));
+    E.epoch = 1;
+  }
+  // a tabled word has at least two bytes (BPE: a one-symbol word is not tabled) or one (WP)
+  const uint64_t max_uniq = (mode == kDedupWp ? n_bytes : n_bytes / 2) + 2;
+  const uint64_t nb_new = (n_tiles + 1023) / 1024;
+  if ((rc = E.utext.reserve(n_bytes + 64)) || (rc = E.uoff.reserve((max_uniq + 2) * 8)) || (rc = E.misc.reserve(64)) ||
+      (rc = E.uslot.reserve((max_uniq + 2) * 4)) || (rc = E.newlist.reserve((max_uniq + 2) * 8)) ||
+      (rc = E.tile_new.reserve((n_tiles + 1) * 8)) || (rc = E.new_local.reserve((n_tiles + 1) * 8)) ||
+      (rc = E.tile_words.reserve((n_tiles + 1) * 4)))
+    return rc;
+  if (E.new_blk.cap < (2 * nb_new + 2) * 8) {
+    if ((rc = E.new_blk.reserve((2 * nb_new + 2) * 8))) return rc;
+    SWT_HIP(hipMemsetAsync(E.new_blk.p, 0, E.new_blk.cap, st));  // the scan's ticket starts at zero (and leaves it so)
+  }
+  unsigned long long *d_misc = E.misc.as<unsigned long long>();  // [0] unique words:32 | their bytes:32, [1..2] diagnostics
+  DedupTab D;
+  D.slot = E.slot.as<unsigned long long>();
+  D.rec = E.rec.as<unsigned long long>();
+  D.n_bytes = n_bytes;
+  D.diag = (debug_knob(2) & 4) ? 1u : 0u;
+  D.bits = E.bits;
+  D.epoch = E.epoch;
+  D.newlist = E.newlist.as<unsigned long long>();
+  D.tile_new = E.tile_new.as<unsigned long long>();
+  D.overflow = reinterpret_cast<unsigned int *>(d_misc + 1);
+  if (D.diag) SWT_HIP(hipMemsetAsync(d_misc, 0, 32, st));
+  uint32_t *wref = ws.scratch.as<uint32_t>();
+  uint64_t *plan1 = ws.plan.as<uint64_t>();
+  unsigned long long *new_local = E.new_local.as<unsigned long long>(), *new_blk = E.new_blk.as<unsigned long long>();
+  launch_plan(d_sent_off, n_sent, n_tiles, kDTile, plan1, st);
+  prof_begin(st, 3);
+  if (mode == kDedupWp)
+    hipLaunchKernelGGL(wordref_kernel<kDedupWp>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off, plan1, d_cls, D, wref,
+                       ws.sent_local.as<uint32_t>(), E.tile_words.as<uint32_t>(), (uint32_t)debug_knob(2));
+  else
+    hipLaunchKernelGGL(wordref_kernel<kDedupBpe>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off, plan1, d_cls, D, wref,
+                       ws.sent_local.as<uint32_t>(), E.tile_words.as<uint32_t>(), (uint32_t)debug_knob(2));
+  prof_end(st, 3);
+  launch_scan_u64(n_tiles, D.tile_new, new_local, new_blk, reinterpret_cast<uint64_t *>(d_misc), st);
+  if (mode == kDedupWp)
+    hipLaunchKernelGGL(ureg_kernel<kDedupWp>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, d_sent_off, plan1, D, new_local,
+                       new_blk + 1 + nb_new, d_misc, E.uslot.as<uint32_t>(), E.uoff.as<uint64_t>(), E.utext.as<uint8_t>());
+  else
+    hipLaunchKernelGGL(ureg_kernel<kDedupBpe>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, d_sent_off, plan1, D, new_local,
+                       new_blk + 1 + nb_new, d_misc, E.uslot.as<uint32_t>(), E.uoff.as<uint64_t>(), E.utext.as<uint8_t>());
+  SWT_HIP(hipGetLastError());
+  if (D.diag) {
+    unsigned long long h[3] = {0, 0, 0};
+    SWT_HIP(hipMemcpyAsync(h, d_misc, 24, hipMemcpyDeviceToHost, st));
+    SWT_HIP(hipStreamSynchronize(st));
+    const unsigned int *c = reinterpret_cast<const unsigned int *>(h + 1);
+    fprintf(stderr, "[swt] dedup: %llu unique words, %llu bytes; CAS %u inserted, %u lost to another lane\n", h[0] >> 32,
+            h[0] & 0xFFFFFFFFull, c[1], c[2]);
+  }
+  return SWT_OK;
+}
+
+int dedup_back(DedupEngine &E, TileWorkspace &ws, const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_bytes,
+               const uint32_t *d_unique_tokens, DedupMode mode, uint8_t *d_status, uint32_t *d_out_ids, uint64_t *d_out_off,
+               uint64_t *d_n_tokens, hipStream_t st) {
+  const uint64_t n_tiles = tile_count(n_bytes, kDTile);
+  const uint64_t nb = (n_tiles + 1023) / 1024;
+  const uint32_t *wref = ws.scratch.as<uint32_t>();
+  const uint64_t *plan1 = ws.plan.as<uint64_t>();
+  const unsigned long long *rec = E.rec.as<unsigned long long>();
+  const unsigned long long *blk_base = ws.blk.as<unsigned long long>() + 1 + nb;
+  if (mode == kDedupWp) {
+    hipLaunchKernelGGL(wp_refs_kernel<false>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, plan1, n_tiles, n_sent, wref,
+                       E.tile_words.as<uint32_t>(), ws.sent_local.as<uint32_t>(), rec, d_unique_tokens, ws.tile_base.as<uint32_t>(),
+                       blk_base, d_n_tokens, ws.tile_tok.as<uint32_t>(), d_out_ids, d_out_off, d_status);
+    launch_scan_only(n_tiles, ws, d_n_tokens, st);
+    hipLaunchKernelGGL(wp_refs_kernel<true>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, plan1, n_tiles, n_sent, wref,
+                       E.tile_words.as<uint32_t>(), ws.sent_local.as<uint32_t>(), rec, d_unique_tokens, ws.tile_base.as<uint32_t>(),
+                       blk_base, d_n_tokens, ws.tile_tok.as<uint32_t>(), d_out_ids, d_out_off, d_status);
+  } else {
+    hipLaunchKernelGGL(refcount_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, plan1, wref, E.tile_words.as<uint32_t>(), rec,
+                       ws.tile_tok.as<uint32_t>());
+    launch_scan_only(n_tiles, ws, d_n_tokens, st);
+    hipLaunchKernelGGL(refwrite_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, plan1, n_tiles, n_sent, wref,
+                       E.tile_words.as<uint32_t>(), ws.sent_local.as<uint32_t>(), rec, d_unique_tokens, ws.tile_base.as<uint32_t>(),
+                       blk_base, d_n_tokens, d_out_ids, d_out_off);
+  }
+  SWT_HIP(hipGetLastError());
+  return SWT_OK;
+}
+
+}  // namespace swt
