@@ -13,6 +13,7 @@
 // Node ids: 0 = root, 1 = root_p (detached, childless), 2.. in creation order; root_sharp is the node of "##".
 #include <unordered_map>
 
+#include "swt_dedup.h"
 #include "swt_tile.h"
 
 namespace swt {
@@ -162,6 +163,8 @@ constexpr int kWpTile = 512;    // bytes of sentence starts per tile
 constexpr int kWpCap = 1024;    // staged bytes per chunk
 constexpr int kWpBlocks = kWpCap / 64;
 constexpr int kWpClsLds = 1024;
+constexpr uint32_t kWpUTile = 256;       // smallest tile of the encode over the unique chunks (dedup path)
+constexpr uint64_t kWpUMaxTiles = 8192;  // its fixed launch size
 
 struct WpGiant { uint64_t end; uint32_t ntok; uint32_t nsent; };
 
@@ -511,6 +514,24 @@ static int build_trie(HostTrie &H, const uint32_t *blob, const uint64_t *off, ui
   return SWT_OK;
 }
 
+// After the encode over the unique chunks (every chunk a "sentence" of that launch): each chunk's token run -- its place in
+// the launch's scratch and its length, or kRecFailed when the reference never returns on it -- goes to its table slot.
+__global__ __launch_bounds__(64) void wp_urec_kernel(const uint64_t *__restrict__ uoff, const uint64_t *__restrict__ plan,
+                                                     const uint32_t *__restrict__ sent_local, const uint32_t *__restrict__ tile_tok,
+                                                     const uint8_t *__restrict__ status, const uint32_t *__restrict__ uslot,
+                                                     unsigned long long *__restrict__ rec) {
+  const uint64_t t = blockIdx.x;
+  const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
+  if (s_lo == s_hi) return;
+  const uint64_t span_base = uoff[s_lo];
+  const uint32_t total = tile_tok[t];
+  for (uint64_t s = s_lo + threadIdx.x; s < s_hi; s += 64) {
+    const uint32_t a = sent_local[s], b = s + 1 < s_hi ? sent_local[s + 1] : total;
+    const uint32_t cnt = status[s] != SWT_WP_OK ? kRecFailed : b - a;
+    rec[uslot[s]] = (span_base + a) | ((unsigned long long)cnt << 32);
+  }
+}
+
 }  // namespace swt
 
 using namespace swt;
@@ -528,6 +549,11 @@ struct swt_wp_trie {
   uint32_t *d_pops = nullptr;
   TileWorkspace ws;
   DevBuf in_text, in_off, out_ids, out_off, out_status, n_tok;
+  // word-level dedup inside one call (swt_dedup.h): possible when no vocabulary token holds a str.isspace character
+  bool dedup_ok = false;
+  DedupEngine dd;
+  TileWorkspace ws2;  // the encode over the unique chunks
+  DevBuf u_status;
 };
 
 static int wp_upload(swt_wp_trie *t) {
@@ -575,6 +601,13 @@ int swt_wp_trie_create(const uint32_t *vocab_cps, const uint64_t *vocab_off, uin
     while (t->h_edges[h] != kEdgeEmpty) h = (h + 1) & mask;
     t->h_edges[h] = (kv.first << 21) | kv.second;
   }
+  // A segment of FastWP.tokenize never reads past the whitespace that ends its chunk unless the trie has an edge labelled
+  // with a whitespace character (wordpiece.py:291-316 follows edges only): then, and only then, chunks are independent.
+  t->dedup_ok = true;
+  for (const auto &kv : H.edges) {
+    const uint32_t cp = (uint32_t)(kv.first & ((1u << 21) - 1u));
+    if (cp < kNumCodePoints && (host_class_table()[cp] & SWT_CLS_PY_SPACE)) t->dedup_ok = false;
+  }
   *out = t;
   return SWT_OK;
 }
@@ -585,7 +618,9 @@ void swt_wp_trie_destroy(swt_wp_trie *t) {
   if (t->d_nodes) (void)hipFree(t->d_nodes);
   if (t->d_pops) (void)hipFree(t->d_pops);
   t->ws.release();
-  for (DevBuf *b : {&t->in_text, &t->in_off, &t->out_ids, &t->out_off, &t->out_status, &t->n_tok}) b->release();
+  t->ws2.release();
+  t->dd.release();
+  for (DevBuf *b : {&t->in_text, &t->in_off, &t->out_ids, &t->out_off, &t->out_status, &t->n_tok, &t->u_status}) b->release();
   delete t;
 }
 
@@ -658,6 +693,33 @@ int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, c
   T.corner_nonterm = t->H.corner_nonterm ? 1u : 0u;
   T.empty_status = t->H.child(t->H.root, ' ') >= 0 ? SWT_WP_INDEXERROR : SWT_WP_OK;
   T.corner_id = t->H.corner.size() == 1 ? t->H.corner[0] : t->H.n_vocab + 2;
+  // debug knob 1: bit 0 = never dedup, bit 1 = dedup whatever the batch size (tests)
+  if (t->dedup_ok && T.empty_status == SWT_WP_OK && n_bytes <= kDedupMaxBytes && !(debug_knob(1) & 1) &&
+      (n_bytes >= kDedupMinBytes || (debug_knob(1) & 2))) {
+    // Word-level dedup (swt_dedup.h): the chunks between whitespace are encoded once per call.  The encode over the unique
+    // chunks is this same kernel with every chunk as a "sentence"; its launch size is fixed and the tile size follows on
+    // the device (the number of unique chunks never reaches the host).
+    const uint64_t max_uniq = n_bytes + 2;
+    uint64_t n_tiles2 = tile_count(n_bytes, kWpUTile);
+    if (n_tiles2 > kWpUMaxTiles) n_tiles2 = kWpUMaxTiles;
+    if ((rc = t->ws2.reserve(n_bytes, max_uniq, n_tiles2)) || (rc = t->u_status.reserve(max_uniq + 2))) return rc;
+    prof_begin(st, 2);
+    if ((rc = dedup_front(t->dd, t->ws, d_text, n_bytes, d_sent_off, n_sent, d_cls, kDedupWp, st))) return rc;
+    launch_plan_dev(t->dd.uoff.as<uint64_t>(), t->dd.total_ptr(), n_tiles2, kWpUTile, t->ws2.plan.as<uint64_t>(), st);
+    prof_begin(st);
+    hipLaunchKernelGGL(wp_encode_kernel, dim3((unsigned)n_tiles2), dim3(64), 0, st, t->dd.utext.as<uint8_t>(), n_bytes,
+                       t->dd.uoff.as<uint64_t>(), t->ws2.plan.as<uint64_t>(), d_cls, T, t->ws2.scratch.as<uint32_t>(),
+                       t->ws2.sent_local.as<uint32_t>(), t->ws2.tile_tok.as<uint32_t>(), t->u_status.as<uint8_t>());
+    prof_end(st);
+    hipLaunchKernelGGL(wp_urec_kernel, dim3((unsigned)n_tiles2), dim3(64), 0, st, t->dd.uoff.as<uint64_t>(), t->ws2.plan.as<uint64_t>(),
+                       t->ws2.sent_local.as<uint32_t>(), t->ws2.tile_tok.as<uint32_t>(), t->u_status.as<uint8_t>(),
+                       t->dd.uslot.as<uint32_t>(), t->dd.rec_ptr());
+    rc = dedup_back(t->dd, t->ws, d_sent_off, n_sent, n_bytes, t->ws2.scratch.as<uint32_t>(), kDedupWp, d_status, d_out_ids, d_out_off,
+                    d_n_tokens, st);
+    prof_end(st, 2);
+    return rc;
+  }
+  prof_begin(st, 2);
   launch_plan(d_sent_off, n_sent, n_tiles, kWpTile, t->ws.plan.as<uint64_t>(), st);
   prof_begin(st);
   hipLaunchKernelGGL(wp_encode_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
@@ -665,6 +727,7 @@ int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, c
                      t->ws.tile_tok.as<uint32_t>(), d_status);
   prof_end(st);
   launch_scan_gather(d_sent_off, n_sent, n_tiles, t->ws, d_out_ids, d_out_off, d_n_tokens, st);
+  prof_end(st, 2);
   SWT_HIP(hipGetLastError());
   return SWT_OK;
 }

@@ -323,6 +323,42 @@ def test_wp_edge_shapes(wp, wp_orc):
         same_wp(wp, wp_orc, texts)
 
 
+def test_wp_dedup_path_equals_direct_path(swt, wp, wp_orc, dev, golden, corpora, ref_dir):
+    """word-level dedup inside a call (chunks between whitespace; default for batches >= 256 KiB when no vocabulary token
+    holds whitespace) against the oracle and against the direct path, statuses included"""
+    fw = golden("fuzz_wp.json")
+    fuzz = [c["text"] for c in fw["sentences"]]
+    cases = [
+        [], [""], ["", "", ""], ["", "a", "", "b", ""], ["a"], ["a", "b", "a b", " a  b ", "\ta\nb\r"],
+        ["słowo " * 3000], ["x" * 20000], ["nie wiem " * 700, "a", "tak " * 1200, ""],
+        ["a" * 4095, "b" * 4096, "c" * 4097, "d" * 2047, "e" * 2048, "f" * 2049],
+        ["wyraz"] * 3000, ["w " * 2500],                           # more words in a tile than the LDS path holds
+        ["hello!", "a ## b", "(a", "ok", "abc€def", "dobrze"],     # non-terminating chunks: the whole sentence is refused
+        ["dobrze hello! dobrze", "ok ok ok", "a ## b a", "tak (a tak"],
+        ["5×2km", "˝zgoda˝", "áb", "zażółć gęślą jaźń", "a\u00a0b", "a\u2028b c\u3000d"],
+        fuzz, corpora["pan"][:400],
+    ]
+    tut = swt.FastWP()
+    tut.load_resources(os.path.join(ref_dir, "resources/tests/FastWordPiece"))
+    from oracle import oracle as O
+    tut_orc = O.OracleWP(tut._tokens)
+    try:
+        dev.debug_knob(1, 2)  # dedup whatever the size
+        for texts in cases:
+            same_wp(wp, wp_orc, texts)
+            same_wp(tut, tut_orc, texts)
+        got_d = wp.encode_ids_batch(corpora["t5k"])
+        dev.debug_knob(1, 1)  # never dedup
+        got_n = wp.encode_ids_batch(corpora["t5k"])
+    finally:
+        dev.debug_knob(1, 0)
+    for a, b in zip(got_d, got_n):
+        assert np.array_equal(a, b)
+    for _ in range(3):  # the table is reused under a new epoch
+        for a, b in zip(wp.encode_ids_batch(corpora["t5k"]), got_n):
+            assert np.array_equal(a, b)
+
+
 def test_wp_v30k_subsample_and_properties(swt, oracle, dev):
     """config 3 shape: V30k vocabulary, Zipf corpus; oracle parity on a 20,000-sentence subsample"""
     from subword_tokenizers_amd import synth
