@@ -70,6 +70,16 @@ int swt_device_info(int *n_cu, char *name, size_t name_cap);
 int swt_profile_enable(int on);
 int swt_profile_read(double *ms_total, uint64_t *n_launches);
 
+/* str.lower() on the device for the code points it maps one-to-one at equal UTF-8 length (the
+ * reference lowercases on the host: source/utils.py:27 via preprocessing, source/wordpiece.py:248).  The text is rewritten
+ * in place; need_host[s] = 1 marks a sentence that holds one of the 26 code points the device leaves alone (a lowercase of
+ * another UTF-8 length or of several code points, or U+03A3 whose lowercase depends on its neighbours): the caller
+ * lowercases THAT sentence on the host.  swt_lower_of: the table itself (0xFFFFFFFF = host only), for tests. */
+uint32_t swt_lower_of(uint32_t cp);
+int swt_utf8_lower(uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, uint8_t *need_host);
+int swt_utf8_lower_dev(uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off, uint64_t n_sent, uint8_t *d_need_host,
+                       void *stream);
+
 /* Diagnostics only (ablation timing of kernel phases; results are wrong while a knob is set).  which = 0:
  * bit mask of phases the encode kernels skip. */
 int swt_debug_knob(int which, int value);

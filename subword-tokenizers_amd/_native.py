@@ -53,6 +53,9 @@ SIGNATURES = {
     "swt_wp_encode": (C.c_int, [C.c_void_p, u8p, u64p, C.c_uint64, u32p, C.c_uint64, u64p, u8p, u64p]),
     "swt_wp_encode_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "swt_lower_of": (C.c_uint32, [C.c_uint32]),
+    "swt_utf8_lower": (C.c_int, [u8p, u64p, C.c_uint64, u8p]),
+    "swt_utf8_lower_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "swt_bpe_train_create_text": (C.c_int, [u8p, u64p, C.c_uint64, vpp]),
     "swt_wp_train_create_text": (C.c_int, [u8p, u64p, C.c_uint64, vpp]),
     "swt_bpe_train_create_words": (C.c_int, [u32p, u64p, u32p, C.c_uint64, vpp]),
@@ -160,6 +163,30 @@ def device_info():
 # --------------------------------------------------------------------------------------------------
 # packing: what the reference does per sentence in Python (str.lower(), utils.py:27 / wordpiece.py:248)
 # stays in Python; the device consumes the lowercased UTF-8 bytes of the whole batch.
+
+def lower_of(cp):
+    """the device lowercase table: lowercase code point, or 0xFFFFFFFF for the code points left to the host"""
+    return int(lib().swt_lower_of(cp))
+
+
+def pack_and_lower(texts):
+    """list[str] -> (uint8 bytes of the LOWERCASED texts, uint64 offsets[n+1]): UTF-8 packing on the host, str.lower() on the
+    device (swt_utf8_lower); the few sentences it flags are lowercased here and spliced in."""
+    buf, off = pack_utf8(texts)
+    n = len(texts)
+    if n == 0 or buf.size == 0:
+        return buf, off
+    buf = buf.copy()
+    need = np.zeros(n, dtype=np.uint8)
+    check(lib().swt_utf8_lower(ptr(buf, u8p), ptr(off, u64p), n, ptr(need, u8p)))
+    if need.any():
+        data = buf.tobytes()
+        parts = [texts[i].lower().encode("utf-8", "surrogatepass") if need[i] else data[int(off[i]):int(off[i + 1])] for i in range(n)]
+        off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(np.fromiter(map(len, parts), dtype=np.uint64, count=n), out=off[1:])
+        buf = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    return buf, off
+
 
 def pack_utf8(lowered):
     """list[str] (already lowercased) -> (uint8 bytes, uint64 offsets[n+1])."""

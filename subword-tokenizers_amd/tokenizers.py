@@ -143,7 +143,7 @@ class NaiveBPE(SubwordTokenizer):
         if not isinstance(max_vocab, int):
             raise TypeError("Maximum vocabulary size must be an integer.")
         self.reset()
-        text, off = N.pack_utf8([example.lower() for example in corpus])
+        text, off = N.pack_and_lower(corpus)
         trainer = N.BpeTrainer.from_text(text, off)  # bpe.py:70-81 (split, Counter, symbolise)
         syms = _SymbolTable()
         self.vocab.update(chr(int(c)) for c in trainer.base_symbols())  # bpe.py:75
@@ -278,7 +278,7 @@ class FastBPE(NaiveBPE):
         if not isinstance(texts, list) or not all(isinstance(t, str) for t in texts):
             raise TypeError("Text must be a string.")
         table = self._ensure_table()
-        text, off = N.pack_utf8([t.lower() for t in texts])  # utils.py:27 lower()
+        text, off = N.pack_and_lower(texts)  # utils.py:27 lower(), on the device
         return table.encode(text, off)
 
     def tokenize_batch(self, texts: List[str]) -> List[List[str]]:
@@ -355,7 +355,7 @@ class NaiveWP(SubwordTokenizer):
         if not isinstance(max_vocab, int):
             raise TypeError("max_vocab must be an int.")
         self.reset()
-        text, off = N.pack_utf8([example.lower() for example in corpus])
+        text, off = N.pack_and_lower(corpus)
         trainer = N.BpeTrainer.from_text_wordpiece(text, off)  # wordpiece.py:44-58 (split, Counter, '##' symbols)
         syms = _WpSymbols()
         self.vocab |= {syms.string(int(c)) for c in trainer.base_symbols()}  # wordpiece.py:62-63
@@ -572,7 +572,7 @@ class FastWP(NaiveWP):
             raise TypeError("Text to tokenize must be a string.")
         if self._trie is None:
             raise AttributeError("'FastWP' object has no attribute 'vocab_trie'")  # as the reference before load/train
-        text, off = N.pack_utf8([t.lower() for t in texts])  # wordpiece.py:248 lower(); the " " is implicit
+        text, off = N.pack_and_lower(texts)  # wordpiece.py:248 lower(), on the device; the " " is implicit
         return self._trie.encode(text, off)
 
     def tokenize_batch(self, texts: List[str]) -> List[List[str]]:

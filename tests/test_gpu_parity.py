@@ -164,6 +164,22 @@ def test_bpe_dedup_growing_batches_and_epoch_wrap(swt, oracle, dev, bpe, corpora
         dev.debug_knob(1, 0)
 
 
+def test_device_lowercase_equals_str_lower(swt, dev, bpe, bpe_orc, corpora):
+    """swt_utf8_lower + the host splice of flagged sentences == [t.lower() for t in texts], byte for byte"""
+    import random
+    rng = random.Random(248)
+    alphabet = ("ABCXYZabc ĄĆĘŁŃÓŚŹŻ ÀÉÎÕÜ ΑΒΓΣΩσς ЖЩЯ İI ẞ K Ω Å ȺȾ ⱢⱤ Ꞔ \U00010400\U0001E900 ǅ Ǆ ǲ 中文 \x00\x1c ,.;!?\u00a0\u2028")
+    texts = ["", "A", "ŻÓŁĆ gęślą JAŹŃ", "ΟΔΥΣΣΕΥΣ ΣΑΣ Σ", "İstanbul İİ", "STRAẞE", "K", "x" * 5000 + "Ω", "Z" * 70000]
+    for _ in range(300):
+        texts.append("".join(rng.choice(alphabet) for _ in range(rng.randint(0, 80))))
+    texts += [t.upper() for t in corpora["pan"][:300]] + corpora["t5k"][:500]
+    got_text, got_off = dev.pack_and_lower(texts)
+    want_text, want_off = dev.pack_utf8([t.lower() for t in texts])
+    assert np.array_equal(got_off, want_off) and np.array_equal(got_text, want_text)
+    # and through the encoder: upper-case input gives the ids of the lowercased text
+    same_bpe(bpe, bpe_orc, [t.upper() for t in corpora["pan"][:200]] + ["ΣΟΦΟΣ İstanbul STRAẞE"])
+
+
 def test_bpe_ragged_random_batches(bpe, bpe_orc, corpora):
     rng = np.random.default_rng(7)
     pool = corpora["t5k"] + corpora["pan"] + ["", " ", "x" * 5000, "ala, ma! kota?"]

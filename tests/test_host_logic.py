@@ -55,6 +55,28 @@ def test_product_never_imports_the_oracle():
                 assert not bad.search(src), os.path.join(dirpath, f)
 
 
+def test_lower_table_is_pythons_str_lower(native, golden):
+    """the device lowercase table against str.lower() of this interpreter, every code point; the 26 it leaves to
+    the host are exactly those whose lowercase changes length, expands, or depends on context (U+03A3)"""
+    fx = golden("unicode_lower.json")
+    host = set(fx["host"])
+    assert len(host) == 26 and 0x3A3 in host and 0x130 in host
+    n_pairs = 0
+    for cp in range(0x110000):
+        if 0xD800 <= cp <= 0xDFFF:
+            assert native.lower_of(cp) == cp
+            continue
+        low = chr(cp).lower()
+        got = native.lower_of(cp)
+        if cp in host:
+            assert got == 0xFFFFFFFF
+            assert cp == 0x3A3 or len(low) != 1 or len(low.encode()) != len(chr(cp).encode())
+        else:
+            assert low == chr(got), hex(cp)
+            n_pairs += got != cp
+    assert n_pairs == len(fx["pairs"]) == fx["meta"]["pairs"]
+
+
 def test_class_table_matches_fixture(native, golden):
     fx = golden("unicode_classes.json")
     for bit, name in ((1, "bert_ws"), (2, "bert_punct"), (4, "py_space"), (8, "py_alnum")):
