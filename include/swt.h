@@ -77,6 +77,11 @@ int swt_profile_read(double *ms_total, uint64_t *n_launches);
  * lowercases THAT sentence on the host.  swt_lower_of: the table itself (0xFFFFFFFF = host only), for tests. */
 uint32_t swt_lower_of(uint32_t cp);
 int swt_utf8_lower(uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, uint8_t *need_host);
+/* The same for a host that only knows its sentences' lengths in CODE POINTS (Python: "".join(texts).encode() and len(str)
+ * are cheap, every string's byte length is not): text = well-formed UTF-8 of all sentences joined, cp_off[n_sent + 1] =
+ * running code-point counts.  Writes byte_off[n_sent + 1] (a code point starts at every byte that is not a continuation
+ * byte), lowercases in place and flags as above. */
+int swt_utf8_prepare(uint8_t *text, uint64_t n_bytes, const uint64_t *cp_off, uint64_t n_sent, uint64_t *byte_off, uint8_t *need_host);
 int swt_utf8_lower_dev(uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off, uint64_t n_sent, uint8_t *d_need_host,
                        void *stream);
 

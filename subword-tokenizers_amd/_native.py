@@ -55,6 +55,7 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "swt_lower_of": (C.c_uint32, [C.c_uint32]),
     "swt_utf8_lower": (C.c_int, [u8p, u64p, C.c_uint64, u8p]),
+    "swt_utf8_prepare": (C.c_int, [u8p, C.c_uint64, u64p, C.c_uint64, u64p, u8p]),
     "swt_utf8_lower_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "swt_bpe_train_create_text": (C.c_int, [u8p, u64p, C.c_uint64, vpp]),
     "swt_wp_train_create_text": (C.c_int, [u8p, u64p, C.c_uint64, vpp]),
@@ -170,15 +171,20 @@ def lower_of(cp):
 
 
 def pack_and_lower(texts):
-    """list[str] -> (uint8 bytes of the LOWERCASED texts, uint64 offsets[n+1]): UTF-8 packing on the host, str.lower() on the
-    device (swt_utf8_lower); the few sentences it flags are lowercased here and spliced in."""
-    buf, off = pack_utf8(texts)
+    """list[str] -> (uint8 bytes of the LOWERCASED texts, uint64 byte offsets[n+1]).  The host joins and encodes once and
+    counts code points (len(str)); byte offsets and str.lower() come from the device (swt_utf8_prepare); the few sentences
+    it flags are lowercased here and spliced in."""
     n = len(texts)
+    cp_off = np.zeros(n + 1, dtype=np.uint64)
+    if n:
+        np.cumsum(np.fromiter(map(len, texts), dtype=np.uint64, count=n), out=cp_off[1:])
+    data = "".join(texts).encode("utf-8", "surrogatepass")
+    buf = np.frombuffer(data, dtype=np.uint8).copy() if data else np.zeros(0, dtype=np.uint8)
+    off = np.zeros(n + 1, dtype=np.uint64)
     if n == 0 or buf.size == 0:
         return buf, off
-    buf = buf.copy()
     need = np.zeros(n, dtype=np.uint8)
-    check(lib().swt_utf8_lower(ptr(buf, u8p), ptr(off, u64p), n, ptr(need, u8p)))
+    check(lib().swt_utf8_prepare(ptr(buf, u8p), int(buf.size), ptr(cp_off, u64p), n, ptr(off, u64p), ptr(need, u8p)))
     if need.any():
         data = buf.tobytes()
         parts = [texts[i].lower().encode("utf-8", "surrogatepass") if need[i] else data[int(off[i]):int(off[i + 1])] for i in range(n)]

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "swt_common.h"
+#include "swt_tile.h"
 #include "unicode_lower.inc"
 
 namespace swt {
@@ -85,6 +86,69 @@ __global__ __launch_bounds__(256) void lower_kernel(uint8_t *__restrict__ text, 
   }
 }
 
+// ---- sentence offsets in BYTES from offsets in CODE POINTS ---------------------------------------------------------------
+// The host can join its strings and encode them in one call, and it knows every string's length in code points for free
+// (len(str)); what costs it 20 ms per 8.5 MB is the length of every string in BYTES.  A code point is a byte that is not a
+// UTF-8 continuation byte, so the device counts those per 1-KiB block, scans the counts, and one wave per sentence finds
+// the byte at which its first code point starts.
+constexpr uint32_t kOffBlock = 1024;
+
+__global__ __launch_bounds__(64) void lead_count_kernel(const uint8_t *__restrict__ text, uint64_t n_bytes, uint32_t *__restrict__ blk_cnt) {
+  const uint64_t b0 = (uint64_t)blockIdx.x * kOffBlock;
+  uint32_t c = 0;
+  for (uint32_t i = threadIdx.x * 16; i < kOffBlock; i += 64 * 16) {
+    const uint64_t g = b0 + i;
+    if (g + 16 <= n_bytes && ((reinterpret_cast<uintptr_t>(text + g) & 15) == 0)) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(text + g);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        // continuation bytes are 10xxxxxx: bit 7 set and bit 6 clear
+        const uint32_t cont = (w[k] >> 7) & ~(w[k] >> 6) & 0x01010101u;
+        c += 4u - (uint32_t)__popc(cont);
+      }
+    } else {
+      for (int k = 0; k < 16; k++)
+        if (g + k < n_bytes && (text[g + k] & 0xC0u) != 0x80u) c++;
+    }
+  }
+  for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = c;
+}
+
+__global__ __launch_bounds__(64) void cp_to_byte_kernel(const uint8_t *__restrict__ text, uint64_t n_bytes, const uint64_t *__restrict__ cp_off,
+                                                        uint64_t n_off, uint64_t n_blocks, const uint32_t *__restrict__ blk_local,
+                                                        const unsigned long long *__restrict__ blk_base, uint64_t *__restrict__ byte_off) {
+  const uint64_t s = blockIdx.x;
+  if (s >= n_off) return;
+  const int lane = threadIdx.x;
+  const uint64_t k = cp_off[s];  // code points before this sentence
+  // the block that holds code point k: the last one whose exclusive prefix is <= k
+  uint64_t a = 0, z = n_blocks;
+  while (a + 1 < z) {
+    const uint64_t mid = (a + z) >> 1;
+    if (blk_base[mid >> 10] + blk_local[mid] <= k) a = mid; else z = mid;
+  }
+  uint64_t need = k - (blk_base[a >> 10] + blk_local[a]);  // leads to pass inside block a
+  uint64_t pos = a * (uint64_t)kOffBlock;
+  uint64_t found = n_bytes;  // k == total code points: the end of the text
+  for (uint32_t i = 0; i < kOffBlock && pos + i < n_bytes; i += 64) {
+    const uint64_t g = pos + i + lane;
+    const bool lead = g < n_bytes && (text[g] & 0xC0u) != 0x80u;
+    const unsigned long long M = __ballot(lead);
+    const uint32_t c = (uint32_t)__popcll(M);
+    if (need < c) {
+      // the (need)-th set bit of M
+      unsigned long long m = M;
+      for (uint64_t j = 0; j < need; j++) m &= m - 1ull;
+      found = pos + i + (uint64_t)__builtin_ctzll(m);
+      break;
+    }
+    need -= c;
+  }
+  if (lane == 0) byte_off[s] = found;
+}
+
 }  // namespace swt
 
 using namespace swt;
@@ -109,6 +173,51 @@ int swt_utf8_lower_dev(uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent
   }
   SWT_HIP(hipGetLastError());
   return SWT_OK;
+}
+
+// d_byte_off[s] = byte at which the sentence that starts after d_cp_off[s] code points begins (n_sent + 1 entries; well-formed
+// UTF-8: a code point is a byte that is not a continuation byte)
+static int utf8_offsets_dev(const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_cp_off, uint64_t n_sent, uint64_t *d_byte_off,
+                            TileWorkspace &ws, hipStream_t st) {
+  const uint64_t n_blocks = n_bytes ? (n_bytes + kOffBlock - 1) / kOffBlock : 1;
+  int rc;
+  if ((rc = ws.reserve(0, 0, n_blocks))) return rc;  // tile_tok = counts, tile_base / blk = their scan, plan[0] = the total
+  hipLaunchKernelGGL(lead_count_kernel, dim3((unsigned)n_blocks), dim3(64), 0, st, d_text, n_bytes, ws.tile_tok.as<uint32_t>());
+  launch_scan_only(n_blocks, ws, ws.plan.as<uint64_t>(), st);
+  const uint64_t nb = (n_blocks + 1023) / 1024;
+  hipLaunchKernelGGL(cp_to_byte_kernel, dim3((unsigned)(n_sent + 1)), dim3(64), 0, st, d_text, n_bytes, d_cp_off, n_sent + 1, n_blocks,
+                     ws.tile_base.as<uint32_t>(), ws.blk.as<unsigned long long>() + 1 + nb, d_byte_off);
+  SWT_HIP(hipGetLastError());
+  return SWT_OK;
+}
+
+int swt_utf8_prepare(uint8_t *text, uint64_t n_bytes, const uint64_t *cp_off, uint64_t n_sent, uint64_t *byte_off, uint8_t *need_host) {
+  if (!cp_off || !byte_off || (n_sent && !need_host) || (n_bytes && !text)) return fail(SWT_ERR_INVALID, "null argument");
+  if (cp_off[0] != 0) return fail(SWT_ERR_INVALID, "cp_off[0] must be 0");
+  for (uint64_t s = 0; s < n_sent; s++)
+    if (cp_off[s] > cp_off[s + 1]) return fail(SWT_ERR_INVALID, "offsets must be non-decreasing");
+  if (cp_off[n_sent] > n_bytes) return fail(SWT_ERR_INVALID, "more code points than bytes");
+  if (n_sent + 1 > 0x7FFFFFFFull) return fail(SWT_ERR_UNSUPPORTED, "too many sentences for one call");
+  int rc = ensure_device();
+  if (rc) return rc;
+  DevBuf d_text, d_cp, d_off, d_flag;
+  TileWorkspace ws;
+  if ((rc = d_text.reserve(n_bytes + 16)) || (rc = d_cp.reserve((n_sent + 1) * 8)) || (rc = d_off.reserve((n_sent + 1) * 8)) ||
+      (rc = d_flag.reserve(n_sent + 16)))
+    return rc;
+  if (n_bytes) SWT_HIP(hipMemcpy(d_text.p, text, n_bytes, hipMemcpyHostToDevice));
+  SWT_HIP(hipMemcpy(d_cp.p, cp_off, (n_sent + 1) * 8, hipMemcpyHostToDevice));
+  rc = utf8_offsets_dev(d_text.as<uint8_t>(), n_bytes, d_cp.as<uint64_t>(), n_sent, d_off.as<uint64_t>(), ws, nullptr);
+  if (!rc) rc = swt_utf8_lower_dev(d_text.as<uint8_t>(), n_bytes, d_off.as<uint64_t>(), n_sent, d_flag.as<uint8_t>(), nullptr);
+  if (!rc) {
+    SWT_HIP(hipMemcpy(byte_off, d_off.p, (n_sent + 1) * 8, hipMemcpyDeviceToHost));
+    if (n_bytes) SWT_HIP(hipMemcpy(text, d_text.p, n_bytes, hipMemcpyDeviceToHost));
+    if (n_sent) SWT_HIP(hipMemcpy(need_host, d_flag.p, n_sent, hipMemcpyDeviceToHost));
+    if (byte_off[n_sent] != n_bytes)
+      rc = fail(SWT_ERR_INVALID, "cp_off[n_sent] = %llu is not the number of code points in the text", (unsigned long long)cp_off[n_sent]);
+  }
+  d_text.release(); d_cp.release(); d_off.release(); d_flag.release(); ws.release();
+  return rc;
 }
 
 int swt_utf8_lower(uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, uint8_t *need_host) {
