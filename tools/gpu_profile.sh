@@ -18,7 +18,7 @@ rows = [r for r in csv.DictReader(open(sys.argv[1])) if "swt::" in r.get("Kernel
 per = collections.defaultdict(list)
 for r in rows:
     per[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
-calls = len(per.get("swt::bpe_wordref_kernel", [])) or 1
+calls = max([len(v) for k, v in per.items() if "wordref_kernel" in k] or [1])
 tot = 0.0
 with open("%s/bpe_encode_%s_per_kernel.csv" % (sys.argv[3], sys.argv[2]), "w") as o:
     o.write("kernel,launches,mean_%s_KiB_per_launch\n" % sys.argv[2])
