@@ -85,8 +85,10 @@ int swt_utf8_prepare(uint8_t *text, uint64_t n_bytes, const uint64_t *cp_off, ui
 int swt_utf8_lower_dev(uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off, uint64_t n_sent, uint8_t *d_need_host,
                        void *stream);
 
-/* Diagnostics only (ablation timing of kernel phases; results are wrong while a knob is set).  which = 0:
- * bit mask of phases the encode kernels skip. */
+/* Diagnostics and test switches.  which = 0: bit mask of phases the BPE encode kernel skips (ablation timing; results are
+ * wrong while set); 1: bit 0 = never use the word-level dedup, bit 1 = use it whatever the batch size; 2: ablation of the
+ * dedup front kernel; 3: tile size of FastBPE's unique-word pass; 4: log2 of the dedup word table's slots (tests: a tiny
+ * table makes words overflow it; results stay exact). */
 int swt_debug_knob(int which, int value);
 
 /* Code-point classes compiled into the library (fixture data probed from the wheel/interpreter the

@@ -21,6 +21,11 @@ struct DedupTab {
   uint32_t diag;                 // diagnostics: bit 0 tallies CAS successes / failures behind `overflow`
   uint32_t bits;
   uint32_t epoch;
+  // The table is kept SMALL (a few MB: its hot lines stay in the 4-MiB L2 of every XCD) and is not sized for the worst
+  // case.  A word that finds neither itself nor a free slot within kDdMaxProbes steps -- and any word of 255+ bytes --
+  // is simply not deduplicated: it gets a record slot of its own behind the table, numbered by its position in the
+  // text, and is encoded like a new word.  Correct whatever the load; only repeated words that overflow cost extra.
+  uint32_t ovf_shift;            // position >> ovf_shift is unique per tabled word (1: two bytes at least; 0: one)
   // New words are NOT numbered with a global counter (one hot address serialises every returning atomic of the chip:
   // that alone cost 170 us of a 230 us kernel).  The tile that inserted a word lists it; a scan over the tiles'
   // (count, bytes) numbers the words afterwards (bpe_ureg_kernel).
@@ -28,6 +33,9 @@ struct DedupTab {
   unsigned long long *tile_new;  // per tile: new words:32 | their bytes:32 (a dedup call holds at most 2^30 bytes)
   unsigned int *overflow;
 };
+
+constexpr uint32_t kDdMaxProbes = 24;
+__device__ __forceinline__ uint32_t dd_own_slot(const DedupTab &D, uint64_t gpos) { return (1u << D.bits) + (uint32_t)(gpos >> D.ovf_shift); }
 
 // the same function as the wide form in dd_find_or_insert_lds, byte by byte (words in global memory)
 __device__ __forceinline__ unsigned long long dd_pack8(const uint8_t *p, uint32_t n) {
@@ -51,9 +59,11 @@ __device__ __forceinline__ unsigned long long dd_hash(const uint8_t *p, uint32_t
 __device__ uint32_t dd_find_or_insert(const DedupTab &D, const uint8_t *__restrict__ text, const uint8_t *mine, uint32_t len,
                                       uint64_t gpos, bool &is_new) {
   is_new = false;
+  if (len >= 255u) { is_new = true; return dd_own_slot(D, gpos); }
   const unsigned long long h = dd_hash(mine, len);
   const uint32_t mask = (1u << D.bits) - 1u;
-  const uint32_t lf = len < 255u ? len : 255u;
+  const uint32_t lf = len;
+  uint32_t probes = 0;
   const unsigned long long head = ((unsigned long long)D.epoch << 56) | (((h >> 40) & 0xFFull) << 48) | ((unsigned long long)lf << 40);
   uint32_t idx = (uint32_t)h & mask;
   for (;;) {
@@ -67,13 +77,14 @@ __device__ uint32_t dd_find_or_insert(const DedupTab &D, const uint8_t *__restri
       v = prev;
       if ((uint32_t)(v >> 56) != D.epoch) continue;  // changed to another stale value?  look again
     }
-    if (lf != 255u && (v & ~kDOffMask) == head) {
+    if ((v & ~kDOffMask) == head) {
       const uint8_t *rep = text + (v & kDOffMask);
       bool same = true;
       for (uint32_t i = 0; i < len; i++)
         if (rep[i] != mine[i]) { same = false; break; }
       if (same) return idx;
     }
+    if (++probes >= kDdMaxProbes) { is_new = true; return dd_own_slot(D, gpos); }
     idx = (idx + 1) & mask;
   }
 }
@@ -83,6 +94,7 @@ __device__ uint32_t dd_find_or_insert(const DedupTab &D, const uint8_t *__restri
 __device__ __forceinline__ uint32_t dd_find_or_insert_lds(const DedupTab &D, const uint8_t *__restrict__ text, const uint8_t *mine,
                                                           uint32_t len, uint64_t gpos, bool &is_new) {
   is_new = false;
+  if (len >= 255u) { is_new = true; return dd_own_slot(D, gpos); }
   unsigned long long w0 = *reinterpret_cast<const u64u *>(mine), w1 = *reinterpret_cast<const u64u *>(mine + 8);
   if (len < 8) { w0 &= (1ull << (8 * len)) - 1ull; w1 = 0; }
   else if (len < 16) w1 &= (1ull << (8 * (len - 8))) - 1ull;
@@ -97,7 +109,8 @@ __device__ __forceinline__ uint32_t dd_find_or_insert_lds(const DedupTab &D, con
   }
   h ^= h >> 29; h *= 0x94d049bb133111ebull; h ^= h >> 32;
   const uint32_t mask = (1u << D.bits) - 1u;
-  const uint32_t lf = len < 255u ? len : 255u;
+  const uint32_t lf = len;
+  uint32_t probes = 0;
   const unsigned long long head = ((unsigned long long)D.epoch << 56) | (((h >> 40) & 0xFFull) << 48) | ((unsigned long long)lf << 40);
   uint32_t idx = (uint32_t)h & mask;
   for (;;) {
@@ -112,7 +125,7 @@ __device__ __forceinline__ uint32_t dd_find_or_insert_lds(const DedupTab &D, con
       v = prev;
       if ((uint32_t)(v >> 56) != D.epoch) continue;
     }
-    if (lf != 255u && (v & ~kDOffMask) == head) {
+    if ((v & ~kDOffMask) == head) {
       const uint64_t ro = v & kDOffMask;
       const uint8_t *rep = text + ro;
       bool same;
@@ -129,6 +142,7 @@ __device__ __forceinline__ uint32_t dd_find_or_insert_lds(const DedupTab &D, con
       }
       if (same) return idx;
     }
+    if (++probes >= kDdMaxProbes) { is_new = true; return dd_own_slot(D, gpos); }
     idx = (idx + 1) & mask;
   }
 }
@@ -612,17 +626,23 @@ int dedup_front(DedupEngine &E, TileWorkspace &ws, const uint8_t *d_text, uint64
   if (n_bytes > kDedupMaxBytes) return 1;
   const uint64_t n_tiles = tile_count(n_bytes, kDTile);
   if ((rc = ws.reserve(n_bytes, n_sent, n_tiles))) return rc;
-  // table: one slot per byte of text is always enough; never cleared (epoch)
+  // table: one slot per 32 bytes of text (S85k: one distinct word per 107 bytes), 2^16 .. 2^24 slots: small on purpose
+  // (see DedupTab); never cleared (epoch).  rec[] = the table's slots, then the own slots of the words that overflowed.
   uint32_t bits = 16;
-  while ((1ull << bits) < n_bytes + 16 && bits < 30) bits++;
+  while ((1ull << bits) < n_bytes / 32 && bits < 24) bits++;
+  if (debug_knob(4) > 0) {  // tests: a table of 2^knob slots, so that words overflow it
+    bits = (uint32_t)debug_knob(4);
+    if (bits != E.bits) E.bits = 0;
+  }
   if (bits > E.bits) {
     E.slot.release();
-    E.rec.release();
-    if ((rc = E.slot.reserve(((size_t)1 << bits) * 8)) || (rc = E.rec.reserve(((size_t)1 << bits) * 8))) return rc;
+    if ((rc = E.slot.reserve(((size_t)1 << bits) * 8))) return rc;
     SWT_HIP(hipMemsetAsync(E.slot.p, 0, ((size_t)1 << bits) * 8, st));
     E.bits = bits;
     E.epoch = 0;
   }
+  const uint32_t ovf_shift = mode == kDedupWp ? 0u : 1u;
+  if ((rc = E.rec.reserve((((size_t)1 << E.bits) + (n_bytes >> ovf_shift) + 2) * 8))) return rc;
   if (++E.epoch >= 256) {
     SWT_HIP(hipMemsetAsync(E.slot.p, 0, ((size_t)1 << E.bits) * 8, st));
     E.epoch = 1;
@@ -647,6 +667,7 @@ int dedup_front(DedupEngine &E, TileWorkspace &ws, const uint8_t *d_text, uint64
   D.diag = (debug_knob(2) & 4) ? 1u : 0u;
   D.bits = E.bits;
   D.epoch = E.epoch;
+  D.ovf_shift = ovf_shift;
   D.newlist = E.newlist.as<unsigned long long>();
   D.tile_new = E.tile_new.as<unsigned long long>();
   D.overflow = reinterpret_cast<unsigned int *>(d_misc + 1);

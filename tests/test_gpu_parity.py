@@ -164,6 +164,22 @@ def test_bpe_dedup_growing_batches_and_epoch_wrap(swt, oracle, dev, bpe, corpora
         dev.debug_knob(1, 0)
 
 
+def test_dedup_table_overflow_is_harmless(swt, dev, bpe, bpe_orc, wp, wp_orc, corpora):
+    """the word table is small on purpose; a word that finds no slot is encoded on its own -- same ids whatever the load"""
+    texts = corpora["t5k"][:2500] + ["x" * 300 + " " + "x" * 300, "hello! ok", "a ## b"]
+    try:
+        dev.debug_knob(1, 2)
+        for bits in (4, 8, 12):
+            dev.debug_knob(4, bits)
+            same_bpe(bpe, bpe_orc, texts)
+            same_wp(wp, wp_orc, texts)
+    finally:
+        dev.debug_knob(4, 0)
+        dev.debug_knob(1, 0)
+    same_bpe(bpe, bpe_orc, texts)
+    same_wp(wp, wp_orc, texts)
+
+
 def test_device_lowercase_equals_str_lower(swt, dev, bpe, bpe_orc, corpora):
     """swt_utf8_lower + the host splice of flagged sentences == [t.lower() for t in texts], byte for byte"""
     import random
