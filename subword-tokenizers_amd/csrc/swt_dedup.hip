@@ -575,17 +575,36 @@ __global__ __launch_bounds__(64) void wp_refs_kernel(const uint64_t *__restrict_
     if (lane == 0) wp_refs_serial<Write>(sent_off, s_lo, s_hi, my_rec, n_w, sent_word, rec, u_ids, base, tile_tok + t, out_ids, out_off, status);
     return;
   }
-  for (uint32_t k = lane; k < n_w; k += 64) cnt[k] = (uint32_t)(rec[my_rec[k] & ~kRefSlot] >> 32);
-  __syncthreads();
-  for (uint64_t s = s_lo + lane; s < s_hi; s += 64) {
-    const uint32_t w0 = sent_word[s], w1 = s + 1 < s_hi ? sent_word[s + 1] : n_w;
-    bool bad = false;
-    for (uint32_t w = w0; w < w1; w++) bad |= cnt[w] == kRecFailed;
-    if (bad)
-      for (uint32_t w = w0; w < w1; w++) cnt[w] = 0u;
-    if (Write) status[s] = bad ? (uint8_t)SWT_WP_NONTERMINATING : (uint8_t)SWT_WP_OK;
+  bool any_bad = false;
+  uint32_t my_sum = 0;
+  for (uint32_t k = lane; k < n_w; k += 64) {
+    const uint32_t c = (uint32_t)(rec[my_rec[k] & ~kRefSlot] >> 32);
+    cnt[k] = c;
+    any_bad |= c == kRecFailed;
+    my_sum += c;
   }
+  any_bad = __any(any_bad);
   __syncthreads();
+  if (any_bad) {
+    // rare: some chunk of this tile cannot be encoded -- find its sentence(s), one lane per sentence
+    for (uint64_t s = s_lo + lane; s < s_hi; s += 64) {
+      const uint32_t w0 = sent_word[s], w1 = s + 1 < s_hi ? sent_word[s + 1] : n_w;
+      bool bad = false;
+      for (uint32_t w = w0; w < w1; w++) bad |= cnt[w] == kRecFailed;
+      if (bad)
+        for (uint32_t w = w0; w < w1; w++) cnt[w] = 0u;
+      if (Write) status[s] = bad ? (uint8_t)SWT_WP_NONTERMINATING : (uint8_t)SWT_WP_OK;
+    }
+    __syncthreads();
+  } else {
+    if (Write)
+      for (uint64_t s = s_lo + lane; s < s_hi; s += 64) status[s] = (uint8_t)SWT_WP_OK;
+    if (!Write) {  // the common case of the counting launch: the tile's total is the plain sum
+      for (int d = 32; d >= 1; d >>= 1) my_sum += __shfl_xor(my_sum, d);
+      if (lane == 0) tile_tok[t] = my_sum;
+      return;
+    }
+  }
   uint32_t run = 0;
   for (uint32_t k0 = 0; k0 < n_w; k0 += 64) {
     const uint32_t k = k0 + lane;
