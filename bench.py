@@ -164,8 +164,8 @@ def bench_bpe_encode(args, torch, dist, rank, world, local):
         achieved = algo / per_call_s / 1e9
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_from_profile("bpe_encode"),
-                "kernel": "dedup pipeline: plan, bpe_wordref, scan, bpe_ureg, plan_dev, bpe_encode (unique words), "
-                          "bpe_refcount, scan, bpe_refwrite",
+                "kernel": "dedup pipeline: plan, wordref, scan, ureg, plan_dev, bpe_encode (unique words), "
+                          "refcount, scan, refwrite",
                 "kernel_us": round(per_call_s * 1e6, 2),
                 "algorithmic_bytes_per_launch": int(algo), "launches_timed": int(calls),
                 "dominant_kernel": {"name": "bpe_encode_kernel", "us": round(kernel_ms * 1e3 / max(launches, 1), 2),
