@@ -16,7 +16,7 @@
 
 namespace swt {
 
-constexpr uint64_t kDedupMinBytes = 1u << 18;   // smaller batches are not worth the extra launches
+constexpr uint64_t kDedupMinBytes = 1u << 20;   // below ~0.9 MB the nine launches cost more than the merge rounds they save (measured)
 constexpr uint64_t kDedupMaxBytes = 1ull << 30;  // 32-bit fields of the records
 constexpr uint32_t kRecFailed = 0xFFFFFFFFu;     // count field of rec[]: the word cannot be encoded (FastWP non-termination)
 
