@@ -180,6 +180,48 @@ def test_dedup_table_overflow_is_harmless(swt, dev, bpe, bpe_orc, wp, wp_orc, co
     same_wp(wp, wp_orc, texts)
 
 
+def test_random_tables_and_texts_both_paths(swt, oracle, dev):
+    """seeded stress: random merge tables / vocabularies over tiny alphabets (twin runs, overlapping merges, punctuation and
+    '#' inside chunks), random ragged texts; direct path and dedup path against the oracle"""
+    import random
+    rng = random.Random(20261004)
+    for case in range(12):
+        alpha = rng.choice(["ab", "abc", "aąb", "abcdż", "xy#", "ab.,"])
+        letters = [c for c in alpha if c.isalnum()] or ["a"]
+        # a BPE table: random pairs over symbols that exist when the merge is made
+        syms = list(dict.fromkeys(letters))
+        merges = []
+        for _ in range(rng.randint(1, 25)):
+            l, r = rng.choice(syms), rng.choice(syms)
+            if (l, r) not in merges:
+                merges.append((l, r))
+                syms.append(l + r)
+        bpe = swt.FastBPE()
+        bpe.merges_list = list(merges)
+        bpe._build_table()
+        borc = oracle.OracleBPE(merges)
+        # a WordPiece vocabulary: single characters (so that the reference terminates) + random pieces
+        pieces = set(alpha) | {"##" + c for c in alpha if c != "#"}
+        for _ in range(rng.randint(0, 20)):
+            w = "".join(rng.choice(letters) for _ in range(rng.randint(2, 5)))
+            pieces.add(w if rng.random() < 0.5 else "##" + w)
+        wp = swt.FastWP()
+        wp.vocab = set(pieces)
+        wp._build_trie()
+        worc = oracle.OracleWP(wp._tokens)
+        texts = []
+        for _ in range(rng.randint(1, 60)):
+            words = ["".join(rng.choice(alpha) for _ in range(rng.randint(1, 12))) for _ in range(rng.randint(0, 30))]
+            texts.append(rng.choice(["", " ", "  "]).join([""] + words) if rng.random() < 0.2 else " ".join(words))
+        try:
+            for knob in (1, 2):
+                dev.debug_knob(1, knob)
+                same_bpe(bpe, borc, texts)
+                same_wp(wp, worc, texts)
+        finally:
+            dev.debug_knob(1, 0)
+
+
 def test_device_lowercase_equals_str_lower(swt, dev, bpe, bpe_orc, corpora):
     """swt_utf8_lower + the host splice of flagged sentences == [t.lower() for t in texts], byte for byte"""
     import random
