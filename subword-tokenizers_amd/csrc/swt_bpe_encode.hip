@@ -144,9 +144,10 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
     const uint64_t *__restrict__ plan, const uint8_t *__restrict__ cls_tab, const BpeSlot *__restrict__ slots,
     uint32_t bits, const uint32_t *__restrict__ merged_of_rank, uint32_t *__restrict__ scratch,
     uint32_t *__restrict__ sent_local, uint32_t *__restrict__ tile_tok, const uint32_t *__restrict__ uslot,
-    unsigned long long *__restrict__ rec, uint32_t dbg) {
-  // uslot/rec (dedup path, every "sentence" is one unique word): the word's token run -- its place in scratch and its
-  // length -- goes straight to the word's table slot, and nobody needs a scan or a gather of this launch's output.
+    unsigned long long *__restrict__ rec, unsigned long long *__restrict__ drec, uint32_t dbg) {
+  // uslot/rec/drec (dedup path, every "sentence" s is unique word s): the word's token run -- its place in scratch and its
+  // length -- goes straight to drec[s] (dense: stays in L2 for the last pass) and length | s to the word's table slot, and
+  // nobody needs a scan or a gather of this launch's output.
   constexpr int Blocks = Cap / 64;
   __shared__ BpeLds<Cap> L;
   const int lane = threadIdx.x;
@@ -295,7 +296,10 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
         for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
           if (sent_off[s] >= g.end) break;
           sent_local[s] = run;
-          if (rec) rec[uslot[s]] = (unsigned long long)(span_base + run) | ((unsigned long long)g.ntok << 32);
+          if (rec) {
+            drec[s] = (unsigned long long)(span_base + run) | ((unsigned long long)g.ntok << 32);
+            rec[uslot[s]] = (unsigned long long)s | ((unsigned long long)g.ntok << 32);
+          }
           mine++;
         }
         for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
@@ -491,7 +495,8 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
         const uint64_t rel2 = sent_off[s + 1] - abase;
         uint32_t e2 = total;
         if (rel2 < ce && (rel2 >> 6) < nblk) e2 = L.blkpre[rel2 >> 6] + __popcll(L.vmask[rel2 >> 6] & ((1ull << (rel2 & 63)) - 1ull));
-        rec[uslot[s]] = (unsigned long long)(span_base + run + e) | ((unsigned long long)(e2 - e) << 32);
+        drec[s] = (unsigned long long)(span_base + run + e) | ((unsigned long long)(e2 - e) << 32);
+        rec[uslot[s]] = (unsigned long long)s | ((unsigned long long)(e2 - e) << 32);
       }
       mine++;
     }
@@ -540,10 +545,10 @@ static int bpe_upload(swt_bpe_table *t) {
 template <bool Packed, int Cap>
 static void launch_encode_kernel_as(swt_bpe_table *t, uint64_t n_tiles, const TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes,
                                     const uint64_t *d_sent_off, const uint8_t *d_cls, const uint32_t *d_uslot,
-                                    unsigned long long *d_rec, hipStream_t st) {
+                                    unsigned long long *d_rec, unsigned long long *d_drec, hipStream_t st) {
   hipLaunchKernelGGL((bpe_encode_kernel<Packed, Cap>), dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
                      ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, ws.scratch.as<uint32_t>(),
-                     ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, (uint32_t)debug_knob(0));
+                     ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, (uint32_t)debug_knob(0));
 }
 
 extern "C" {
@@ -608,8 +613,8 @@ void swt_bpe_table_destroy(swt_bpe_table *t) {
 // cap = staged bytes per chunk (LDS footprint ~ 20 B per byte): 512 for running text, less for the unique-word pass
 static void launch_encode_kernel(swt_bpe_table *t, uint64_t n_tiles, const TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes,
                                  const uint64_t *d_sent_off, const uint8_t *d_cls, const uint32_t *d_uslot, unsigned long long *d_rec,
-                                 hipStream_t st, int cap = kBpeCap) {
-#define SWT_ENC(P, C) launch_encode_kernel_as<P, C>(t, n_tiles, ws, d_text, n_bytes, d_sent_off, d_cls, d_uslot, d_rec, st)
+                                 unsigned long long *d_drec, hipStream_t st, int cap = kBpeCap) {
+#define SWT_ENC(P, C) launch_encode_kernel_as<P, C>(t, n_tiles, ws, d_text, n_bytes, d_sent_off, d_cls, d_uslot, d_rec, d_drec, st)
   if (t->packed) {
     if (cap == 128) SWT_ENC(true, 128); else if (cap == 256) SWT_ENC(true, 256); else SWT_ENC(true, 512);
   } else {
@@ -629,7 +634,7 @@ static int bpe_encode_direct(swt_bpe_table *t, TileWorkspace &ws, const uint8_t 
   prof_begin(st, 2);
   launch_plan(d_sent_off, n_sent, n_tiles, kBpeTile, ws.plan.as<uint64_t>(), st);
   prof_begin(st);
-  launch_encode_kernel(t, n_tiles, ws, d_text, n_bytes, d_sent_off, d_cls, nullptr, nullptr, st);
+  launch_encode_kernel(t, n_tiles, ws, d_text, n_bytes, d_sent_off, d_cls, nullptr, nullptr, nullptr, st);
   prof_end(st);
   launch_scan_gather(d_sent_off, n_sent, n_tiles, ws, d_out_ids, d_out_off, d_n_tokens, st);
   prof_end(st, 2);
@@ -657,7 +662,7 @@ static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_
   launch_plan_dev(t->dd.uoff.as<uint64_t>(), t->dd.total_ptr(), n_tiles2, tile2, t->ws2.plan.as<uint64_t>(), st);
   prof_begin(st);
   launch_encode_kernel(t, n_tiles2, t->ws2, t->dd.utext.as<uint8_t>(), n_bytes, t->dd.uoff.as<uint64_t>(), nullptr,
-                       t->dd.uslot.as<uint32_t>(), t->dd.rec_ptr(), st, (int)(2 * tile2));
+                       t->dd.uslot.as<uint32_t>(), t->dd.rec_ptr(), t->dd.drec_ptr(), st, (int)(2 * tile2));
   prof_end(st);
   rc = dedup_back(t->dd, t->ws, d_sent_off, n_sent, n_bytes, t->ws2.scratch.as<uint32_t>(), kDedupBpe, nullptr, d_out_ids, d_out_off,
                   d_n_tokens, st);

@@ -7,8 +7,10 @@
 //   front   plan, wordref (one wave per 1-KiB tile: the split, then one lane per word -- hash, table lookup with an EXACT
 //           byte compare against the slot's representative occurrence, or insert), scan, ureg (the words a tile inserted
 //           are copied to the unique-word text in tile order)
-//   (the caller encodes the unique words and leaves count:32 | place:32 of each one's token run in rec[slot])
-//   back    refcount (tokens per tile from the word records), scan, refwrite (tokens + sentence offsets)
+//   (the caller encodes the unique words: unique word u leaves count:32 | place:32 of its token run in drec[u] -- a dense
+//   array that stays in L2 -- and count:32 | u:32 in rec[its table slot])
+//   back    refcount (tokens per tile from the word records; the records are rewritten from table slots to unique indices on
+//           the way, so that the last pass gathers from the dense array only), scan, refwrite (tokens + sentence offsets)
 // Slots carry an 8-bit epoch, so the table is never cleared between calls; nothing here returns to the host.
 #pragma once
 #include "swt_common.h"
@@ -26,10 +28,11 @@ enum DedupMode {
 };
 
 struct DedupEngine {
-  DevBuf slot, rec, uslot, utext, uoff, misc, newlist, tile_new, new_local, new_blk, tile_words;
+  DevBuf slot, rec, drec, uslot, utext, uoff, misc, newlist, tile_new, new_local, new_blk, tile_words;
   uint32_t bits = 0, epoch = 0;
   void release();
-  unsigned long long *rec_ptr() const { return rec.as<unsigned long long>(); }
+  unsigned long long *rec_ptr() const { return rec.as<unsigned long long>(); }    // per table slot: count:32 | unique index:32
+  unsigned long long *drec_ptr() const { return drec.as<unsigned long long>(); }  // per unique word: count:32 | place:32
   const unsigned long long *total_ptr() const { return misc.as<unsigned long long>(); }  // unique words:32 | their bytes:32
 };
 

@@ -427,27 +427,36 @@ __global__ __launch_bounds__(64) void ureg_kernel(const uint8_t *__restrict__ te
   }
 }
 
-__device__ __forceinline__ uint32_t ref_count(uint32_t v, const unsigned long long *__restrict__ rec, uint64_t &src) {
+// a word record: a code point (BPE: the one-symbol word is its own token), or kRefSlot | table slot until the counting
+// pass has run, kRefSlot | unique index afterwards
+__device__ __forceinline__ uint32_t ref_count_dense(uint32_t v, const unsigned long long *__restrict__ drec, uint64_t &src) {
   src = 0;
   if (!(v & kRefSlot)) return 1;
-  const unsigned long long r = rec[v & ~kRefSlot];
+  const unsigned long long r = drec[v & ~kRefSlot];
   src = r & 0xFFFFFFFFull;
   return (uint32_t)(r >> 32);
 }
 
-// tokens per tile (a tile's word records are the first tile_words[t] entries behind wref[span_base])
+// tokens per tile (a tile's word records are the first tile_words[t] entries behind wref[span_base]); the records change
+// from table slots to unique-word indices here, so that refwrite_kernel gathers from the dense drec[] only
 __global__ __launch_bounds__(64) void refcount_kernel(const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
-                                                          const uint32_t *__restrict__ wref, const uint32_t *__restrict__ tile_words,
-                                                          const unsigned long long *__restrict__ rec, uint32_t *__restrict__ tile_tok) {
+                                                      uint32_t *__restrict__ wref, const uint32_t *__restrict__ tile_words,
+                                                      const unsigned long long *__restrict__ rec, uint32_t *__restrict__ tile_tok) {
   const uint64_t t = blockIdx.x;
   const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
   uint32_t total = 0;
   if (s_lo != s_hi) {
-    const uint32_t *my_rec = wref + sent_off[s_lo];
+    uint32_t *my_rec = wref + sent_off[s_lo];
     const uint32_t n_w = tile_words[t];
     for (uint32_t k = threadIdx.x; k < n_w; k += 64) {
-      uint64_t src;
-      total += ref_count(my_rec[k], rec, src);
+      const uint32_t v = my_rec[k];
+      if (v & kRefSlot) {
+        const unsigned long long r = rec[v & ~kRefSlot];  // count:32 | unique index:32
+        total += (uint32_t)(r >> 32);
+        my_rec[k] = kRefSlot | (uint32_t)r;
+      } else {
+        total += 1;
+      }
     }
     for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
   }
@@ -482,7 +491,7 @@ __global__ __launch_bounds__(64) void refwrite_kernel(const uint64_t *__restrict
       uint32_t v = 0, n = 0;
       if (j < k1) {
         v = my_rec[j];
-        n = ref_count(v, rec, src);
+        n = ref_count_dense(v, rec, src);
       }
       uint32_t x = n;
       for (int d = 1; d < 64; d <<= 1) {
@@ -515,9 +524,10 @@ __global__ __launch_bounds__(64) void refwrite_kernel(const uint64_t *__restrict
 
 // ---- FastWP back half: a sentence with a failed chunk (the reference never returns on it) yields NO tokens and a status,
 // so the counts are summed per sentence.  One kernel, two uses: Write = false leaves the tile's token total, Write = true
-// copies the tokens and writes sentence offsets and statuses.
+// copies the tokens and writes sentence offsets and statuses.  `rec` is the table's rec[] for the counting launch -- which
+// also rewrites every record from its table slot to the unique index found there -- and the dense drec[] for the writing one.
 template <bool Write>
-__device__ void wp_refs_serial(const uint64_t *__restrict__ sent_off, uint64_t s_lo, uint64_t s_hi, const uint32_t *__restrict__ my_rec,
+__device__ void wp_refs_serial(const uint64_t *__restrict__ sent_off, uint64_t s_lo, uint64_t s_hi, uint32_t *__restrict__ my_rec,
                                uint32_t n_w, const uint32_t *__restrict__ sent_word, const unsigned long long *__restrict__ rec,
                                const uint32_t *__restrict__ u_ids, uint64_t base, uint32_t *__restrict__ tile_tok_out,
                                uint32_t *__restrict__ out_ids, uint64_t *__restrict__ out_off, uint8_t *__restrict__ status) {
@@ -528,7 +538,9 @@ __device__ void wp_refs_serial(const uint64_t *__restrict__ sent_off, uint64_t s
     bool bad = false;
     uint32_t tot = 0;
     for (uint32_t w = w0; w < w1; w++) {
-      const uint32_t c = (uint32_t)(rec[my_rec[w] & ~kRefSlot] >> 32);
+      const unsigned long long r = rec[my_rec[w] & ~kRefSlot];
+      if (!Write) my_rec[w] = kRefSlot | (uint32_t)r;
+      const uint32_t c = (uint32_t)(r >> 32);
       bad |= c == kRecFailed;
       tot += c;
     }
@@ -552,7 +564,7 @@ __device__ void wp_refs_serial(const uint64_t *__restrict__ sent_off, uint64_t s
 
 template <bool Write>
 __global__ __launch_bounds__(64) void wp_refs_kernel(const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
-                                                     uint64_t n_tiles, uint64_t n_sent, const uint32_t *__restrict__ wref,
+                                                     uint64_t n_tiles, uint64_t n_sent, uint32_t *__restrict__ wref,
                                                      const uint32_t *__restrict__ tile_words, const uint32_t *__restrict__ sent_word,
                                                      const unsigned long long *__restrict__ rec, const uint32_t *__restrict__ u_ids,
                                                      const uint32_t *__restrict__ tile_base, const unsigned long long *__restrict__ blk_base,
@@ -569,7 +581,7 @@ __global__ __launch_bounds__(64) void wp_refs_kernel(const uint64_t *__restrict_
     return;
   }
   const uint64_t base = Write ? blk_base[t >> 10] + tile_base[t] : 0ull;
-  const uint32_t *my_rec = wref + sent_off[s_lo];
+  uint32_t *my_rec = wref + sent_off[s_lo];
   const uint32_t n_w = tile_words[t];
   if (n_w > (uint32_t)kDCap) {
     if (lane == 0) wp_refs_serial<Write>(sent_off, s_lo, s_hi, my_rec, n_w, sent_word, rec, u_ids, base, tile_tok + t, out_ids, out_off, status);
@@ -578,7 +590,9 @@ __global__ __launch_bounds__(64) void wp_refs_kernel(const uint64_t *__restrict_
   bool any_bad = false;
   uint32_t my_sum = 0;
   for (uint32_t k = lane; k < n_w; k += 64) {
-    const uint32_t c = (uint32_t)(rec[my_rec[k] & ~kRefSlot] >> 32);
+    const unsigned long long r = rec[my_rec[k] & ~kRefSlot];
+    if (!Write) my_rec[k] = kRefSlot | (uint32_t)r;
+    const uint32_t c = (uint32_t)(r >> 32);
     cnt[k] = c;
     any_bad |= c == kRecFailed;
     my_sum += c;
@@ -635,7 +649,7 @@ __global__ __launch_bounds__(64) void wp_refs_kernel(const uint64_t *__restrict_
 
 
 void DedupEngine::release() {
-  for (DevBuf *b : {&slot, &rec, &uslot, &utext, &uoff, &misc, &newlist, &tile_new, &new_local, &new_blk, &tile_words}) b->release();
+  for (DevBuf *b : {&slot, &rec, &drec, &uslot, &utext, &uoff, &misc, &newlist, &tile_new, &new_local, &new_blk, &tile_words}) b->release();
   bits = epoch = 0;
 }
 
@@ -670,7 +684,7 @@ int dedup_front(DedupEngine &E, TileWorkspace &ws, const uint8_t *d_text, uint64
   const uint64_t max_uniq = (mode == kDedupWp ? n_bytes : n_bytes / 2) + 2;
   const uint64_t nb_new = (n_tiles + 1023) / 1024;
   if ((rc = E.utext.reserve(n_bytes + 64)) || (rc = E.uoff.reserve((max_uniq + 2) * 8)) || (rc = E.misc.reserve(64)) ||
-      (rc = E.uslot.reserve((max_uniq + 2) * 4)) || (rc = E.newlist.reserve((max_uniq + 2) * 8)) ||
+      (rc = E.uslot.reserve((max_uniq + 2) * 4)) || (rc = E.drec.reserve((max_uniq + 2) * 8)) || (rc = E.newlist.reserve((max_uniq + 2) * 8)) ||
       (rc = E.tile_new.reserve((n_tiles + 1) * 8)) || (rc = E.new_local.reserve((n_tiles + 1) * 8)) ||
       (rc = E.tile_words.reserve((n_tiles + 1) * 4)))
     return rc;
@@ -727,9 +741,9 @@ int dedup_back(DedupEngine &E, TileWorkspace &ws, const uint64_t *d_sent_off, ui
                uint64_t *d_n_tokens, hipStream_t st) {
   const uint64_t n_tiles = tile_count(n_bytes, kDTile);
   const uint64_t nb = (n_tiles + 1023) / 1024;
-  const uint32_t *wref = ws.scratch.as<uint32_t>();
+  uint32_t *wref = ws.scratch.as<uint32_t>();
   const uint64_t *plan1 = ws.plan.as<uint64_t>();
-  const unsigned long long *rec = E.rec.as<unsigned long long>();
+  const unsigned long long *rec = E.rec.as<unsigned long long>(), *drec = E.drec.as<unsigned long long>();
   const unsigned long long *blk_base = ws.blk.as<unsigned long long>() + 1 + nb;
   if (mode == kDedupWp) {
     hipLaunchKernelGGL(wp_refs_kernel<false>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, plan1, n_tiles, n_sent, wref,
@@ -737,14 +751,14 @@ int dedup_back(DedupEngine &E, TileWorkspace &ws, const uint64_t *d_sent_off, ui
                        blk_base, d_n_tokens, ws.tile_tok.as<uint32_t>(), d_out_ids, d_out_off, d_status);
     launch_scan_only(n_tiles, ws, d_n_tokens, st);
     hipLaunchKernelGGL(wp_refs_kernel<true>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, plan1, n_tiles, n_sent, wref,
-                       E.tile_words.as<uint32_t>(), ws.sent_local.as<uint32_t>(), rec, d_unique_tokens, ws.tile_base.as<uint32_t>(),
+                       E.tile_words.as<uint32_t>(), ws.sent_local.as<uint32_t>(), drec, d_unique_tokens, ws.tile_base.as<uint32_t>(),
                        blk_base, d_n_tokens, ws.tile_tok.as<uint32_t>(), d_out_ids, d_out_off, d_status);
   } else {
     hipLaunchKernelGGL(refcount_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, plan1, wref, E.tile_words.as<uint32_t>(), rec,
                        ws.tile_tok.as<uint32_t>());
     launch_scan_only(n_tiles, ws, d_n_tokens, st);
     hipLaunchKernelGGL(refwrite_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_sent_off, plan1, n_tiles, n_sent, wref,
-                       E.tile_words.as<uint32_t>(), ws.sent_local.as<uint32_t>(), rec, d_unique_tokens, ws.tile_base.as<uint32_t>(),
+                       E.tile_words.as<uint32_t>(), ws.sent_local.as<uint32_t>(), drec, d_unique_tokens, ws.tile_base.as<uint32_t>(),
                        blk_base, d_n_tokens, d_out_ids, d_out_off);
   }
   SWT_HIP(hipGetLastError());

@@ -519,7 +519,7 @@ static int build_trie(HostTrie &H, const uint32_t *blob, const uint64_t *off, ui
 __global__ __launch_bounds__(64) void wp_urec_kernel(const uint64_t *__restrict__ uoff, const uint64_t *__restrict__ plan,
                                                      const uint32_t *__restrict__ sent_local, const uint32_t *__restrict__ tile_tok,
                                                      const uint8_t *__restrict__ status, const uint32_t *__restrict__ uslot,
-                                                     unsigned long long *__restrict__ rec) {
+                                                     unsigned long long *__restrict__ rec, unsigned long long *__restrict__ drec) {
   const uint64_t t = blockIdx.x;
   const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
   if (s_lo == s_hi) return;
@@ -528,7 +528,8 @@ __global__ __launch_bounds__(64) void wp_urec_kernel(const uint64_t *__restrict_
   for (uint64_t s = s_lo + threadIdx.x; s < s_hi; s += 64) {
     const uint32_t a = sent_local[s], b = s + 1 < s_hi ? sent_local[s + 1] : total;
     const uint32_t cnt = status[s] != SWT_WP_OK ? kRecFailed : b - a;
-    rec[uslot[s]] = (span_base + a) | ((unsigned long long)cnt << 32);
+    drec[s] = (span_base + a) | ((unsigned long long)cnt << 32);  // dense, for the last pass
+    rec[uslot[s]] = s | ((unsigned long long)cnt << 32);           // the counting pass finds the unique index here
   }
 }
 
@@ -713,7 +714,7 @@ int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, c
     prof_end(st);
     hipLaunchKernelGGL(wp_urec_kernel, dim3((unsigned)n_tiles2), dim3(64), 0, st, t->dd.uoff.as<uint64_t>(), t->ws2.plan.as<uint64_t>(),
                        t->ws2.sent_local.as<uint32_t>(), t->ws2.tile_tok.as<uint32_t>(), t->u_status.as<uint8_t>(),
-                       t->dd.uslot.as<uint32_t>(), t->dd.rec_ptr());
+                       t->dd.uslot.as<uint32_t>(), t->dd.rec_ptr(), t->dd.drec_ptr());
     rc = dedup_back(t->dd, t->ws, d_sent_off, n_sent, n_bytes, t->ws2.scratch.as<uint32_t>(), kDedupWp, d_status, d_out_ids, d_out_off,
                     d_n_tokens, st);
     prof_end(st, 2);
