@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the MI355X subword-tokenizer hot path, one JSON line on stdout.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bpe_encode|wp_encode|bpe_train|wp_train]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bpe_encode|wp_encode|bpe_train|wp_train|bpe_train_1g]
 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
 (one process per GPU; RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the environment).  Encode shards the corpus
@@ -354,6 +354,71 @@ def bench_bpe_train(args, torch, dist, rank, world, local):
     }
 
 
+def bench_bpe_train_words(args, torch, dist, rank, world, local):
+    """BASELINE configs[3]: BPE training of a 1 GiB corpus to 32k merges, in the reference's own formulation (bpe.py:73-81:
+    deduplicated word types with frequencies): 2,000,000 synthetic types, Zipf(1.05), ~110 M tokens ~ 2^30 bytes."""
+    from subword_tokenizers_amd import _native as N
+    from subword_tokenizers_amd import synth
+
+    if world != 1:
+        raise SystemExit("bpe_train_1g: single GPU here (the sharded exchange is exercised by --workload bpe_train --gpus N)")
+    N.init(local)
+    n_types, tokens = args.types or 2_000_000, None
+    sym, off, freq = synth.train_words(n_types, 1073741824, total_tokens=(args.types or 2_000_000) * 55)
+    n_merges = args.merges or 32000
+    corpus_bytes = int(((np.diff(off.astype(np.int64)) + 1) * freq.astype(np.int64)).sum())  # word + one separator, weighted
+    times = []
+    lefts = rights = counts = None
+    for it in range(args.warmup + args.steps):
+        if it == args.warmup:
+            N.profile_enable(True)
+            N.profile_read()
+        barrier_sync(torch, dist)
+        t0 = time.perf_counter()
+        tr = N.BpeTrainer.from_words(sym, off, freq)
+        lefts, rights, counts = tr.run(n_merges, N.SYM_BASE)
+        info = tr.info()
+        tr.close()
+        barrier_sync(torch, dist)
+        if it >= args.warmup:
+            times.append(time.perf_counter() - t0)
+    kernel_ms, launches = N.profile_read()
+    N.profile_enable(False)
+    from oracle import oracle as O
+
+    sample = 20
+    orc = O.OracleBPETrainer.from_words(sym, off, freq)
+    n0, w0 = orc.n_symbols, orc.n_words
+    t1 = time.perf_counter()
+    orc.run(10 ** 9, sample)
+    cpu_s = time.perf_counter() - t1
+    ids, cnt = orc.merge_ids()
+    if not (np.array_equal(np.asarray(lefts[:sample], dtype=np.uint32), ids[:, 0])
+            and np.array_equal(np.asarray(rights[:sample], dtype=np.uint32), ids[:, 1])
+            and np.array_equal(np.asarray(counts[:sample], dtype=np.uint64), cnt)):
+        raise SystemExit("PARITY FAILURE: device merges differ from the oracle on the first %d merges" % sample)
+    algo = 12.0 * n0 + 8.0 * w0
+    per_launch_s = kernel_ms / 1e3 / max(launches, 1)
+    achieved = algo / per_launch_s / 1e9 if per_launch_s else 0.0
+    elapsed = sum(times)
+    return {
+        "metric": "BPE train seconds per 1k merges", "value": round(elapsed / len(times) / max(len(lefts), 1) * 1000, 4),
+        "unit": "s/1k-merges", "higher_is_better": False, "ms_per_step": round(elapsed / len(times) * 1e3, 3), "dtype": "u32",
+        "config": {"workload": "configs[3] shape: BPE train of %d word types / %d tokens (~%.2f GB of text) to %d merges, "
+                               "deduplicated-words-with-frequencies form, %d symbols" % (w0, int(freq.sum()), corpus_bytes / 1e9, len(lefts), n0),
+                   "parallelism": "single GPU"},
+        "scaling": "strong",
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "apply_kernel",
+                     "kernel_us": round(per_launch_s * 1e6, 2), "algorithmic_bytes_per_launch": int(algo),
+                     "launches_timed": int(launches),
+                     "note": "algorithmic bytes are those of the reference's full-rescan formulation at N_0"},
+        "cpu_baseline": {"value": round(cpu_s / sample * 1000, 3), "unit": "s/1k-merges", "cores": 1, "kind": "port",
+                         "sample": "first %d merges of the same run through oracle/swt_oracle.c (full recount per merge)" % sample},
+        "final_symbols": info["n_symbols"],
+    }
+
+
 def bench_wp_train(args, torch, dist, rank, world, local):
     """NaiveWP.train (wordpiece.py:29-103) on S85k, `--max-vocab` default = initial symbols + 2000"""
     from subword_tokenizers_amd import _native as N
@@ -422,11 +487,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="bpe_encode", choices=["bpe_encode", "wp_encode", "bpe_train", "wp_train"])
+    ap.add_argument("--workload", default="bpe_encode", choices=["bpe_encode", "wp_encode", "bpe_train", "wp_train", "bpe_train_1g"])
     ap.add_argument("--sentences", type=int, default=None, help="wp_encode: sentences per GPU (default 1,000,000)")
     ap.add_argument("--max-vocab", type=int, default=None, help="bpe_train: target vocabulary (default 8000)")
+    ap.add_argument("--types", type=int, default=None, help="bpe_train_1g: word types (default 2,000,000)")
+    ap.add_argument("--merges", type=int, default=None, help="bpe_train_1g: merges (default 32,000)")
     args = ap.parse_args()
-    defaults = {"bpe_encode": (200, 20), "wp_encode": (20, 3), "bpe_train": (2, 1), "wp_train": (2, 1)}[args.workload]
+    defaults = {"bpe_encode": (200, 20), "wp_encode": (20, 3), "bpe_train": (2, 1), "wp_train": (2, 1), "bpe_train_1g": (1, 0)}[args.workload]
     if args.steps is None:
         args.steps = defaults[0]
     if args.warmup is None:
@@ -434,7 +501,7 @@ def main():
 
     torch, dist, rank, world, local = dist_setup(args.gpus)
     fn = {"bpe_encode": bench_bpe_encode, "wp_encode": bench_wp_encode, "bpe_train": bench_bpe_train,
-          "wp_train": bench_wp_train}[args.workload]
+          "wp_train": bench_wp_train, "bpe_train_1g": bench_bpe_train_words}[args.workload]
     res = fn(args, torch, dist, rank, world, local)
     line = {"metric": res.pop("metric"), "value": res.pop("value"), "unit": res.pop("unit"), "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"),

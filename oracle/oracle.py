@@ -54,6 +54,7 @@ def lib():
             "orc_bpe_tokenize_batch": (C.c_uint64, [C.c_void_p, _u32p, _u64p, C.c_uint64, _u32p, _u64p]),
             "orc_train_new": (C.c_void_p, [_u32p, _u64p, C.c_uint64]),
             "orc_wptrain_new": (C.c_void_p, [_u32p, _u64p, C.c_uint64]),
+            "orc_train_new_words": (C.c_void_p, [_u32p, _u64p, _u32p, C.c_uint64]),
             "orc_wp_score_bits": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64]),
             "orc_train_free": (None, [C.c_void_p]),
             "orc_train_n_words": (C.c_uint64, [C.c_void_p]),
@@ -193,6 +194,16 @@ class OracleBPETrainer:
     def __init__(self, corpus):
         blob, off = pack([t.lower() for t in corpus])
         self._h = lib().orc_train_new(_p32(blob), _p64(off), len(corpus))
+
+    @classmethod
+    def from_words(cls, syms, word_off, freq):
+        """the state after bpe.py:73-81 given directly: unique words (code points, CSR) with their frequencies"""
+        self = cls.__new__(cls)
+        syms = np.ascontiguousarray(syms, dtype=np.uint32)
+        word_off = np.ascontiguousarray(word_off, dtype=np.uint64)
+        freq = np.ascontiguousarray(freq, dtype=np.uint32)
+        self._h = lib().orc_train_new_words(_p32(syms), _p64(word_off), _p32(freq), int(word_off.size - 1))
+        return self
 
     def __del__(self):
         if getattr(self, "_h", None):

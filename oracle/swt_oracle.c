@@ -376,6 +376,25 @@ static orc_train *train_new(const uint32_t *text, const uint64_t *sent_off, uint
   return t;
 }
 orc_train *orc_train_new(const uint32_t *text, const uint64_t *sent_off, uint64_t n_sent) { return train_new(text, sent_off, n_sent, 0); }
+/* the state after bpe.py:73-81 given directly: unique words as code points (CSR) with their frequencies */
+orc_train *orc_train_new_words(const uint32_t *syms, const uint64_t *word_off, const uint32_t *freq, uint64_t n_words) {
+  orc_train *t = (orc_train *)calloc(1, sizeof *t);
+  st_init(&t->st);
+  map_init(&t->pairs, 1 << 16);
+  map_init(&t->sfreq, 1 << 12);
+  uint8_t *seen = (uint8_t *)calloc(0x110000, 1);
+  v64_push(&t->woff, 0);
+  for (uint64_t w = 0; w < n_words; w++) {
+    for (uint64_t q = word_off[w]; q < word_off[w + 1]; q++) {
+      v32_push(&t->syms, syms[q]);
+      if (syms[q] < 0x110000u && !seen[syms[q]]) { seen[syms[q]] = 1; t->vocab_size++; } /* bpe.py:75 */
+    }
+    v64_push(&t->woff, t->syms.n);
+    v32_push(&t->freq, freq[w]);
+  }
+  free(seen);
+  return t;
+}
 orc_train *orc_wptrain_new(const uint32_t *text, const uint64_t *sent_off, uint64_t n_sent) { return train_new(text, sent_off, n_sent, 1); }
 
 /* Python's int / int (wordpiece.py:86): the quotient of two exact integers, correctly rounded (half to even) to a

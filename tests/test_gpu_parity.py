@@ -607,6 +607,25 @@ def test_train_create_words_and_exhaustion(dev, oracle):
     assert list(np.diff(dw)) == [1, 1]
 
 
+def test_train_config3_shape_words_with_frequencies(dev, oracle):
+    """BASELINE configs[3] in shape (reference formulation: deduplicated word types with Zipf frequencies, scaled to 200 k types
+    / 20 M tokens): the first 300 merges, pairs and counts, against the oracle's full recount"""
+    from subword_tokenizers_amd import synth
+    sym, off, freq = synth.train_words(200000, 1073741824, total_tokens=20_000_000)
+    tr = dev.BpeTrainer.from_words(sym, off, freq)
+    lefts, rights, counts = tr.run(300, dev.SYM_BASE)
+    orc = oracle.OracleBPETrainer.from_words(sym, off, freq)
+    orc.run(10 ** 9, 300)
+    ids, cnt = orc.merge_ids()
+    assert len(lefts) == 300 == len(ids)
+    assert np.array_equal(np.asarray(lefts, dtype=np.uint32), ids[:, 0]) and np.array_equal(np.asarray(rights, dtype=np.uint32), ids[:, 1])
+    assert np.array_equal(np.asarray(counts, dtype=np.uint64), cnt)
+    got_sym, got_off, got_freq = tr.export()
+    want_sym, want_off, want_freq = orc.export()
+    assert np.array_equal(got_off, want_off) and np.array_equal(got_sym, want_sym) and np.array_equal(got_freq, want_freq)
+    tr.close()
+
+
 def _wp_order_cases(golden, ref_dir):
     import json
     for c in golden("wp_train_order.json"):
