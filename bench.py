@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the MI355X subword-tokenizer hot path, one JSON line on stdout.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bpe_encode|wp_encode|bpe_train|wp_train|bpe_train_1g]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bpe_encode|wp_encode|bpe_train|wp_train|bpe_train_1g|mixed_encode]
 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
 (one process per GPU; RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the environment).  Encode shards the corpus
@@ -354,6 +354,92 @@ def bench_bpe_train(args, torch, dist, rank, world, local):
     }
 
 
+def bench_mixed_encode(args, torch, dist, rank, world, local):
+    """BASELINE configs[4] per GPU: 10 M sentences over 8 GPUs = 1.25 M per GPU, half through FastBPE (8,000 merges) and half
+    through FastWP (V30k); corpus-sharded, no collective.  One step = one FastBPE call + one FastWP call."""
+    from subword_tokenizers_amd import _native as N
+    from subword_tokenizers_amd import synth, tokenizers
+
+    N.init(local)
+    n_each = args.sentences or 625000
+    bpe = tokenizers.FastBPE()
+    bpe.merges_list = list(synth.pretrained_merges()[:8000])
+    bpe._build_table()
+    wp = tokenizers.FastWP()
+    wp.vocab = set(synth.v30k())
+    wp._build_trie()
+    b_sents = synth.sentences(n_each, 10000000 + rank)
+    b_text, b_off = N.pack_utf8([s.lower() for s in b_sents])
+    w_text, w_off = synth.wp_corpus(n_each, seed=20000000 + rank, vocab=synth.v30k())
+    bufs = []
+    for text, off in ((b_text, b_off), (w_text, w_off)):
+        nb = int(text.size)
+        bufs.append((to_dev(torch, text), to_dev(torch, off.view(np.int64)), torch.empty(nb + 64, dtype=torch.int32, device="cuda"),
+                     torch.empty(n_each + 1, dtype=torch.int64, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda"), nb))
+    d_status = torch.empty(n_each + 8, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        t, o, out, oo, nt, nb = bufs[0]
+        bpe._table.encode_dev(t.data_ptr(), nb, o.data_ptr(), n_each, out.data_ptr(), oo.data_ptr(), nt.data_ptr(), 0, stream)
+        t, o, out, oo, nt, nb = bufs[1]
+        wp._trie.encode_dev(t.data_ptr(), nb, o.data_ptr(), n_each, out.data_ptr(), oo.data_ptr(), d_status.data_ptr(), nt.data_ptr(), stream)
+
+    for _ in range(args.warmup):
+        step()
+    barrier_sync(torch, dist)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier_sync(torch, dist)
+    elapsed = max_over_ranks(torch, dist, time.perf_counter() - t0)
+    N.profile_enable(2)
+    N.profile_read()
+    for _ in range(min(max(args.steps, 1), 5)):
+        step()
+    torch.cuda.synchronize()
+    call_ms, calls = N.profile_read()
+    N.profile_enable(False)
+    n_bytes = bufs[0][5] + bufs[1][5]
+    total_bytes = sum_over_ranks(torch, dist, float(n_bytes))
+    roof = cpu = None
+    if rank == 0:
+        from oracle import oracle as O
+
+        sub = min(n_each, 10000)
+        borc, worc = O.OracleBPE(bpe.merges_list), O.OracleWP(wp._tokens)
+        t1 = time.perf_counter()
+        bo_ids, bo_off = borc.tokenize_batch_ids(b_sents[:sub])
+        wo_ids, wo_off, wo_st = worc.tokenize_batch_ids(synth.unpack(w_text, w_off, 0, sub))
+        cpu_s = time.perf_counter() - t1
+        for (t, o, out, oo, nt, nb), (ids, off) in zip(bufs, ((bo_ids, bo_off), (wo_ids, wo_off))):
+            offs = oo[:sub + 1].cpu().numpy().view(np.uint64)
+            got = out[:int(offs[-1])].cpu().numpy().view(np.uint32)
+            if not (np.array_equal(got, ids) and np.array_equal(offs, off)):
+                raise SystemExit("PARITY FAILURE: device ids differ from the oracle on the benchmark subsample")
+        if not np.array_equal(d_status[:sub].cpu().numpy(), wo_st):
+            raise SystemExit("PARITY FAILURE: FastWP statuses differ from the oracle")
+        n_tok = int(bufs[0][4].item()) + int(bufs[1][4].item())
+        algo = n_bytes + 4.0 * n_tok + 8.0 * 2 * (n_each + 1)
+        per_step_s = call_ms / 1e3 / max(calls // 2, 1)
+        achieved = algo / per_step_s / 1e9
+        roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None, "kernel": "one FastBPE call + one FastWP call (both dedup pipelines), first kernel .. last kernel of each",
+                "kernel_us": round(per_step_s * 1e6, 2), "algorithmic_bytes_per_launch": int(algo), "launches_timed": int(calls // 2)}
+        sub_bytes = int(b_off[sub]) + int(w_off[sub])
+        cpu = {"value": round(sub_bytes / 1e6 / cpu_s, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+               "sample": "first %d sentences of each half (%.1f MB) through oracle/swt_oracle.c, lower() + packing included" % (sub, sub_bytes / 1e6)}
+    return {
+        "metric": "mixed FastBPE + FastWP encode throughput (input MB/s, tokens bit-exact)",
+        "value": round(total_bytes * args.steps / 1e6 / elapsed, 1), "unit": "MB/s", "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "dtype": "u32",
+        "config": {"workload": "configs[4] per GPU: %d sentences through FastBPE (8,000 merges, %.1f MB) + %d through FastWP (V30k, %.1f MB)"
+                               % (n_each, bufs[0][5] / 1e6, n_each, bufs[1][5] / 1e6),
+                   "sentences_per_gpu": 2 * n_each, "bytes_per_gpu": n_bytes, "parallelism": "corpus-sharded x%d, no collective" % world},
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+
+
 def bench_bpe_train_words(args, torch, dist, rank, world, local):
     """BASELINE configs[3]: BPE training of a 1 GiB corpus to 32k merges, in the reference's own formulation (bpe.py:73-81:
     deduplicated word types with frequencies): 2,000,000 synthetic types, Zipf(1.05), ~110 M tokens ~ 2^30 bytes."""
@@ -487,13 +573,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="bpe_encode", choices=["bpe_encode", "wp_encode", "bpe_train", "wp_train", "bpe_train_1g"])
-    ap.add_argument("--sentences", type=int, default=None, help="wp_encode: sentences per GPU (default 1,000,000)")
+    ap.add_argument("--workload", default="bpe_encode", choices=["bpe_encode", "wp_encode", "bpe_train", "wp_train", "bpe_train_1g", "mixed_encode"])
+    ap.add_argument("--sentences", type=int, default=None, help="wp_encode: sentences per GPU (default 1,000,000); mixed_encode: per half (default 625,000)")
     ap.add_argument("--max-vocab", type=int, default=None, help="bpe_train: target vocabulary (default 8000)")
     ap.add_argument("--types", type=int, default=None, help="bpe_train_1g: word types (default 2,000,000)")
     ap.add_argument("--merges", type=int, default=None, help="bpe_train_1g: merges (default 32,000)")
     args = ap.parse_args()
-    defaults = {"bpe_encode": (200, 20), "wp_encode": (20, 3), "bpe_train": (2, 1), "wp_train": (2, 1), "bpe_train_1g": (1, 0)}[args.workload]
+    defaults = {"bpe_encode": (200, 20), "wp_encode": (20, 3), "bpe_train": (2, 1), "wp_train": (2, 1), "bpe_train_1g": (1, 0), "mixed_encode": (10, 2)}[args.workload]
     if args.steps is None:
         args.steps = defaults[0]
     if args.warmup is None:
@@ -501,7 +587,7 @@ def main():
 
     torch, dist, rank, world, local = dist_setup(args.gpus)
     fn = {"bpe_encode": bench_bpe_encode, "wp_encode": bench_wp_encode, "bpe_train": bench_bpe_train,
-          "wp_train": bench_wp_train, "bpe_train_1g": bench_bpe_train_words}[args.workload]
+          "wp_train": bench_wp_train, "bpe_train_1g": bench_bpe_train_words, "mixed_encode": bench_mixed_encode}[args.workload]
     res = fn(args, torch, dist, rank, world, local)
     line = {"metric": res.pop("metric"), "value": res.pop("value"), "unit": res.pop("unit"), "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"),
