@@ -656,10 +656,10 @@ static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_
   if (n_bytes > kDedupMaxBytes) return 1;
   if ((rc = t->ws2.reserve(n_bytes, n_bytes / 2 + 2, n_tiles2))) return rc;
   prof_begin(st, 2);
-  if ((rc = dedup_front(t->dd, t->ws, d_text, n_bytes, d_sent_off, n_sent, d_cls, kDedupBpe, st))) return rc;
+  if ((rc = dedup_front(t->dd, t->ws, d_text, n_bytes, d_sent_off, n_sent, d_cls, kDedupBpe, st, t->ws2.plan.as<uint64_t>(), n_tiles2, tile2)))
+    return rc;
   // encode the unique words once (raw-word mode: each one is a "sentence"); their token runs stay in ws2.scratch and
   // phase F of the kernel leaves count | place in rec[slot]
-  launch_plan_dev(t->dd.uoff.as<uint64_t>(), t->dd.total_ptr(), n_tiles2, tile2, t->ws2.plan.as<uint64_t>(), st);
   prof_begin(st);
   launch_encode_kernel(t, n_tiles2, t->ws2, t->dd.utext.as<uint8_t>(), n_bytes, t->dd.uoff.as<uint64_t>(), nullptr,
                        t->dd.uslot.as<uint32_t>(), t->dd.rec_ptr(), t->dd.drec_ptr(), st, (int)(2 * tile2));

@@ -38,9 +38,11 @@ struct DedupEngine {
 
 // Front half.  On return (stream order): ws.scratch = dense word records per tile, ws.sent_local = words of the tile before
 // each sentence, E.tile_words, E.utext / E.uoff / E.uslot = the unique words, E.misc[0] = their number and bytes.
+// d_plan2[0 .. n_tiles2]: the tile plan of the caller's launch over the unique words (first unique word at or after byte
+// tt * tile2, with tile2 = the smallest size >= tile2_min that covers the unique bytes with n_tiles2 tiles).
 // Returns 1 when the batch does not fit this path (the caller encodes directly).
 int dedup_front(DedupEngine &E, TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off, uint64_t n_sent,
-                const uint8_t *d_cls, DedupMode mode, hipStream_t st);
+                const uint8_t *d_cls, DedupMode mode, hipStream_t st, uint64_t *d_plan2, uint64_t n_tiles2, uint32_t tile2_min);
 
 // Back half.  d_unique_tokens = the buffer the rec[] places point into.  kDedupWp also writes d_status per sentence.
 int dedup_back(DedupEngine &E, TileWorkspace &ws, const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_bytes,

@@ -394,11 +394,24 @@ __global__ __launch_bounds__(64) void ureg_kernel(const uint8_t *__restrict__ te
                                                       const unsigned long long *__restrict__ new_local,
                                                       const unsigned long long *__restrict__ new_blk_base,
                                                       const unsigned long long *__restrict__ d_total, uint32_t *__restrict__ uslot,
-                                                      uint64_t *__restrict__ uoff, uint8_t *__restrict__ utext) {
+                                                      uint64_t *__restrict__ uoff, uint8_t *__restrict__ utext,
+                                                      uint64_t *__restrict__ plan2, uint64_t n_tiles2, uint32_t tile2_min) {
   const int lane = threadIdx.x;
   const uint64_t t = blockIdx.x;
   const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
-  if (t == 0 && lane == 0) uoff[*d_total >> 32] = *d_total & 0xFFFFFFFFull;  // the end of the last unique word
+  // The plan of the launch that encodes the unique words (plan2[tt] = first unique word that starts at or after byte
+  // tt * tile2) is written here too: that launch has a fixed n_tiles2 workgroups, so the tile size follows from the
+  // number of unique bytes, which only the device knows.  A boundary inside (start, end] of a word belongs to the word
+  // after it; boundary 0 and the boundaries behind the text are written by workgroup 0.
+  const uint64_t n_uniq = *d_total >> 32, ubytes = *d_total & 0xFFFFFFFFull;
+  uint64_t tile2 = n_tiles2 ? (ubytes + n_tiles2 - 1) / n_tiles2 : 0;
+  if (tile2 < tile2_min) tile2 = tile2_min;
+  if (t == 0) {
+    if (lane == 0) uoff[n_uniq] = ubytes;  // the end of the last unique word
+    if (plan2)
+      for (uint64_t tt = lane; tt <= n_tiles2; tt += 64)
+        if (tt == 0 || tt * tile2 > ubytes) plan2[tt] = tt == 0 ? 0ull : n_uniq;
+  }
   if (s_lo == s_hi) return;
   const uint32_t n_new = (uint32_t)(D.tile_new[t] >> 32);
   if (!n_new) return;
@@ -422,6 +435,8 @@ __global__ __launch_bounds__(64) void ureg_kernel(const uint8_t *__restrict__ te
       uoff[u0 + k] = bo;
       uslot[u0 + k] = idx;
       for (uint32_t i = 0; i < len; i++) utext[bo + i] = text[pos + i];
+      if (plan2)
+        for (uint64_t T = (bo / tile2 + 1) * tile2; T <= bo + len; T += tile2) plan2[T / tile2] = u0 + k + 1;
     }
     b0 += __shfl(x, 63);
   }
@@ -654,7 +669,7 @@ void DedupEngine::release() {
 }
 
 int dedup_front(DedupEngine &E, TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off, uint64_t n_sent,
-                const uint8_t *d_cls, DedupMode mode, hipStream_t st) {
+                const uint8_t *d_cls, DedupMode mode, hipStream_t st, uint64_t *d_plan2, uint64_t n_tiles2, uint32_t tile2_min) {
   int rc;
   if (n_bytes > kDedupMaxBytes) return 1;
   const uint64_t n_tiles = tile_count(n_bytes, kDTile);
@@ -720,10 +735,12 @@ int dedup_front(DedupEngine &E, TileWorkspace &ws, const uint8_t *d_text, uint64
   launch_scan_u64(n_tiles, D.tile_new, new_local, new_blk, reinterpret_cast<uint64_t *>(d_misc), st);
   if (mode == kDedupWp)
     hipLaunchKernelGGL(ureg_kernel<kDedupWp>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, d_sent_off, plan1, D, new_local,
-                       new_blk + 1 + nb_new, d_misc, E.uslot.as<uint32_t>(), E.uoff.as<uint64_t>(), E.utext.as<uint8_t>());
+                       new_blk + 1 + nb_new, d_misc, E.uslot.as<uint32_t>(), E.uoff.as<uint64_t>(), E.utext.as<uint8_t>(), d_plan2,
+                       n_tiles2, tile2_min);
   else
     hipLaunchKernelGGL(ureg_kernel<kDedupBpe>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, d_sent_off, plan1, D, new_local,
-                       new_blk + 1 + nb_new, d_misc, E.uslot.as<uint32_t>(), E.uoff.as<uint64_t>(), E.utext.as<uint8_t>());
+                       new_blk + 1 + nb_new, d_misc, E.uslot.as<uint32_t>(), E.uoff.as<uint64_t>(), E.utext.as<uint8_t>(), d_plan2,
+                       n_tiles2, tile2_min);
   SWT_HIP(hipGetLastError());
   if (D.diag) {
     unsigned long long h[3] = {0, 0, 0};

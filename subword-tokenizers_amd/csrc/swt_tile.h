@@ -28,10 +28,6 @@ inline uint64_t tile_count(uint64_t n_bytes, uint32_t tile) { return n_bytes ? (
 
 // Host launchers of the skeleton's own kernels (defined in swt_tile.hip).
 void launch_plan(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, uint32_t tile, uint64_t *d_plan, hipStream_t st);
-// sizes on the device: *d_total = sentences:32 | bytes:32; plan[0 .. n_tiles_max] is written for the smallest tile size
-// >= tile_min that needs at most n_tiles_max tiles; the tiles behind the real ones are empty
-void launch_plan_dev(const uint64_t *d_sent_off, const unsigned long long *d_total, uint64_t n_tiles_max, uint32_t tile_min,
-                     uint64_t *d_plan, hipStream_t st);
 void launch_scan_only(uint64_t n_tiles, const TileWorkspace &ws, uint64_t *d_n_tokens, hipStream_t st);
 // the same scan over 64-bit values: d_local[i] = exclusive sum inside i's group of 1024, blk = [ticket (zero), totals[nb],
 // bases[nb]] with nb = ceil(n / 1024); global exclusive sum of i = blk[1 + nb + (i >> 10)] + d_local[i]

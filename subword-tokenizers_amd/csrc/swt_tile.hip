@@ -18,29 +18,6 @@ __global__ void plan_kernel(const uint64_t *__restrict__ sent_off, uint64_t n_se
   plan[t] = lo;
 }
 
-// The same plan when the number of sentences and bytes is only known on the device (*d_total = sentences:32 | bytes:32).
-// The launch that follows has a FIXED number of workgroups (n_tiles_max), so the tile size is chosen here: the smallest
-// one >= tile_min that covers the bytes with at most n_tiles_max tiles; the tiles behind the real ones come out empty
-// (plan[t] = n_sent).
-__global__ void plan_dev_kernel(const uint64_t *__restrict__ sent_off, const unsigned long long *__restrict__ d_total,
-                                uint64_t n_tiles_max, uint32_t tile_min, uint64_t *__restrict__ plan) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t > n_tiles_max) return;
-  const unsigned long long tot = *d_total;
-  const uint64_t n_sent = tot >> 32, n_bytes = tot & 0xFFFFFFFFull;
-  uint64_t tile = (n_bytes + n_tiles_max - 1) / n_tiles_max;
-  if (tile < tile_min) tile = tile_min;
-  const uint64_t n_tiles = n_bytes ? (n_bytes + tile - 1) / tile : 1;
-  if (t >= n_tiles) { plan[t] = n_sent; return; }
-  const uint64_t target = t * tile;
-  uint64_t lo = 0, hi = n_sent;
-  while (lo < hi) {
-    const uint64_t mid = (lo + hi) >> 1;
-    if (sent_off[mid] < target) lo = mid + 1; else hi = mid;
-  }
-  plan[t] = lo;
-}
-
 // Exclusive scan of the tile totals, one launch: every workgroup scans its 1024 tiles locally and publishes its total;
 // the last one to arrive (ticket) scans the workgroup totals.  Global base of tile t = blk_base[t >> 10] + tile_base[t].
 template <class T>
@@ -139,12 +116,6 @@ void TileWorkspace::release() {
 
 void launch_plan(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, uint32_t tile, uint64_t *d_plan, hipStream_t st) {
   hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n_tiles + 1 + 255) / 256)), dim3(256), 0, st, d_sent_off, n_sent, n_tiles, tile, d_plan);
-}
-
-void launch_plan_dev(const uint64_t *d_sent_off, const unsigned long long *d_total, uint64_t n_tiles_max, uint32_t tile_min,
-                     uint64_t *d_plan, hipStream_t st) {
-  hipLaunchKernelGGL(plan_dev_kernel, dim3((unsigned)((n_tiles_max + 1 + 255) / 256)), dim3(256), 0, st, d_sent_off, d_total,
-                     n_tiles_max, tile_min, d_plan);
 }
 
 void launch_scan_only(uint64_t n_tiles, const TileWorkspace &ws, uint64_t *d_n_tokens, hipStream_t st) {

@@ -705,8 +705,9 @@ int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, c
     if (n_tiles2 > kWpUMaxTiles) n_tiles2 = kWpUMaxTiles;
     if ((rc = t->ws2.reserve(n_bytes, max_uniq, n_tiles2)) || (rc = t->u_status.reserve(max_uniq + 2))) return rc;
     prof_begin(st, 2);
-    if ((rc = dedup_front(t->dd, t->ws, d_text, n_bytes, d_sent_off, n_sent, d_cls, kDedupWp, st))) return rc;
-    launch_plan_dev(t->dd.uoff.as<uint64_t>(), t->dd.total_ptr(), n_tiles2, kWpUTile, t->ws2.plan.as<uint64_t>(), st);
+    if ((rc = dedup_front(t->dd, t->ws, d_text, n_bytes, d_sent_off, n_sent, d_cls, kDedupWp, st, t->ws2.plan.as<uint64_t>(), n_tiles2,
+                          kWpUTile)))
+      return rc;
     prof_begin(st);
     hipLaunchKernelGGL(wp_encode_kernel, dim3((unsigned)n_tiles2), dim3(64), 0, st, t->dd.utext.as<uint8_t>(), n_bytes,
                        t->dd.uoff.as<uint64_t>(), t->ws2.plan.as<uint64_t>(), d_cls, T, t->ws2.scratch.as<uint32_t>(),
