@@ -15,7 +15,7 @@ A "step" is one pass of the whole path (plan + encode + scan + gather kernels) o
 
   roofline      timed with HIP events on the launch stream inside the library (swt_profile_*); achieved = algorithmic
                 bytes / time; algorithmic bytes per call = input bytes + 4 B per output token + 8 B per sentence
-                offset.  FastBPE encode is a pipeline of nine short kernels: its line is that
+                offset.  FastBPE encode is a pipeline of eight short kernels: its line is that
                 of the whole call (first kernel start .. last kernel end) with the longest kernel beside it; the
                 other workloads time their dominant kernel.
   cpu_baseline  the C oracle (oracle/, a port of the reference's algorithm) on one host core of this box, on the
@@ -155,7 +155,7 @@ def bench_bpe_encode(args, torch, dist, rank, world, local):
         cpu_s = time.perf_counter() - t1
         if not (np.array_equal(ids, oids) and np.array_equal(offs, ooff)):
             raise SystemExit("PARITY FAILURE: device ids differ from the oracle on the benchmark batch")
-        # Since the word-level dedup the batch passes through nine short kernels and none of them touches all of the
+        # Since the word-level dedup the batch passes through eight short kernels and none of them touches all of the
         # algorithmic bytes, so the roofline line is that of the whole call: algorithmic bytes of the batch over the
         # time from the first kernel's start to the last kernel's end (HIP events on the launch stream).  The longest
         # single kernel (bpe_encode_kernel over the unique words) is reported beside it.
@@ -164,8 +164,7 @@ def bench_bpe_encode(args, torch, dist, rank, world, local):
         achieved = algo / per_call_s / 1e9
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_from_profile("bpe_encode"),
-                "kernel": "dedup pipeline: plan, wordref, scan, ureg, plan_dev, bpe_encode (unique words), "
-                          "refcount, scan, refwrite",
+                "kernel": "dedup pipeline: plan, wordref, scan, ureg, bpe_encode (unique words), refcount, scan, refwrite",
                 "kernel_us": round(per_call_s * 1e6, 2),
                 "algorithmic_bytes_per_launch": int(algo), "launches_timed": int(calls),
                 "dominant_kernel": {"name": "bpe_encode_kernel", "us": round(kernel_ms * 1e3 / max(launches, 1), 2),
@@ -248,7 +247,7 @@ def bench_wp_encode(args, torch, dist, rank, world, local):
         st = d_status[:sub].cpu().numpy()
         if not (np.array_equal(ids, oids) and np.array_equal(offs, ooff) and np.array_equal(st, ost)):
             raise SystemExit("PARITY FAILURE: device ids differ from the oracle on the benchmark subsample")
-        # With the word-level dedup the call is a pipeline (plan, wordref, scan, ureg, plan_dev, wp_encode over the unique
+        # With the word-level dedup the call is a pipeline (plan, wordref, scan, ureg, wp_encode over the unique
         # chunks, urec, refs-count, scan, refs-write): the roofline line is that of the whole call, the longest kernel
         # (wordref: split + table lookup of every chunk) is reported beside it.  Without dedup (refs == 0: a vocabulary
         # with whitespace inside tokens) the dominant kernel is wp_encode_kernel itself.

@@ -642,8 +642,8 @@ static int bpe_encode_direct(swt_bpe_table *t, TileWorkspace &ws, const uint8_t 
   return SWT_OK;
 }
 
-// The dedup path (swt_dedup.h): nine launches, no host round trip -- the number of unique words stays on the device, so
-// the unique-word encode has a fixed number of workgroups and its tile size follows on the device (plan_dev_kernel).
+// The dedup path (swt_dedup.h): eight launches, no host round trip -- the number of unique words stays on the device, so
+// the unique-word encode has a fixed number of workgroups and its tile size follows on the device (ureg_kernel writes its plan).
 // Returns 1 when the batch is too large for the 32-bit fields of this path (the caller takes the direct path).
 constexpr int kUTile = 128;            // smallest tile of the unique-word pass (chunk = 2 such tiles); measured: 64 -> 84 us, 128 -> 72 us, 256 -> 88 us
 constexpr uint64_t kUMaxTiles = 8192;  // its launch size: 256 CUs x 32 single-wave workgroups

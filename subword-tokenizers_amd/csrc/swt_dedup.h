@@ -18,7 +18,7 @@
 
 namespace swt {
 
-constexpr uint64_t kDedupMinBytes = 1u << 20;   // below ~0.9 MB the nine launches cost more than the merge rounds they save (measured)
+constexpr uint64_t kDedupMinBytes = 1u << 20;   // below ~0.9 MB the extra launches cost more than the merge rounds they save (measured)
 constexpr uint64_t kDedupMaxBytes = 1ull << 30;  // 32-bit fields of the records
 constexpr uint32_t kRecFailed = 0xFFFFFFFFu;     // count field of rec[]: the word cannot be encoded (FastWP non-termination)
 
