@@ -31,7 +31,7 @@
 namespace swt {
 
 constexpr int kTrainThreads = 256;
-constexpr int kArgBlocks = 512;
+constexpr int kArgBlocks = 1024;
 constexpr uint32_t kMaxRunSteps = 512;
 constexpr uint32_t kRunBatch = 256;
 
@@ -173,13 +173,31 @@ __global__ __launch_bounds__(256) void argmax_kernel(const unsigned long long *_
   __shared__ unsigned long long sm[4], sc[4], sk[4];
   __shared__ bool is_last;
   unsigned long long m = 0, c = 0, k = kEmptyKey;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
-    const long long v = cnt[i];
-    if (v > 0 && (sfreq || (unsigned long long)v >= m)) {
-      const unsigned long long key = keys[i];
-      if (key != kEmptyKey) {
-        const unsigned long long val = pair_value(key, v, sfreq);
-        if (val >= m) arg_combine(m, c, k, val, 1ull, key);
+  // the counts are streamed two per load, four loads in flight per lane (cap is a power of two >= 1024); a key is only
+  // fetched for a count that can still win
+  const uint64_t n2 = cap >> 1;
+  const longlong2 *cnt2 = reinterpret_cast<const longlong2 *>(cnt);
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n2; i0 += 4 * stride) {
+    longlong2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint64_t i = i0 + u * stride;
+      v[u] = i < n2 ? cnt2[i] : make_longlong2(0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint64_t i = i0 + u * stride;
+      const long long vv[2] = {v[u].x, v[u].y};
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        if (vv[h] > 0 && (sfreq || (unsigned long long)vv[h] >= m)) {
+          const unsigned long long key = keys[2 * i + h];
+          if (key != kEmptyKey) {
+            const unsigned long long val = pair_value(key, vv[h], sfreq);
+            if (val >= m) arg_combine(m, c, k, val, 1ull, key);
+          }
+        }
       }
     }
   }
@@ -723,7 +741,7 @@ int swt_bpe_train_best(swt_bpe_trainer *t, uint32_t *left, uint32_t *right, uint
   int rc = ensure_device();
   if (rc) return rc;
   const uint64_t cap = 1ull << t->T.bits;
-  const unsigned g = grid_for(cap, 256 * 8, kArgBlocks);
+  const unsigned g = grid_for(cap, 256 * 8, kArgBlocks);  // 8 counts per thread: 4 double loads
   unsigned int *ticket = reinterpret_cast<unsigned int *>(t->d_parts + kArgBlocks);
   hipLaunchKernelGGL(argmax_kernel, dim3(g), dim3(256), 0, 0, t->T.keys, t->T.cnt, cap, t->d_parts, ticket, t->d_res,
                      (const long long *)t->d_sfreq);
@@ -825,7 +843,7 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
     if (t->h_res.max_count == 0 || by_sym < per) per = by_sym;
     if ((rc = ensure_room(t, per * k))) return rc;
     const uint64_t cap = 1ull << t->T.bits;
-    const unsigned g = grid_for(cap, 256 * 8, kArgBlocks);
+    const unsigned g = grid_for(cap, 256 * 8, kArgBlocks);  // 8 counts per thread: 4 double loads
     const unsigned gw = grid_for(t->n_words ? t->n_words : 1, kTrainThreads * 8, 256);
     SWT_HIP(hipMemsetAsync(t->d_halt, 0, 8, 0));
     for (uint32_t i = 0; i < k; i++) {
