@@ -175,6 +175,9 @@ def pack_and_lower(texts):
     counts code points (len(str)); byte offsets and str.lower() come from the device (swt_utf8_prepare); the few sentences
     it flags are lowercased here and spliced in."""
     n = len(texts)
+    if n <= 64 and sum(map(len, texts)) <= 16384:
+        # the reference-style call (one sentence, or a few): a device round trip costs more than str.lower() here
+        return pack_utf8([t.lower() for t in texts])
     cp_off = np.zeros(n + 1, dtype=np.uint64)
     if n:
         np.cumsum(np.fromiter(map(len, texts), dtype=np.uint64, count=n), out=cp_off[1:])

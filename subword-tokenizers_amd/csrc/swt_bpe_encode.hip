@@ -20,6 +20,8 @@
 //          and only symbols next to a merge probe the table again -- one L2 round trip per round for the wave
 //     E/F  order-preserving ballot compaction to the tile's output run, per-sentence offsets
 // A word longer than a chunk falls to a one-lane global-memory path (correct, slow, pathological inputs only).
+#include <cstring>
+
 #include "swt_dedup.h"
 #include "swt_tile.h"
 
@@ -528,6 +530,8 @@ struct swt_bpe_table {
   // word-level dedup inside one call
   TileWorkspace ws2;          // workspaces of the encode over the unique words
   DedupEngine dd;
+  PinnedBuf pin;       // small host calls: inputs and outputs staged in one pinned buffer, one copy each way
+  DevBuf small_in, small_out;
 };
 
 static int bpe_upload(swt_bpe_table *t) {
@@ -605,6 +609,9 @@ void swt_bpe_table_destroy(swt_bpe_table *t) {
   t->ws.release();
   t->ws2.release();
   t->dd.release();
+  t->pin.release();
+  t->small_in.release();
+  t->small_out.release();
   for (DevBuf *b : {&t->in_text, &t->in_off, &t->out_ids, &t->out_off, &t->n_tok}) b->release();
   delete t;
 }
@@ -706,6 +713,34 @@ int swt_bpe_encode(swt_bpe_table *t, const uint8_t *text, const uint64_t *sent_o
     if (sent_off[s] > sent_off[s + 1])
       return fail(SWT_ERR_INVALID, "sentence offsets must be non-decreasing (at %llu)", (unsigned long long)s);
   if (n_bytes && !text) return fail(SWT_ERR_INVALID, "null text");
+  if (n_bytes <= kSmallCallBytes && n_sent <= kSmallCallSents) {
+    // The reference-style call (one sentence, or a few): five small copies and their synchronisations cost more than the
+    // kernels.  Offsets + text go up in ONE copy from pinned memory, token count + offsets + ids come back in ONE.
+    const size_t off_bytes = ((n_sent + 1) * 8 + 15) & ~(size_t)15;
+    const size_t in_bytes = off_bytes + n_bytes + 64;
+    const size_t out_bytes = 16 + off_bytes + (n_bytes + 64) * 4;
+    if ((rc = t->pin.reserve(in_bytes > out_bytes ? in_bytes : out_bytes)) || (rc = t->small_in.reserve(in_bytes)) ||
+        (rc = t->small_out.reserve(out_bytes)))
+      return rc;
+    uint8_t *h = t->pin.as<uint8_t>();
+    memcpy(h, sent_off, (n_sent + 1) * 8);
+    if (n_bytes) memcpy(h + off_bytes, text, n_bytes);
+    SWT_HIP(hipMemcpyAsync(t->small_in.p, h, off_bytes + n_bytes, hipMemcpyHostToDevice, 0));
+    uint8_t *d_in = t->small_in.as<uint8_t>(), *d_out = t->small_out.as<uint8_t>();
+    rc = swt_bpe_encode_dev(t, d_in + off_bytes, n_bytes, reinterpret_cast<const uint64_t *>(d_in), n_sent,
+                            reinterpret_cast<uint32_t *>(d_out + 16 + off_bytes), reinterpret_cast<uint64_t *>(d_out + 16),
+                            reinterpret_cast<uint64_t *>(d_out), flags, nullptr);
+    if (rc) return rc;
+    SWT_HIP(hipMemcpyAsync(h, d_out, 16 + off_bytes + (n_bytes + 64) * 4, hipMemcpyDeviceToHost, 0));
+    SWT_HIP(hipStreamSynchronize(0));
+    const uint64_t nt = *reinterpret_cast<const uint64_t *>(h);
+    *n_tokens = nt;
+    memcpy(out_off, h + 16, (n_sent + 1) * 8);
+    if (nt > out_cap)
+      return fail(SWT_ERR_CAPACITY, "out_ids too small: need %llu ids, have %llu", (unsigned long long)nt, (unsigned long long)out_cap);
+    if (nt) memcpy(out_ids, h + 16 + off_bytes, nt * 4);
+    return SWT_OK;
+  }
   if ((rc = t->in_text.reserve(n_bytes + 64))) return rc;
   if ((rc = t->in_off.reserve((n_sent + 1) * 8))) return rc;
   if ((rc = t->out_ids.reserve((n_bytes + 64) * 4))) return rc;

@@ -45,6 +45,17 @@ struct DevBuf {
   template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// pinned host staging (grow-only): one async copy each way for the small calls of the reference-style entry points
+struct PinnedBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes);
+  void release();
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+constexpr uint64_t kSmallCallBytes = 64 * 1024;  // text bytes up to which the host entry points take the one-copy path
+constexpr uint64_t kSmallCallSents = 4096;
+
 // ---- class table -------------------------------------------------------------------------------
 constexpr uint32_t kNumCodePoints = 0x110000u;
 const uint8_t *host_class_table();          // 0x110000 bytes, bits SWT_CLS_*

@@ -70,6 +70,23 @@ int DevBuf::reserve(size_t bytes) {
   return SWT_OK;
 }
 
+int PinnedBuf::reserve(size_t bytes) {
+  if (bytes <= cap) return SWT_OK;
+  const size_t want = bytes + bytes / 2 + 4096;
+  void *np = nullptr;
+  SWT_HIP(hipHostMalloc(&np, want, hipHostMallocDefault));
+  if (p) (void)hipHostFree(p);
+  p = np;
+  cap = want;
+  return SWT_OK;
+}
+
+void PinnedBuf::release() {
+  if (p) (void)hipHostFree(p);
+  p = nullptr;
+  cap = 0;
+}
+
 void DevBuf::release() {
   if (p) (void)hipFree(p);
   p = nullptr;

@@ -11,6 +11,7 @@
 //   nodes  16 bytes each {failure link, pop offset, pop count, flags}
 //   pops   token ids of every failure_pops list, concatenated
 // Node ids: 0 = root, 1 = root_p (detached, childless), 2.. in creation order; root_sharp is the node of "##".
+#include <cstring>
 #include <unordered_map>
 
 #include "swt_dedup.h"
@@ -555,6 +556,8 @@ struct swt_wp_trie {
   DedupEngine dd;
   TileWorkspace ws2;  // the encode over the unique chunks
   DevBuf u_status;
+  PinnedBuf pin;  // small host calls: one copy each way
+  DevBuf small_in, small_out;
 };
 
 static int wp_upload(swt_wp_trie *t) {
@@ -621,6 +624,9 @@ void swt_wp_trie_destroy(swt_wp_trie *t) {
   t->ws.release();
   t->ws2.release();
   t->dd.release();
+  t->pin.release();
+  t->small_in.release();
+  t->small_out.release();
   for (DevBuf *b : {&t->in_text, &t->in_off, &t->out_ids, &t->out_off, &t->out_status, &t->n_tok, &t->u_status}) b->release();
   delete t;
 }
@@ -745,6 +751,34 @@ int swt_wp_encode(swt_wp_trie *t, const uint8_t *text, const uint64_t *sent_off,
     if (sent_off[s] > sent_off[s + 1])
       return fail(SWT_ERR_INVALID, "sentence offsets must be non-decreasing (at %llu)", (unsigned long long)s);
   if (n_bytes && !text) return fail(SWT_ERR_INVALID, "null text");
+  if (n_bytes <= kSmallCallBytes && n_sent <= kSmallCallSents) {
+    // the reference-style call (one sentence, or a few): one copy up (offsets + text), one copy down (count, offsets, statuses, ids)
+    const size_t off_bytes = ((n_sent + 1) * 8 + 15) & ~(size_t)15, st_bytes = (n_sent + 15) & ~(size_t)15;
+    const size_t in_bytes = off_bytes + n_bytes + 64;
+    const size_t out_bytes = 16 + off_bytes + st_bytes + (n_bytes + 64) * 4;
+    if ((rc = t->pin.reserve(in_bytes > out_bytes ? in_bytes : out_bytes)) || (rc = t->small_in.reserve(in_bytes)) ||
+        (rc = t->small_out.reserve(out_bytes)))
+      return rc;
+    uint8_t *h = t->pin.as<uint8_t>();
+    memcpy(h, sent_off, (n_sent + 1) * 8);
+    if (n_bytes) memcpy(h + off_bytes, text, n_bytes);
+    SWT_HIP(hipMemcpyAsync(t->small_in.p, h, off_bytes + n_bytes, hipMemcpyHostToDevice, 0));
+    uint8_t *d_in = t->small_in.as<uint8_t>(), *d_out = t->small_out.as<uint8_t>();
+    rc = swt_wp_encode_dev(t, d_in + off_bytes, n_bytes, reinterpret_cast<const uint64_t *>(d_in), n_sent,
+                           reinterpret_cast<uint32_t *>(d_out + 16 + off_bytes + st_bytes), reinterpret_cast<uint64_t *>(d_out + 16),
+                           d_out + 16 + off_bytes, reinterpret_cast<uint64_t *>(d_out), nullptr);
+    if (rc) return rc;
+    SWT_HIP(hipMemcpyAsync(h, d_out, 16 + off_bytes + st_bytes + (n_bytes + 64) * 4, hipMemcpyDeviceToHost, 0));
+    SWT_HIP(hipStreamSynchronize(0));
+    const uint64_t nt = *reinterpret_cast<const uint64_t *>(h);
+    *n_tokens = nt;
+    memcpy(out_off, h + 16, (n_sent + 1) * 8);
+    if (n_sent) memcpy(status, h + 16 + off_bytes, n_sent);
+    if (nt > out_cap)
+      return fail(SWT_ERR_CAPACITY, "out_ids too small: need %llu ids, have %llu", (unsigned long long)nt, (unsigned long long)out_cap);
+    if (nt) memcpy(out_ids, h + 16 + off_bytes + st_bytes, nt * 4);
+    return SWT_OK;
+  }
   if ((rc = t->in_text.reserve(n_bytes + 64))) return rc;
   if ((rc = t->in_off.reserve((n_sent + 1) * 8))) return rc;
   if ((rc = t->out_ids.reserve((n_bytes + 64) * 4))) return rc;
