@@ -39,6 +39,7 @@ constexpr int kClsLds = 1024;    // code points whose class is served from LDS (
 
 constexpr int kBpeTile = 256;   // bytes of sentence starts per tile
 constexpr int kBpeCap = 512;    // staged bytes per chunk
+constexpr uint64_t kDirectBytes = 1024, kDirectSents = 64;  // up to here one workgroup and one launch do the whole call
 constexpr uint32_t kNoPos = 0xFFFFu;
 
 __device__ __forceinline__ bool slot_lookup(const BpeSlot *__restrict__ slots, uint32_t bits, uint32_t l, uint32_t r,
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
     const uint64_t *__restrict__ plan, const uint8_t *__restrict__ cls_tab, const BpeSlot *__restrict__ slots,
     uint32_t bits, const uint32_t *__restrict__ merged_of_rank, uint32_t *__restrict__ scratch,
     uint32_t *__restrict__ sent_local, uint32_t *__restrict__ tile_tok, const uint32_t *__restrict__ uslot,
-    unsigned long long *__restrict__ rec, unsigned long long *__restrict__ drec, uint32_t dbg) {
+    unsigned long long *__restrict__ rec, unsigned long long *__restrict__ drec, DirectOut direct, uint32_t dbg) {
   // uslot/rec/drec (dedup path, every "sentence" s is unique word s): the word's token run -- its place in scratch and its
   // length -- goes straight to drec[s] (dense: stays in L2 for the last pass) and length | s to the word's table slot, and
   // nobody needs a scan or a gather of this launch's output.
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
   const unsigned long long lt = (1ull << lane) - 1ull;  // lanes below me
   const unsigned long long le = (2ull << lane) - 1ull;  // me and below
   const uint64_t t = blockIdx.x;
-  const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
+  const uint64_t s_lo = direct.off ? 0 : plan[t], s_hi = direct.off ? direct.n_sent : plan[t + 1];
   if (s_lo == s_hi) {
     if (lane == 0) tile_tok[t] = 0;
     return;
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
         uint32_t mine = 0;
         for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
           if (sent_off[s] >= g.end) break;
-          sent_local[s] = run;
+          if (direct.off) direct.off[s] = run; else sent_local[s] = run;
           if (rec) {
             drec[s] = (unsigned long long)(span_base + run) | ((unsigned long long)g.ntok << 32);
             rec[uslot[s]] = (unsigned long long)s | ((unsigned long long)g.ntok << 32);
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
       if (rel > ce || (rel == ce && !last)) break;
       uint32_t e = total;
       if (rel < ce && (rel >> 6) < nblk) e = L.blkpre[rel >> 6] + __popcll(L.vmask[rel >> 6] & ((1ull << (rel & 63)) - 1ull));
-      sent_local[s] = run + e;
+      if (direct.off) direct.off[s] = run + e; else sent_local[s] = run + e;
       if (rec && rel < ce) {  // a word never straddles the cut, so its end lies in this chunk too
         const uint64_t rel2 = sent_off[s + 1] - abase;
         uint32_t e2 = total;
@@ -509,7 +510,10 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
     cb = abase + ce;
     __syncthreads();
   }
-  if (lane == 0) tile_tok[t] = run;
+  if (lane == 0) {
+    if (direct.off) { direct.off[s_hi] = run; *direct.n_tokens = run; }
+    else tile_tok[t] = run;
+  }
 }
 
 
@@ -552,7 +556,8 @@ static void launch_encode_kernel_as(swt_bpe_table *t, uint64_t n_tiles, const Ti
                                     unsigned long long *d_rec, unsigned long long *d_drec, hipStream_t st) {
   hipLaunchKernelGGL((bpe_encode_kernel<Packed, Cap>), dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
                      ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, ws.scratch.as<uint32_t>(),
-                     ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, (uint32_t)debug_knob(0));
+                     ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, DirectOut{nullptr, nullptr, 0},
+                     (uint32_t)debug_knob(0));
 }
 
 extern "C" {
@@ -637,6 +642,21 @@ static int bpe_encode_direct(swt_bpe_table *t, TileWorkspace &ws, const uint8_t 
   if (n_tiles > 0x7FFFFFFFull)
     return fail(SWT_ERR_UNSUPPORTED, "text too large for one call (%llu bytes)", (unsigned long long)n_bytes);
   int rc;
+  if (n_bytes <= kDirectBytes && n_sent <= kDirectSents) {
+    // a sentence or a few: one workgroup, one launch, the caller's arrays written by the kernel (DirectOut)
+    if ((rc = ws.reserve(64, 0, 1))) return rc;
+    const DirectOut direct{d_out_off, d_n_tokens, n_sent};
+    if (t->packed)
+      hipLaunchKernelGGL((bpe_encode_kernel<true, kBpeCap>), dim3(1), dim3(64), 0, st, d_text, n_bytes, d_sent_off, (const uint64_t *)nullptr, d_cls,
+                         t->d_slots, t->bits, t->d_merged, d_out_ids, ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(),
+                         (const uint32_t *)nullptr, (unsigned long long *)nullptr, (unsigned long long *)nullptr, direct, 0u);
+    else
+      hipLaunchKernelGGL((bpe_encode_kernel<false, kBpeCap>), dim3(1), dim3(64), 0, st, d_text, n_bytes, d_sent_off, (const uint64_t *)nullptr, d_cls,
+                         t->d_slots, t->bits, t->d_merged, d_out_ids, ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(),
+                         (const uint32_t *)nullptr, (unsigned long long *)nullptr, (unsigned long long *)nullptr, direct, 0u);
+    SWT_HIP(hipGetLastError());
+    return SWT_OK;
+  }
   if ((rc = ws.reserve(n_bytes, n_sent, n_tiles))) return rc;
   prof_begin(st, 2);
   launch_plan(d_sent_off, n_sent, n_tiles, kBpeTile, ws.plan.as<uint64_t>(), st);

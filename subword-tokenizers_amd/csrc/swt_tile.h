@@ -17,6 +17,15 @@ namespace swt {
 
 constexpr int kThreads = 256;  // gather_kernel
 
+// Direct mode of the encode kernels, for inputs of a few hundred bytes (the reference-style call: one sentence): ONE workgroup
+// takes all sentences as its tile and writes the caller's arrays itself -- 64-bit sentence offsets, the closing offset and the
+// token count -- so the call is one launch instead of plan + encode + scan + gather.  off == nullptr: the normal mode.
+struct DirectOut {
+  uint64_t *off;
+  uint64_t *n_tokens;
+  uint64_t n_sent;
+};
+
 // Per-call workspaces shared by both encoders (grow-only).
 struct TileWorkspace {
   DevBuf plan, scratch, sent_local, tile_tok, tile_base, blk;

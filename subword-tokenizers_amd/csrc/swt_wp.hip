@@ -164,6 +164,7 @@ constexpr int kWpTile = 512;    // bytes of sentence starts per tile
 constexpr int kWpCap = 1024;    // staged bytes per chunk
 constexpr int kWpBlocks = kWpCap / 64;
 constexpr int kWpClsLds = 1024;
+constexpr uint64_t kWpDirectBytes = 2048, kWpDirectSents = 64;  // up to here one workgroup and one launch do the whole call
 constexpr uint32_t kWpUTile = 256;       // smallest tile of the encode over the unique chunks (dedup path)
 constexpr uint64_t kWpUMaxTiles = 8192;  // its fixed launch size
 
@@ -196,12 +197,12 @@ __device__ __forceinline__ bool wbit(const unsigned long long *m, uint32_t p) { 
 __global__ __launch_bounds__(64) void wp_encode_kernel(
     const uint8_t *__restrict__ text, uint64_t n_bytes, const uint64_t *__restrict__ sent_off,
     const uint64_t *__restrict__ plan, const uint8_t *__restrict__ cls_tab, WpDev T, uint32_t *__restrict__ scratch,
-    uint32_t *__restrict__ sent_local, uint32_t *__restrict__ tile_tok, uint8_t *__restrict__ status) {
+    uint32_t *__restrict__ sent_local, uint32_t *__restrict__ tile_tok, uint8_t *__restrict__ status, DirectOut direct) {
   __shared__ WpLds L;
   const int lane = threadIdx.x;
   const unsigned long long lt = (1ull << lane) - 1ull;
   const uint64_t t = blockIdx.x;
-  const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
+  const uint64_t s_lo = direct.off ? 0 : plan[t], s_hi = direct.off ? direct.n_sent : plan[t + 1];
   if (s_lo == s_hi) {
     if (lane == 0) tile_tok[t] = 0;
     return;
@@ -265,7 +266,10 @@ __global__ __launch_bounds__(64) void wp_encode_kernel(
           const uint64_t e = sent_off[s + 1];
           const uint32_t n = wp_sentence(src, cb, e, tile_out + run, T, stt);
           // empty sentences that also start at cb come first and get no tokens
-          for (uint64_t z = s_next; z <= s; z++) { sent_local[z] = run; status[z] = (uint8_t)T.empty_status; }
+          for (uint64_t z = s_next; z <= s; z++) {
+            if (direct.off) direct.off[z] = run; else sent_local[z] = run;
+            status[z] = (uint8_t)T.empty_status;
+          }
           status[s] = (uint8_t)stt;
           L.giant.end = e;
           L.giant.ntok = n;
@@ -278,7 +282,10 @@ __global__ __launch_bounds__(64) void wp_encode_kernel(
         __syncthreads();
         if (cb >= span_end) {
           // trailing empty sentences at the very end of the span
-          for (uint64_t z = s_next + lane; z < s_hi; z += 64) { sent_local[z] = run; status[z] = (uint8_t)T.empty_status; }
+          for (uint64_t z = s_next + lane; z < s_hi; z += 64) {
+            if (direct.off) direct.off[z] = run; else sent_local[z] = run;
+            status[z] = (uint8_t)T.empty_status;
+          }
           break;
         }
         continue;
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(64) void wp_encode_kernel(
       if (rel > ce || (rel == ce && !last)) break;
       uint32_t ex = total;
       if (rel < ce && (rel >> 6) < nblk) ex = L.blkpre[rel >> 6] + __popcll(L.vmask[rel >> 6] & ((1ull << (rel & 63)) - 1ull));
-      sent_local[s] = run + ex;
+      if (direct.off) direct.off[s] = run + ex; else sent_local[s] = run + ex;
       mine++;
     }
     for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
@@ -402,7 +409,10 @@ __global__ __launch_bounds__(64) void wp_encode_kernel(
     cb = abase + ce;
     __syncthreads();
   }
-  if (lane == 0) tile_tok[t] = run;
+  if (lane == 0) {
+    if (direct.off) { direct.off[s_hi] = run; *direct.n_tokens = run; }
+    else tile_tok[t] = run;
+  }
 }
 
 // ---- host: trie build (utils.py:75-139) and flattening -------------------------------------------
@@ -700,6 +710,14 @@ int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, c
   T.corner_nonterm = t->H.corner_nonterm ? 1u : 0u;
   T.empty_status = t->H.child(t->H.root, ' ') >= 0 ? SWT_WP_INDEXERROR : SWT_WP_OK;
   T.corner_id = t->H.corner.size() == 1 ? t->H.corner[0] : t->H.n_vocab + 2;
+  if (n_bytes <= kWpDirectBytes && n_sent <= kWpDirectSents && !(debug_knob(1) & 2)) {
+    // a sentence or a few: one workgroup, one launch, the caller's arrays written by the kernel (DirectOut, swt_tile.h)
+    hipLaunchKernelGGL(wp_encode_kernel, dim3(1), dim3(64), 0, st, d_text, n_bytes, d_sent_off, (const uint64_t *)nullptr, d_cls, T,
+                       d_out_ids, t->ws.sent_local.as<uint32_t>(), t->ws.tile_tok.as<uint32_t>(), d_status,
+                       DirectOut{d_out_off, d_n_tokens, n_sent});
+    SWT_HIP(hipGetLastError());
+    return SWT_OK;
+  }
   // debug knob 1: bit 0 = never dedup, bit 1 = dedup whatever the batch size (tests)
   if (t->dedup_ok && T.empty_status == SWT_WP_OK && n_bytes <= kDedupMaxBytes && !(debug_knob(1) & 1) &&
       (n_bytes >= kDedupMinBytes || (debug_knob(1) & 2))) {
@@ -717,7 +735,8 @@ int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, c
     prof_begin(st);
     hipLaunchKernelGGL(wp_encode_kernel, dim3((unsigned)n_tiles2), dim3(64), 0, st, t->dd.utext.as<uint8_t>(), n_bytes,
                        t->dd.uoff.as<uint64_t>(), t->ws2.plan.as<uint64_t>(), d_cls, T, t->ws2.scratch.as<uint32_t>(),
-                       t->ws2.sent_local.as<uint32_t>(), t->ws2.tile_tok.as<uint32_t>(), t->u_status.as<uint8_t>());
+                       t->ws2.sent_local.as<uint32_t>(), t->ws2.tile_tok.as<uint32_t>(), t->u_status.as<uint8_t>(),
+                       DirectOut{nullptr, nullptr, 0});
     prof_end(st);
     hipLaunchKernelGGL(wp_urec_kernel, dim3((unsigned)n_tiles2), dim3(64), 0, st, t->dd.uoff.as<uint64_t>(), t->ws2.plan.as<uint64_t>(),
                        t->ws2.sent_local.as<uint32_t>(), t->ws2.tile_tok.as<uint32_t>(), t->u_status.as<uint8_t>(),
@@ -732,7 +751,7 @@ int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, c
   prof_begin(st);
   hipLaunchKernelGGL(wp_encode_kernel, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
                      t->ws.plan.as<uint64_t>(), d_cls, T, t->ws.scratch.as<uint32_t>(), t->ws.sent_local.as<uint32_t>(),
-                     t->ws.tile_tok.as<uint32_t>(), d_status);
+                     t->ws.tile_tok.as<uint32_t>(), d_status, DirectOut{nullptr, nullptr, 0});
   prof_end(st);
   launch_scan_gather(d_sent_off, n_sent, n_tiles, t->ws, d_out_ids, d_out_off, d_n_tokens, st);
   prof_end(st, 2);
