@@ -180,6 +180,23 @@ def test_dedup_table_overflow_is_harmless(swt, dev, bpe, bpe_orc, wp, wp_orc, co
     same_wp(wp, wp_orc, texts)
 
 
+def test_single_launch_direct_mode_boundaries(bpe, bpe_orc, wp, wp_orc):
+    """tiny calls run as one launch of one workgroup that writes the caller's arrays itself (DirectOut): sizes and sentence
+    counts on both sides of its limits (1 KiB / 2 KiB of text, 64 sentences), chunk cuts and giant words inside it"""
+    w = "słowo "
+    cases = [
+        ["a"], ["", "a", ""], ["x" * 1024], ["x" * 1025], ["y" * 600 + " " + "z" * 423], ["y" * 600 + " " + "z" * 424],
+        [w * 170], [w * 171], ["ab " * 341], ["ab " * 342], ["q" * 2048], ["q" * 2049], [("nie wiem, " * 204)[:2048]], [("nie wiem, " * 205)[:2049]],
+        ["a"] * 64, ["a"] * 65, ["ab cd"] * 64, [""] * 64, [""] * 65, ["hello!", "ok"], ["a ## b"] * 3, ["zażółć gęślą jaźń!"] * 40,
+    ]
+    for texts in cases:
+        same_bpe(bpe, bpe_orc, texts)
+        same_wp(wp, wp_orc, texts)
+    for texts in cases:  # and one sentence per call, the reference's own way
+        for t in texts[:3]:
+            assert bpe.tokenize(t) == bpe_orc.tokenize(t)
+
+
 def test_random_tables_and_texts_both_paths(swt, oracle, dev):
     """seeded stress: random merge tables / vocabularies over tiny alphabets (twin runs, overlapping merges, punctuation and
     '#' inside chunks), random ragged texts; direct path and dedup path against the oracle"""
