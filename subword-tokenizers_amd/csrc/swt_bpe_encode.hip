@@ -379,6 +379,74 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
     //      if its pair changed, feeds the next round's per-word minimum, and the list is compacted.
     uint32_t cur = 0, round_no = 0;
     while (na > 0 && !(dbg & 16)) {
+      if (na <= 64 && dbg == 0) {
+        // ---- register rounds: once the symbols of the unfinished words fit one wave (always, after a few rounds; from the
+        // start for the short tiles of the unique-word pass) every entry lives in a lane.  The entries of a word are
+        // consecutive lanes in text order, so "my next symbol" is the lane above me, a round is ballots and shuffles, and
+        // the dependent LDS chain of the list form (~30 accesses per round) shrinks to the word minimum and the compaction.
+        bool valid = (uint32_t)lane < na;
+        uint32_t e = valid ? L.act[lane] : 0u, v = valid ? L.aval[lane] : kNoRank;
+        uint32_t p = e & 0xFFFFu, head = e >> 16;
+        uint32_t sy = valid ? L.sym[p] : 0u;
+        for (;;) {
+          const unsigned long long VALID = __ballot(valid);
+          if (!VALID) break;
+          const uint32_t hw = head >> 1;
+          const uint32_t m = valid ? L.wm[cur][hw] : kNoRank;
+          __syncthreads();
+          if (valid && p == head) L.wm[cur ^ 1][hw] = kNoRank;
+          const uint32_t head1 = __shfl_down(head, 1), head2 = __shfl_down(head, 2);
+          const uint32_t sy1 = __shfl_down(sy, 1), sy2 = __shfl_down(sy, 2);
+          const bool same1 = lane < 63 && ((VALID >> (lane + 1)) & 1ull) && head1 == head;
+          const bool same2 = same1 && lane < 62 && ((VALID >> (lane + 2)) & 1ull) && head2 == head;
+          const bool cand = valid && m != kNoRank && v == m;  // v is the value of (me, lane above me): that lane exists
+          const bool twin = cand && sy1 == sy;
+          const unsigned long long TW = __ballot(twin);
+          bool taken = cand;
+          if (twin) {
+            // a run of twin pairs ("aaaa") merges left to right, non-overlapping (bpe.py:225-235): every second member,
+            // counted from the run's first lane (runs of different words never touch: a word's last symbol is no candidate)
+            const unsigned long long low = ~TW & lt;
+            const int start = low ? 64 - __builtin_clzll(low) : 0;
+            taken = ((lane - start) & 1) == 0;
+          }
+          const unsigned long long TK = __ballot(taken);
+          const bool dead = lane > 0 && ((TK >> (lane - 1)) & 1ull);  // the lane below me merged me in
+          const bool tk1 = same1 && ((TK >> (lane + 1)) & 1ull), tk2 = same2 && ((TK >> (lane + 2)) & 1ull);
+          uint32_t mg = 0;
+          if (valid && m != kNoRank) mg = Packed ? (SWT_SYM_BASE + (m & 0xFFFFu)) : merged_of_rank[m];
+          const bool keep = valid && m != kNoRank && !dead;
+          if (valid && !keep) L.sym[p] = dead ? kInvalidTok : (p != head ? (sy | SWT_BPE_CONT) : sy);  // consumed, or word finished
+          // my symbol and the symbol above me after this round
+          const uint32_t sn = taken ? mg : sy;
+          const bool has_r = taken ? same2 : same1;
+          const uint32_t sr = taken ? (tk2 ? mg : sy2) : (tk1 ? mg : sy1);
+          uint32_t vn = v;
+          if (!has_r) vn = kNoRank;
+          else if (taken || tk1) vn = slot_value(slots, bits, sn, sr);
+          __syncthreads();  // the reset of the next round's minima (above) comes before the lanes feed them
+          if (keep && vn != kNoRank) atomicMin(&L.wm[cur ^ 1][hw], vn);
+          const unsigned long long KEEP = __ballot(keep);
+          if (keep) {
+            const uint32_t d = (uint32_t)__popcll(KEEP & lt);
+            L.act[d] = e;
+            L.aval[d] = vn;
+            L.sym[p] = sn;
+          }
+          __syncthreads();
+          valid = (uint32_t)lane < (uint32_t)__popcll(KEEP);
+          if (valid) {
+            e = L.act[lane];
+            v = L.aval[lane];
+            p = e & 0xFFFFu;
+            head = e >> 16;
+            sy = L.sym[p];
+          }
+          cur ^= 1;
+        }
+        na = 0;
+        break;
+      }
       round_no++;
       const bool stop_now = (dbg >> 8) && round_no > (dbg >> 8);  // ablation: bounded rounds
       bool twin = false;
