@@ -118,7 +118,7 @@ void swt_bpe_table_destroy(swt_bpe_table *t);
  * out_cap >= n_bytes is always sufficient (every token covers at least one byte). */
 #define SWT_BPE_RAW_WORDS 1u   /* flags: every "sentence" is ONE word, no pre-tokenizer split -- this is
                                   FastBPE.encode_word(word) (source/bpe.py:205), batched */
-#define SWT_BPE_NO_DEDUP 2u    /* flags: encode every word occurrence (by default batches of 1 MiB and more encode each
+#define SWT_BPE_NO_DEDUP 2u    /* flags: encode every word occurrence (by default batches of 1.75 MiB and more encode each
                                   DISTINCT word once and copy its tokens to every occurrence; same output either way) */
 int swt_bpe_encode(swt_bpe_table *t, const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent,
                    uint32_t *out_ids, uint64_t out_cap, uint64_t *out_off, uint64_t *n_tokens, uint32_t flags);

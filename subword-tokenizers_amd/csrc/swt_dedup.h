@@ -18,7 +18,10 @@
 
 namespace swt {
 
-constexpr uint64_t kDedupMinBytes = 1u << 20;   // below ~0.9 MB the extra launches cost more than the merge rounds they save (measured)
+// below these sizes the extra launches cost more than the work they save (measured crossovers: FastBPE 1.7 MB, FastWP 2.8 MB;
+// tools/gpu_scale_sweep.py, tools/gpu_wp_crossover.py)
+constexpr uint64_t kDedupMinBytes = 7u << 18;     // FastBPE: 1.75 MiB
+constexpr uint64_t kDedupMinBytesWp = 11u << 18;  // FastWP: 2.75 MiB
 constexpr uint64_t kDedupMaxBytes = 1ull << 30;  // 32-bit fields of the records
 constexpr uint32_t kRecFailed = 0xFFFFFFFFu;     // count field of rec[]: the word cannot be encoded (FastWP non-termination)
 

@@ -720,7 +720,7 @@ int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, c
   }
   // debug knob 1: bit 0 = never dedup, bit 1 = dedup whatever the batch size (tests)
   if (t->dedup_ok && T.empty_status == SWT_WP_OK && n_bytes <= kDedupMaxBytes && !(debug_knob(1) & 1) &&
-      (n_bytes >= kDedupMinBytes || (debug_knob(1) & 2))) {
+      (n_bytes >= kDedupMinBytesWp || (debug_knob(1) & 2))) {
     // Word-level dedup (swt_dedup.h): the chunks between whitespace are encoded once per call.  The encode over the unique
     // chunks is this same kernel with every chunk as a "sentence"; its launch size is fixed and the tile size follows on
     // the device (the number of unique chunks never reaches the host).

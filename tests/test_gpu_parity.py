@@ -119,7 +119,7 @@ def test_bpe_edge_shapes(bpe, bpe_orc):
 
 
 def test_bpe_dedup_path_equals_direct_path(bpe, bpe_orc, dev, corpora):
-    """word-level dedup inside a call (default for batches >= 1 MiB) and the direct path give the same ids"""
+    """word-level dedup inside a call (default for batches >= 1.75 MiB) and the direct path give the same ids"""
     cases = [
         [], [""], ["", "a", "", "b", ""], ["!" * 5000], ["słowo " * 3000], ["x" * 20000], ["ab" * 6000 + " " + "nie " * 10],
         ["ż" * 3000 + " koniec"], ["q" * 300 + " " + "q" * 300, "q" * 300],          # 255+-byte words are never matched
@@ -415,7 +415,7 @@ def test_wp_edge_shapes(wp, wp_orc):
 
 
 def test_wp_dedup_path_equals_direct_path(swt, wp, wp_orc, dev, golden, corpora, ref_dir):
-    """word-level dedup inside a call (chunks between whitespace; default for batches >= 1 MiB when no vocabulary token
+    """word-level dedup inside a call (chunks between whitespace; default for batches >= 1.75 MiB when no vocabulary token
     holds whitespace) against the oracle and against the direct path, statuses included"""
     fw = golden("fuzz_wp.json")
     fuzz = [c["text"] for c in fw["sentences"]]
