@@ -415,7 +415,7 @@ def test_wp_edge_shapes(wp, wp_orc):
 
 
 def test_wp_dedup_path_equals_direct_path(swt, wp, wp_orc, dev, golden, corpora, ref_dir):
-    """word-level dedup inside a call (chunks between whitespace; default for batches >= 1.75 MiB when no vocabulary token
+    """word-level dedup inside a call (chunks between whitespace; default for batches >= 2.75 MiB when no vocabulary token
     holds whitespace) against the oracle and against the direct path, statuses included"""
     fw = golden("fuzz_wp.json")
     fuzz = [c["text"] for c in fw["sentences"]]
