@@ -1,25 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the MI355X subword-tokenizer hot path, one JSON line on stdout.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bpe_encode|wp_encode|bpe_train|wp_train|bpe_train_1g|mixed_encode]
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+                    [--workload headline|bpe_encode|wp_encode|bpe_train|wp_train|bpe_train_1g|mixed_encode]
 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
 (one process per GPU; RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the environment).  Encode shards the corpus
 by sentence: every rank encodes its own S85k-shaped shard with a replicated table and there is NO data-path
 collective (weak scaling); torch.distributed/RCCL is only the barrier and the MAX over ranks of the time.
 
-Headline (BASELINE.json configs[1]): FastBPE encode of S85k -- the seeded stand-in for the absent
-data/train-85k.json -- with the first 8,000 pretrained merges; metric = MB of input
-text (UTF-8, 1 MB = 1e6 B) encoded per second, inputs resident in HBM when the timed region starts.
-A "step" is one pass of the whole path (plan + encode + scan + gather kernels) over the batch.
+Default workload `headline` = BOTH halves of BASELINE.json's metric in one line:
 
-  roofline      timed with HIP events on the launch stream inside the library (swt_profile_*); achieved = algorithmic
-                bytes / time; algorithmic bytes per call = input bytes + 4 B per output token + 8 B per sentence
-                offset.  FastBPE encode is a pipeline of eight short kernels: its line is that
-                of the whole call (first kernel start .. last kernel end) with the longest kernel beside it; the
-                other workloads time their dominant kernel.
-  cpu_baseline  the C oracle (oracle/, a port of the reference's algorithm) on one host core of this box, on the
-                same S85k batch.  The oracle is only the checker/baseline here, never the thing measured.
+  value / unit   FastBPE encode (configs[1]) MB/s of input text (UTF-8, 1 MB = 1e6 B), inputs resident in HBM, first 8,000
+                 pretrained merges, measured on TWO seeded stand-ins for the absent data/train-85k.json -- S85k-lex (closed
+                 lexicon: train-5K's types + 60 k novel ones) and S85k-open (SURVEY.md section 8d-2 to the letter: every
+                 word trigram-sampled, an open vocabulary) -- and reported for the SLOWER of the two; the other one sits in
+                 "other_corpus".  A "step" is one pass of the whole encode path over the batch.
+  "train"        FastBPE.train S85k-open -> vocab 8,000 (the north-star training target): s_per_1k_merges, the per-merge
+                 device time, a roofline against the reference formulation's bytes (12 N_t + 8 W per merge)
+                 divided by the WHOLE merge time, and the C oracle beside it.
+  "encode_detail" per corpus: distinct-word ratio (what the word-level dedup feeds on), the time with the dedup switched
+                 off, and the end-to-end rate from list[str] (host lower/pack + PCIe included; never `value`).
+  roofline       HIP events on the launch stream inside the library (swt_profile_*); achieved = algorithmic bytes / time;
+                 algorithmic bytes per call = input bytes + 4 B per output token + 8 B per sentence offset.
+  cpu_baseline   the C oracle (oracle/, a port of the reference's algorithm) on this box's host: 1 thread, and all host
+                 cores (core count stated).  The oracle is only the checker/baseline here, never the thing measured.
 """
 import argparse
 import json
@@ -91,6 +96,226 @@ def traffic_from_profile(workload):
 
 def to_dev(torch, arr):
     return torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def check_frac(roof):
+    """a roofline fraction above 1 means the bytes were not moved in that time: refuse to print it"""
+    if roof is not None and roof.get("frac") is not None and roof["frac"] > 1.0:
+        raise SystemExit("INVALID roofline: frac %.4f > 1 (%s)" % (roof["frac"], roof.get("kernel")))
+    return roof
+
+
+def encode_corpus_bench(args, torch, dist, rank, N, bpe, sents, merges, name, cpu_leg):
+    """K timed steps of the FastBPE device path over one corpus resident in HBM, then (outside the timed region) the whole-call
+    event timing, the same call with the word-level dedup off, the end-to-end rate from list[str], and the parity check."""
+    text, off = N.pack_utf8([s.lower() for s in sents])
+    n_bytes, n_sent = int(text.size), len(sents)
+    d_text, d_off = to_dev(torch, text), to_dev(torch, off.view(np.int64))
+    d_out = torch.empty(n_bytes + 64, dtype=torch.int32, device="cuda")
+    d_out_off = torch.empty(n_sent + 1, dtype=torch.int64, device="cuda")
+    d_ntok = torch.zeros(1, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(flags=0):
+        bpe._table.encode_dev(d_text.data_ptr(), n_bytes, d_off.data_ptr(), n_sent, d_out.data_ptr(), d_out_off.data_ptr(),
+                              d_ntok.data_ptr(), flags, stream)
+
+    for _ in range(args.warmup):
+        step()
+    barrier_sync(torch, dist)
+    n_tok = int(d_ntok.item())
+    N.profile_enable(True)
+    N.profile_read()
+    barrier_sync(torch, dist)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier_sync(torch, dist)
+    elapsed = max_over_ranks(torch, dist, time.perf_counter() - t0)
+    kernel_ms, launches = N.profile_read()
+    # ---- outside the timed region ----
+    extra = min(max(args.steps, 1), 20)
+    N.profile_enable(2)  # one event pair around ALL kernels of a call
+    for _ in range(extra):
+        step()
+    torch.cuda.synchronize()
+    call_ms, calls = N.profile_read()
+    for _ in range(3):
+        step(N.BPE_NO_DEDUP)
+    torch.cuda.synchronize()
+    N.profile_read()
+    for _ in range(extra):
+        step(N.BPE_NO_DEDUP)
+    torch.cuda.synchronize()
+    nd_ms, nd_calls = N.profile_read()
+    N.profile_enable(False)
+    step()
+    torch.cuda.synchronize()
+    total_bytes = sum_over_ranks(torch, dist, float(n_bytes))
+    res = {"corpus": name, "mb_s": total_bytes * args.steps / 1e6 / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+           "n_bytes": n_bytes, "n_sent": n_sent, "n_tok": n_tok, "roofline": None, "cpu": None, "detail": None}
+    if rank != 0:
+        return res
+    from oracle import oracle as O
+
+    orc = O.OracleBPE(merges)
+    ids = d_out[:n_tok].cpu().numpy().view(np.uint32)
+    offs = d_out_off.cpu().numpy().view(np.uint64)
+    blob, boff = O.pack([s.lower() for s in sents])
+    out = np.zeros(max(blob.size, 1), dtype=np.uint32)
+    oo = np.zeros(n_sent + 1, dtype=np.uint64)
+    # the C call alone (lower() + packing excluded, as on the GPU side): 1 thread, then all host cores
+    t1 = time.perf_counter()
+    O.lib().orc_bpe_tokenize_batch(orc._h, O._p32(blob), O._p64(boff), n_sent, O._p32(out), O._p64(oo))
+    cpu1_s = time.perf_counter() - t1
+    if not (np.array_equal(ids, out[:int(oo[-1])]) and np.array_equal(offs, oo)):
+        raise SystemExit("PARITY FAILURE: device ids differ from the oracle on the benchmark batch (%s)" % name)
+    if cpu_leg:
+        cores = host_cores()
+        t1 = time.perf_counter()
+        O.lib().orc_bpe_tokenize_batch_mt(orc._h, O._p32(blob), O._p64(boff), n_sent, O._p32(out), O._p64(oo), cores)
+        cpun_s = time.perf_counter() - t1
+        if not (np.array_equal(ids, out[:int(oo[-1])]) and np.array_equal(offs, oo)):
+            raise SystemExit("PARITY FAILURE: the threaded oracle differs (%s)" % name)
+        res["cpu"] = {"value": round(n_bytes / 1e6 / cpu1_s, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+                      "sample": "the whole %s batch (%.1f MB), one pass of oracle/swt_oracle.c orc_bpe_tokenize_batch" % (name, n_bytes / 1e6),
+                      "all_cores": {"value": round(n_bytes / 1e6 / cpun_s, 3), "unit": "MB/s", "cores": cores,
+                                    "sample": "the same batch, orc_bpe_tokenize_batch_mt over %d host threads" % cores}}
+    # the call is a pipeline of short kernels and none of them touches all of the algorithmic bytes, so the roofline line is
+    # that of the whole call: algorithmic bytes of the batch over first kernel start .. last kernel end (HIP events on the
+    # launch stream); the longest single kernel (bpe_encode_kernel over the unique words) is reported beside it
+    algo = n_bytes + 4.0 * n_tok + 8.0 * (n_sent + 1)
+    per_call_s = call_ms / 1e3 / max(calls, 1)
+    achieved = algo / per_call_s / 1e9
+    res["roofline"] = check_frac({
+        "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+        "traffic": traffic_from_profile("bpe_encode_" + name) or traffic_from_profile("bpe_encode"),
+        "kernel": "whole call (word-dedup pipeline; the longest kernel beside it)", "kernel_us": round(per_call_s * 1e6, 2),
+        "algorithmic_bytes_per_launch": int(algo), "launches_timed": int(calls),
+        "dominant_kernel": {"name": "bpe_encode_kernel", "us": round(kernel_ms * 1e3 / max(launches, 1), 2), "launches_timed": int(launches)}})
+    # what the dedup feeds on, exactly: the device's own split + Counter (bpe.py:73-77) of this batch
+    tr = N.BpeTrainer.from_text(text, off)
+    _ids, _woff, freq = tr.export()
+    tr.close()
+    n_words, n_distinct = int(freq.astype(np.int64).sum()), int(freq.size)
+    # end to end from list[str]: lower + pack on the host/device, PCIe both ways, ids out (never `value`)
+    bpe.encode_ids_batch(sents[:2000])
+    t1 = time.perf_counter()
+    e_ids, e_off = bpe.encode_ids_batch(sents)
+    e2e_s = time.perf_counter() - t1
+    if not (np.array_equal(e_ids, ids) and np.array_equal(e_off, offs)):
+        raise SystemExit("PARITY FAILURE: encode_ids_batch differs from the device-resident call (%s)" % name)
+    res["detail"] = {"words": n_words, "distinct_words": n_distinct, "distinct_word_ratio": round(n_distinct / max(n_words, 1), 4),
+                     "dedup_call_us": round(per_call_s * 1e6, 2), "no_dedup_ms": round(nd_ms / max(nd_calls, 1), 4),
+                     "end_to_end_mb_s": round(n_bytes / 1e6 / e2e_s, 1),
+                     "end_to_end_note": "FastBPE.encode_ids_batch(list[str]) -> ids: join + str.encode, device lower/offsets, H2D, encode, D2H"}
+    return res
+
+
+def train_bench(args, torch, dist, rank, world, N, sents, max_vocab, name, repeats=2, cpu_sample=200):
+    """FastBPE.train (bpe.py:50-112) of `sents` to max_vocab: wall seconds per 1,000 merges over the whole call (host lower +
+    pack, H2D, device split/Counter/histogram, the merge loop), the merge loop's device time per merge (HIP events around every
+    batch of device-driven merges), the roofline against the reference formulation's bytes and the C oracle's first merges."""
+    from subword_tokenizers_amd import tokenizers
+
+    times, loops = [], []
+    merges, info, trace = [], {}, None
+    for it in range(1 + repeats):  # first pass = warm-up (allocations, code objects)
+        N.profile_enable(True)
+        N.profile_read()
+        barrier_sync(torch, dist)
+        t0 = time.perf_counter()
+        if world == 1:
+            tok = tokenizers.FastBPE()
+            tok.train(sents, max_vocab)
+            merges = list(tok.merges_list)
+            info = tok._trainer.info()
+            trace = tok._trainer.step_trace() if hasattr(tok._trainer, "step_trace") else None
+            tok.reset()
+        else:
+            from subword_tokenizers_amd.distributed import train_sharded
+
+            merges, info = train_sharded(sents, max_vocab, rank, world, dist)
+        barrier_sync(torch, dist)
+        dt = max_over_ranks(torch, dist, time.perf_counter() - t0)
+        ms, _n = N.profile_read()
+        if it:
+            times.append(dt)
+            loops.append(ms / 1e3)
+    N.profile_enable(False)
+    if rank != 0:
+        return None
+    from oracle import oracle as O
+
+    n_merges = max(len(merges), 1)
+    orc = O.OracleBPETrainer(sents)
+    n0, w0 = orc.n_symbols, orc.n_words
+    t1 = time.perf_counter()
+    orc.run(max_vocab, cpu_sample)
+    cpu_s = time.perf_counter() - t1
+    if orc.merges_list != merges[:cpu_sample]:
+        raise SystemExit("PARITY FAILURE: device merges differ from the oracle on the first %d merges (%s)" % (cpu_sample, name))
+    n_final = int(info["n_symbols"])
+    # reference formulation (SURVEY.md 8d): 12 N_t + 8 W bytes per merge; N_t falls from N_0 to N_final (trapezoid), and the
+    # time is that of the WHOLE merge step (every kernel of it), so the fraction is an effective bandwidth and cannot pass 1
+    algo = 12.0 * (n0 + n_final) / 2.0 + 8.0 * w0
+    loop_s = sum(loops) / len(loops)
+    per_merge_s = loop_s / n_merges
+    achieved = algo / per_merge_s / 1e9 if per_merge_s else 0.0
+    wall = sum(times) / len(times)
+    roof = check_frac({
+        "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+        "traffic": traffic_from_profile("bpe_train"), "kernel": "one merge step, all of its kernels (argmax, tie-break, apply)",
+        "kernel_us": round(per_merge_s * 1e6, 2), "algorithmic_bytes_per_launch": int(algo), "launches_timed": int(n_merges * len(loops)),
+        "note": "algorithmic bytes are the reference's full-rescan formulation (12 N_t + 8 W, N_t averaged over the run); the "
+                "incremental design moves far fewer, so this is an effective rate, not HBM traffic"})
+    return {"metric": "BPE train seconds per 1k merges", "s_per_1k_merges": round(wall / n_merges * 1000, 5), "train_wall_s": round(wall, 4),
+            "merge_loop_s": round(loop_s, 4), "us_per_merge_device": round(per_merge_s * 1e6, 2), "n_merges": len(merges),
+            "workload": "FastBPE.train on %s to max_vocab=%d: %d merges, %d unique words, %d -> %d symbols" % (name, max_vocab, len(merges), w0, n0, n_final),
+            "parallelism": "single GPU" if world == 1 else "corpus-sharded x%d, per-merge delta all-gather (RCCL)" % world,
+            "roofline": roof,
+            "cpu_baseline": {"value": round(cpu_s / cpu_sample * 1000, 3), "unit": "s/1k-merges", "cores": 1, "kind": "port",
+                             "sample": "first %d merges of the same run through oracle/swt_oracle.c orc_train_run (the reference's "
+                                       "full recount per merge; its cost per merge falls slowly with N_t)" % cpu_sample}}
+
+
+def bench_headline(args, torch, dist, rank, world, local):
+    """Both halves of BASELINE.json's metric: configs[1] FastBPE encode (value) + FastBPE.train s/1k-merges ("train")."""
+    from subword_tokenizers_amd import _native as N
+    from subword_tokenizers_amd import synth, tokenizers
+
+    N.init(local)
+    merges = synth.pretrained_merges()[:8000]
+    bpe = tokenizers.FastBPE()
+    bpe.merges_list = list(merges)
+    bpe._build_table()
+    corpora = [("S85k-lex", synth.sentences(85000, 85000 + rank) if rank else synth.s85k()),
+               ("S85k-open", synth.sentences_open(85000, 85000 + rank) if rank else synth.s85k_open())]
+    runs = [encode_corpus_bench(args, torch, dist, rank, N, bpe, sents, merges, name, cpu_leg=True) for name, sents in corpora]
+    train = train_bench(args, torch, dist, rank, world, N, corpora[1][1], args.max_vocab or 8000, "S85k-open")
+    head, other = sorted(runs, key=lambda r: r["mb_s"])
+    out = {
+        "metric": "FastBPE encode MB/s (value; tokens bit-exact) + BPE train s/1k-merges (train.s_per_1k_merges)",
+        "value": round(head["mb_s"], 1), "unit": "MB/s", "ms_per_step": round(head["ms_per_step"], 4), "dtype": "u32",
+        "config": {"workload": "configs[1]: FastBPE encode, %s stand-in for train-85k (85,000 sentences, %.2f MB/GPU), first 8,000 "
+                               "pretrained merges -- the slower of S85k-lex / S85k-open" % (head["corpus"], head["n_bytes"] / 1e6),
+                   "sentences_per_gpu": head["n_sent"], "bytes_per_gpu": head["n_bytes"], "tokens_per_gpu": head["n_tok"],
+                   "parallelism": "corpus-sharded x%d, no collective" % world},
+        "roofline": head["roofline"], "cpu_baseline": head["cpu"],
+        "encode_detail": {r["corpus"]: r["detail"] for r in runs},
+        "other_corpus": {"corpus": other["corpus"], "value": round(other["mb_s"], 1), "unit": "MB/s", "ms_per_step": round(other["ms_per_step"], 4),
+                         "bytes_per_gpu": other["n_bytes"], "tokens_per_gpu": other["n_tok"], "roofline": other["roofline"],
+                         "cpu_baseline": other["cpu"]},
+        "train": train,
+    }
+    return out
 
 
 def bench_bpe_encode(args, torch, dist, rank, world, local):
@@ -277,80 +502,21 @@ def bench_wp_encode(args, torch, dist, rank, world, local):
 
 
 def bench_bpe_train(args, torch, dist, rank, world, local):
-    """sec / 1k merges: S85k -> vocab 8,000 (the north-star training target), single GPU."""
+    """sec / 1k merges alone: FastBPE.train on S85k-open -> vocab 8,000 (the north-star training target)."""
     from subword_tokenizers_amd import _native as N
-    from subword_tokenizers_amd import synth, tokenizers
+    from subword_tokenizers_amd import synth
 
     N.init(local)
-    sents = synth.s85k()
-    max_vocab = args.max_vocab or 8000
-    times = []
-    n_merges = 0
-    kernel_ms = launches = 0
-    info = {}
-    merges = []
-    for it in range(args.warmup + args.steps):
-        if it == args.warmup:
-            N.profile_enable(True)
-            N.profile_read()
-        barrier_sync(torch, dist)
-        t0 = time.perf_counter()
-        if world == 1:
-            tok = tokenizers.FastBPE()
-            tok.train(sents, max_vocab)
-            merges = list(tok.merges_list)
-            info = tok._trainer.info()
-            tok.reset()
-        else:
-            # corpus-sharded: contiguous sentence ranges, pair-histogram deltas all-gathered over RCCL every merge
-            from subword_tokenizers_amd.distributed import ShardedBpeTrainer, TorchGroup
-
-            tr = ShardedBpeTrainer.from_corpus(sents, rank, world, TorchGroup(dist, "cuda"))
-            merges = [tuple(m) for m in tr.train(max_vocab)]
-            info = tr.engine.t.info()
-            tr.engine.t.close()
-        barrier_sync(torch, dist)
-        dt = max_over_ranks(torch, dist, time.perf_counter() - t0)
-        if it >= args.warmup:
-            times.append(dt)
-        n_merges = len(merges)
-    kernel_ms, launches = N.profile_read()
-    N.profile_enable(False)
-    elapsed = sum(times)
-    if rank != 0:
+    sents = synth.s85k() if args.corpus == "lex" else synth.s85k_open()
+    name = "S85k-lex" if args.corpus == "lex" else "S85k-open"
+    tr = train_bench(args, torch, dist, rank, world, N, sents, args.max_vocab or 8000, name, repeats=max(args.steps, 1))
+    if tr is None:
         return {"metric": "", "value": 0, "unit": "", "ms_per_step": 0, "dtype": "u32", "config": {}}
-    from oracle import oracle as O
-
-    sample = 200
-    tr = O.OracleBPETrainer(sents)
-    n0, w0 = tr.n_symbols, tr.n_words
-    t1 = time.perf_counter()
-    tr.run(max_vocab, sample)
-    cpu_s = time.perf_counter() - t1
-    if tr.merges_list != merges[:sample]:
-        raise SystemExit("PARITY FAILURE: device merges differ from the oracle on the first %d merges" % sample)
-    # full-rescan formulation of the reference: ~12*N_t + 8*W bytes per merge (SURVEY.md section 8d); N_t <= N_0
-    algo = 12.0 * n0 + 8.0 * w0
-    per_launch_s = kernel_ms / 1e3 / max(launches, 1)
-    achieved = algo / per_launch_s / 1e9 if per_launch_s else 0.0
-    sec_per_1k = elapsed / len(times) / max(n_merges, 1) * 1000
-    return {
-        "metric": "BPE train seconds per 1k merges", "value": round(sec_per_1k, 4), "unit": "s/1k-merges", "higher_is_better": False,
-        "ms_per_step": round(elapsed / len(times) * 1e3, 3), "dtype": "u32",
-        "config": {"workload": "FastBPE.train on S85k (stand-in for train-85k) to max_vocab=%d: %d merges, %d unique words, "
-                               "%d symbols" % (max_vocab, n_merges, w0, n0),
-                   "parallelism": "single GPU" if world == 1 else "corpus-sharded x%d, per-merge delta all-gather (RCCL)" % world},
-        "scaling": "strong",
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_from_profile("bpe_train"),
-                     "kernel": "apply_kernel", "kernel_us": round(per_launch_s * 1e6, 2),
-                     "algorithmic_bytes_per_launch": int(algo), "launches_timed": int(launches),
-                     "note": "algorithmic bytes are those of the reference's full-rescan formulation at N_0; the incremental "
-                             "design moves fewer"},
-        "cpu_baseline": {"value": round(cpu_s / sample * 1000, 3), "unit": "s/1k-merges", "cores": 1, "kind": "port",
-                         "sample": "first %d merges of the same run through oracle/swt_oracle.c orc_train_run" % sample},
-        "final_symbols": info["n_symbols"],
-    }
+    return {"metric": tr["metric"], "value": tr["s_per_1k_merges"], "unit": "s/1k-merges", "higher_is_better": False,
+            "ms_per_step": round(tr["train_wall_s"] * 1e3, 3), "dtype": "u32", "scaling": "strong",
+            "config": {"workload": tr["workload"], "parallelism": tr["parallelism"]},
+            "roofline": tr["roofline"], "cpu_baseline": tr["cpu_baseline"], "us_per_merge_device": tr["us_per_merge_device"],
+            "merge_loop_s": tr["merge_loop_s"]}
 
 
 def bench_mixed_encode(args, torch, dist, rank, world, local):
@@ -471,7 +637,7 @@ def bench_bpe_train_words(args, torch, dist, rank, world, local):
     N.profile_enable(False)
     from oracle import oracle as O
 
-    sample = 20
+    sample = args.parity_merges or 200
     orc = O.OracleBPETrainer.from_words(sym, off, freq)
     n0, w0 = orc.n_symbols, orc.n_words
     t1 = time.perf_counter()
@@ -482,25 +648,26 @@ def bench_bpe_train_words(args, torch, dist, rank, world, local):
             and np.array_equal(np.asarray(rights[:sample], dtype=np.uint32), ids[:, 1])
             and np.array_equal(np.asarray(counts[:sample], dtype=np.uint64), cnt)):
         raise SystemExit("PARITY FAILURE: device merges differ from the oracle on the first %d merges" % sample)
-    algo = 12.0 * n0 + 8.0 * w0
-    per_launch_s = kernel_ms / 1e3 / max(launches, 1)
-    achieved = algo / per_launch_s / 1e9 if per_launch_s else 0.0
+    n_final = int(info["n_symbols"])
+    algo = 12.0 * (n0 + n_final) / 2.0 + 8.0 * w0  # reference formulation, N_t averaged over the run (trapezoid)
+    per_merge_s = kernel_ms / 1e3 / max(len(times), 1) / max(len(lefts), 1)  # the event brackets span whole batches of merge steps
+    achieved = algo / per_merge_s / 1e9 if per_merge_s else 0.0
     elapsed = sum(times)
     return {
         "metric": "BPE train seconds per 1k merges", "value": round(elapsed / len(times) / max(len(lefts), 1) * 1000, 4),
         "unit": "s/1k-merges", "higher_is_better": False, "ms_per_step": round(elapsed / len(times) * 1e3, 3), "dtype": "u32",
         "config": {"workload": "configs[3] shape: BPE train of %d word types / %d tokens (~%.2f GB of text) to %d merges, "
-                               "deduplicated-words-with-frequencies form, %d symbols" % (w0, int(freq.sum()), corpus_bytes / 1e9, len(lefts), n0),
+                               "deduplicated-words-with-frequencies form, %d -> %d symbols" % (w0, int(freq.sum()), corpus_bytes / 1e9, len(lefts), n0, n_final),
                    "parallelism": "single GPU"},
         "scaling": "strong",
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "apply_kernel",
-                     "kernel_us": round(per_launch_s * 1e6, 2), "algorithmic_bytes_per_launch": int(algo),
-                     "launches_timed": int(launches),
-                     "note": "algorithmic bytes are those of the reference's full-rescan formulation at N_0"},
+        "roofline": check_frac({"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "one merge step, all of its kernels",
+                     "kernel_us": round(per_merge_s * 1e6, 2), "algorithmic_bytes_per_launch": int(algo),
+                     "launches_timed": int(len(lefts) * len(times)),
+                     "note": "algorithmic bytes are the reference's full-rescan formulation (12 N_t + 8 W); effective rate, not HBM traffic"}),
         "cpu_baseline": {"value": round(cpu_s / sample * 1000, 3), "unit": "s/1k-merges", "cores": 1, "kind": "port",
                          "sample": "first %d merges of the same run through oracle/swt_oracle.c (full recount per merge)" % sample},
-        "final_symbols": info["n_symbols"],
+        "final_symbols": info["n_symbols"], "parity_merges_checked": sample,
     }
 
 
@@ -546,21 +713,22 @@ def bench_wp_train(args, torch, dist, rank, world, local):
     cpu_s = time.perf_counter() - t1
     if [tuple(m) for m in tr.merges_list] != [tuple(m) for m in order[:sample]]:
         raise SystemExit("PARITY FAILURE: device merges differ from the oracle on the first %d merges" % sample)
-    algo = 16.0 * n0 + 8.0 * w0  # the reference's formulation: pair pass + symbol pass + rewrite read/write, per merge
-    per_launch_s = kernel_ms / 1e3 / max(launches, 1)
-    achieved = algo / per_launch_s / 1e9 if per_launch_s else 0.0
+    n_final = int(info["n_symbols"])
+    algo = 16.0 * (n0 + n_final) / 2.0 + 8.0 * w0  # the reference's formulation: pair pass + symbol pass + rewrite read/write, per merge
+    per_merge_s = kernel_ms / 1e3 / max(len(times), 1) / max(len(order), 1)
+    achieved = algo / per_merge_s / 1e9 if per_merge_s else 0.0
     elapsed = sum(times)
     return {
         "metric": "WordPiece train seconds per 1k merges", "value": round(elapsed / len(times) / max(len(order), 1) * 1000, 4),
         "unit": "s/1k-merges", "higher_is_better": False, "ms_per_step": round(elapsed / len(times) * 1e3, 3), "dtype": "u32+f64 score",
-        "config": {"workload": "NaiveWP.train on S85k to max_vocab=%d: %d initial symbols, %d merges, %d unique words, %d symbols"
-                               % (max_vocab, base, len(order), w0, n0), "parallelism": "single GPU"},
+        "config": {"workload": "NaiveWP.train on S85k to max_vocab=%d: %d initial symbols, %d merges, %d unique words, %d -> %d symbols"
+                               % (max_vocab, base, len(order), w0, n0, n_final), "parallelism": "single GPU"},
         "scaling": "strong",
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "apply_kernel",
-                     "kernel_us": round(per_launch_s * 1e6, 2), "algorithmic_bytes_per_launch": int(algo),
-                     "launches_timed": int(launches),
-                     "note": "algorithmic bytes are those of the reference's full-rescan formulation at N_0"},
+        "roofline": check_frac({"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "one merge step, all of its kernels",
+                     "kernel_us": round(per_merge_s * 1e6, 2), "algorithmic_bytes_per_launch": int(algo),
+                     "launches_timed": int(len(order) * len(times)),
+                     "note": "algorithmic bytes are the reference's full-rescan formulation; effective rate, not HBM traffic"}),
         "cpu_baseline": {"value": round(cpu_s / sample * 1000, 3), "unit": "s/1k-merges", "cores": 1, "kind": "port",
                          "sample": "first %d merges of the same run through oracle/swt_oracle.c (orc_wptrain_new + orc_train_run)" % sample},
         "final_symbols": info["n_symbols"],
@@ -572,20 +740,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="bpe_encode", choices=["bpe_encode", "wp_encode", "bpe_train", "wp_train", "bpe_train_1g", "mixed_encode"])
+    ap.add_argument("--workload", default="headline", choices=["headline", "bpe_encode", "wp_encode", "bpe_train", "wp_train", "bpe_train_1g", "mixed_encode"])
     ap.add_argument("--sentences", type=int, default=None, help="wp_encode: sentences per GPU (default 1,000,000); mixed_encode: per half (default 625,000)")
     ap.add_argument("--max-vocab", type=int, default=None, help="bpe_train: target vocabulary (default 8000)")
     ap.add_argument("--types", type=int, default=None, help="bpe_train_1g: word types (default 2,000,000)")
     ap.add_argument("--merges", type=int, default=None, help="bpe_train_1g: merges (default 32,000)")
+    ap.add_argument("--parity-merges", type=int, default=None, help="bpe_train_1g: merges compared with the oracle (default 200)")
+    ap.add_argument("--corpus", default="open", choices=["open", "lex"], help="bpe_train: S85k-open (default) or S85k-lex")
     args = ap.parse_args()
-    defaults = {"bpe_encode": (200, 20), "wp_encode": (20, 3), "bpe_train": (2, 1), "wp_train": (2, 1), "bpe_train_1g": (1, 0), "mixed_encode": (10, 2)}[args.workload]
+    defaults = {"headline": (100, 10), "bpe_encode": (200, 20), "wp_encode": (20, 3), "bpe_train": (2, 1), "wp_train": (2, 1), "bpe_train_1g": (1, 0), "mixed_encode": (10, 2)}[args.workload]
     if args.steps is None:
         args.steps = defaults[0]
     if args.warmup is None:
         args.warmup = defaults[1]
 
     torch, dist, rank, world, local = dist_setup(args.gpus)
-    fn = {"bpe_encode": bench_bpe_encode, "wp_encode": bench_wp_encode, "bpe_train": bench_bpe_train,
+    fn = {"headline": bench_headline, "bpe_encode": bench_bpe_encode, "wp_encode": bench_wp_encode, "bpe_train": bench_bpe_train,
           "wp_train": bench_wp_train, "bpe_train_1g": bench_bpe_train_words, "mixed_encode": bench_mixed_encode}[args.workload]
     res = fn(args, torch, dist, rank, world, local)
     line = {"metric": res.pop("metric"), "value": res.pop("value"), "unit": res.pop("unit"), "n_gpus": world,

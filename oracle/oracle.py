@@ -52,6 +52,8 @@ def lib():
             "orc_bpe_encode_word": (C.c_uint64, [C.c_void_p, _u32p, C.c_uint64, _u32p]),
             "orc_bpe_tokenize": (C.c_uint64, [C.c_void_p, _u32p, C.c_uint64, _u32p]),
             "orc_bpe_tokenize_batch": (C.c_uint64, [C.c_void_p, _u32p, _u64p, C.c_uint64, _u32p, _u64p]),
+            "orc_bpe_tokenize_batch_mt": (C.c_uint64, [C.c_void_p, _u32p, _u64p, C.c_uint64, _u32p, _u64p, C.c_int]),
+            "orc_wp_tokenize_batch_mt": (C.c_uint64, [C.c_void_p, _u32p, _u64p, C.c_uint64, _u32p, C.c_uint64, _u64p, _u8p, C.c_int]),
             "orc_train_new": (C.c_void_p, [_u32p, _u64p, C.c_uint64]),
             "orc_wptrain_new": (C.c_void_p, [_u32p, _u64p, C.c_uint64]),
             "orc_train_new_words": (C.c_void_p, [_u32p, _u64p, _u32p, C.c_uint64]),
@@ -185,6 +187,14 @@ class OracleBPE:
         out = np.zeros(max(blob.size, 1), dtype=np.uint32)
         out_off = np.zeros(len(texts) + 1, dtype=np.uint64)
         lib().orc_bpe_tokenize_batch(self._h, _p32(blob), _p64(off), len(texts), _p32(out), _p64(out_off))
+        return out[:int(out_off[-1])], out_off
+
+    def tokenize_packed_mt(self, blob, off, n_threads):
+        """already lowercased + packed (pack()) -> (ids, offsets) over n_threads host threads (cpu_baseline, all cores)"""
+        n = int(off.size - 1)
+        out = np.zeros(max(blob.size, 1), dtype=np.uint32)
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        lib().orc_bpe_tokenize_batch_mt(self._h, _p32(blob), _p64(off), n, _p32(out), _p64(out_off), int(n_threads))
         return out[:int(out_off[-1])], out_off
 
 
@@ -323,3 +333,15 @@ class OracleWP:
                                           _p64(out_off), status.ctypes.data_as(_u8p))
         assert tot <= cap
         return out[:tot], out_off, status[:len(texts)]
+
+    def tokenize_packed_mt(self, blob, off, n_threads):
+        """already lowercased + packed -> (ids, offsets, status) over n_threads host threads"""
+        n = int(off.size - 1)
+        cap = 4 * blob.size + 64 * n + 64
+        out = np.zeros(cap, dtype=np.uint32)
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        status = np.zeros(max(n, 1), dtype=np.uint8)
+        tot = lib().orc_wp_tokenize_batch_mt(self._h, _p32(blob), _p64(off), n, _p32(out), cap, _p64(out_off),
+                                             status.ctypes.data_as(_u8p), int(n_threads))
+        assert tot <= cap
+        return out[:tot], out_off, status[:n]

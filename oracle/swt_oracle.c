@@ -736,3 +736,83 @@ int64_t orc_wp_corner(const orc_wp *w, uint32_t *out, uint64_t cap) {
   for (uint32_t k = 0; k < w->corner.n && k < cap; k++) out[k] = w->corner.p[k];
   return (int64_t)w->corner.n;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* All-host-cores form of the two batch encoders, for bench.py's cpu_baseline ("1 thread and all host cores", SURVEY.md
+ * section 8d).  Sentences are independent (source/bpe.py:245-249, source/wordpiece.py:233-270 keep no state across calls):
+ * thread k encodes a contiguous range into a buffer of its own, then the ranges are concatenated in order -- the result
+ * is the single-thread result, byte for byte. */
+typedef struct {
+  const orc_bpe *bpe; const orc_wp *wp;
+  const uint32_t *text; const uint64_t *sent_off;
+  uint64_t lo, hi;
+  uint32_t *buf; uint64_t cap, n_tok;
+  uint64_t *cnt;     /* tokens per sentence, global array */
+  uint8_t *status;   /* global array or NULL */
+} mt_job;
+
+static void *mt_worker(void *arg) {
+  mt_job *j = (mt_job *)arg;
+  uint64_t nt = 0;
+  for (uint64_t s = j->lo; s < j->hi; s++) {
+    const uint32_t *p = j->text + j->sent_off[s];
+    uint64_t n = j->sent_off[s + 1] - j->sent_off[s], k;
+    if (j->bpe) {
+      k = orc_bpe_tokenize(j->bpe, p, n, j->buf + nt);
+    } else {
+      int st;
+      k = orc_wp_tokenize(j->wp, p, n, j->buf + nt, j->cap - nt, &st);
+      if (j->status) j->status[s] = (uint8_t)st;
+      if (st != ORC_WP_OK) k = 0;
+    }
+    j->cnt[s] = k;
+    nt += k;
+  }
+  j->n_tok = nt;
+  return NULL;
+}
+
+static uint64_t mt_run(const orc_bpe *bpe, const orc_wp *wp, const uint32_t *text, const uint64_t *sent_off, uint64_t n_sent,
+                       uint32_t *out, uint64_t out_cap, uint64_t *out_off, uint8_t *status, int n_threads) {
+  if (n_threads < 1) n_threads = 1;
+  if ((uint64_t)n_threads > n_sent) n_threads = n_sent ? (int)n_sent : 1;
+  mt_job *jobs = (mt_job *)calloc((size_t)n_threads, sizeof *jobs);
+  pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof *th);
+  uint64_t *cnt = (uint64_t *)calloc(n_sent + 1, 8);
+  /* ranges of about equal text, so the threads finish together */
+  uint64_t total = sent_off[n_sent] - sent_off[0], s = 0;
+  for (int k = 0; k < n_threads; k++) {
+    mt_job *j = &jobs[k];
+    j->bpe = bpe; j->wp = wp; j->text = text; j->sent_off = sent_off; j->cnt = cnt; j->status = status;
+    j->lo = s;
+    uint64_t want = sent_off[0] + total * (uint64_t)(k + 1) / (uint64_t)n_threads;
+    while (s < n_sent && (sent_off[s + 1] <= want || k == n_threads - 1)) s++;
+    j->hi = s;
+    j->cap = 4 * (sent_off[j->hi] - sent_off[j->lo]) + 64 * (j->hi - j->lo) + 64; /* the bound oracle.py's single-thread wrapper uses */
+    j->buf = (uint32_t *)malloc(j->cap * 4);
+  }
+  for (int k = 0; k < n_threads; k++) pthread_create(&th[k], NULL, mt_worker, &jobs[k]);
+  uint64_t nt = 0;
+  for (int k = 0; k < n_threads; k++) {
+    pthread_join(th[k], NULL);
+    uint64_t room = nt < out_cap ? out_cap - nt : 0, n = jobs[k].n_tok < room ? jobs[k].n_tok : room;
+    if (n) memcpy(out + nt, jobs[k].buf, n * 4);
+    nt += jobs[k].n_tok;
+    free(jobs[k].buf);
+  }
+  uint64_t o = 0;
+  for (uint64_t q = 0; q < n_sent; q++) { out_off[q] = o; o += cnt[q]; }
+  out_off[n_sent] = o;
+  free(cnt); free(th); free(jobs);
+  return nt;
+}
+
+uint64_t orc_bpe_tokenize_batch_mt(const orc_bpe *m, const uint32_t *text, const uint64_t *sent_off, uint64_t n_sent,
+                                   uint32_t *out, uint64_t *out_off, int n_threads) {
+  return mt_run(m, NULL, text, sent_off, n_sent, out, ~0ull, out_off, NULL, n_threads);
+}
+
+uint64_t orc_wp_tokenize_batch_mt(const orc_wp *w, const uint32_t *text, const uint64_t *sent_off, uint64_t n_sent,
+                                  uint32_t *out, uint64_t out_cap, uint64_t *out_off, uint8_t *status, int n_threads) {
+  return mt_run(NULL, w, text, sent_off, n_sent, out, out_cap, out_off, status, n_threads);
+}

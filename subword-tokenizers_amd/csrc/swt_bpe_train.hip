@@ -846,18 +846,18 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
     const unsigned g = grid_for(cap, 256 * 8, kArgBlocks);  // 8 counts per thread: 4 double loads
     const unsigned gw = grid_for(t->n_words ? t->n_words : 1, kTrainThreads * 8, 256);
     SWT_HIP(hipMemsetAsync(t->d_halt, 0, 8, 0));
+    prof_begin(0);  // one bracket around the whole batch of merge steps: bench.py divides by the merges done
     for (uint32_t i = 0; i < k; i++) {
       hipLaunchKernelGGL(argmax_kernel, dim3(g), dim3(256), 0, 0, t->T.keys, t->T.cnt, cap, t->d_parts, ticket, t->d_res,
                          (const long long *)t->d_sfreq);
       hipLaunchKernelGGL(first_pos_kernel, dim3(gw), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff, t->d_wlen, t->n_words, t->T,
                          t->d_res, t->d_cmd, t->d_steplog, i, first_merged + done + i, ticket2, t->d_sfreq);
-      prof_begin(0);
       if (t->n_words)
         hipLaunchKernelGGL(apply_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff,
                            t->d_wlen, t->d_freq, t->n_words, 0u, 0u, 0u, t->T, t->d_res, (unsigned long long *)nullptr,
                            (long long *)nullptr, (uint64_t)0, (const StepCmd *)t->d_cmd, t->d_sfreq);
-      prof_end(0);
     }
+    prof_end(0);
     SWT_HIP(hipGetLastError());
     SWT_HIP(hipMemcpy(hlog.data(), t->d_steplog, k * sizeof(StepLog), hipMemcpyDeviceToHost));
     if ((rc = sync_result(t))) return rc;

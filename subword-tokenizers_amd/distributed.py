@@ -247,3 +247,13 @@ def reduce_scalar(dist, value: float, op: str, device):
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op={"max": dist.ReduceOp.MAX, "sum": dist.ReduceOp.SUM}[op])
     return float(t.item())
+
+
+def train_sharded(corpus: List[str], max_vocab: int, rank: int, world: int, dist):
+    """bench.py's N > 1 training leg: this rank's shard of `corpus` through ShardedBpeTrainer over torch.distributed
+    (backend "nccl" = RCCL).  -> (merges_list, trainer info of this rank)"""
+    tr = ShardedBpeTrainer.from_corpus(corpus, rank, world, TorchGroup(dist, "cuda"))
+    merges = [tuple(m) for m in tr.train(max_vocab)]
+    info = tr.engine.t.info()
+    tr.engine.t.close()
+    return merges, info

@@ -148,6 +148,126 @@ def s85k(n=85000, seed=85000):
     return sentences(n, seed)
 
 
+# ---- S85k-open: SURVEY.md section 8(d)2 to the letter -------------------------------------------------------------------
+# EVERY word is drawn from the char-trigram model fit on train-5K's lowercase words (frequency-weighted), so unseen word
+# types keep appearing as the corpus grows (an open vocabulary); sentence lengths and punctuation marks are train-5K's
+# empirical distributions.  Vectorised: all words of the corpus advance one character per numpy step.
+
+@lru_cache(maxsize=None)
+def _trigram_tables():
+    """Dense form of the trigram model: alphabet (index 0 = '^' padding, last = '$' end), cum[ctx0 * A + ctx1, next]."""
+    words, _, _ = _t5k_stats()
+    chars = sorted({ch for w in words for ch in w})
+    alpha = ["^"] + chars + ["$"]
+    idx = {c: i for i, c in enumerate(alpha)}
+    A = len(alpha)
+    cnt = np.zeros((A * A, A), dtype=np.float64)
+    for w, f in words.items():
+        p = [0, 0] + [idx[c] for c in w] + [A - 1]
+        for i in range(len(p) - 2):
+            cnt[p[i] * A + p[i + 1], p[i + 2]] += f
+    tot = cnt.sum(axis=1, keepdims=True)
+    tot[tot == 0] = 1.0
+    cum = np.cumsum(cnt / tot, axis=1)
+    cum[:, -1] = 1.0
+    return alpha, cum
+
+
+def _sample_words_trigram(rng, n, max_len=24):
+    """n words (list[str], none empty) from the trigram model."""
+    alpha, cum = _trigram_tables()
+    A = len(alpha)
+    out = np.zeros((n, max_len), dtype=np.int32)
+    lens = np.zeros(n, dtype=np.int32)
+    c0 = np.zeros(n, dtype=np.int64)
+    c1 = np.zeros(n, dtype=np.int64)
+    alive = np.arange(n)
+    flat = (cum + np.arange(A * A, dtype=np.float64)[:, None]).ravel()
+    for step in range(max_len):
+        if alive.size == 0:
+            break
+        # inverse CDF of every live word's context in one searchsorted: row r of cum shifted to [r, r + 1]
+        ctx = c0[alive] * A + c1[alive]
+        nxt = np.searchsorted(flat, ctx + rng.random(alive.size) * (1.0 - 1e-12), side="right") - ctx * A
+        if step == 0:  # an empty word is not a word: redraw the end marker as the most likely first character
+            first = cum[0]
+            best = int(np.argmax(np.diff(np.concatenate([[0.0], first[:-1]]))))
+            nxt[nxt >= A - 1] = best
+        nxt = np.minimum(nxt, A - 1)
+        go = nxt < A - 1
+        sel = alive[go]
+        out[sel, step] = nxt[go]
+        lens[sel] = step + 1
+        c0[sel] = c1[sel]
+        c1[sel] = nxt[go]
+        alive = sel
+    table = np.array([ord(c) for c in alpha], dtype=np.uint32)
+    cps = table[out]
+    blob = cps.astype("<u4").tobytes().decode("utf-32-le")
+    return [blob[i * max_len:i * max_len + int(lens[i])] for i in range(n)]
+
+
+def sentences_open(n, seed):
+    """n sentences: train-5K's sentence-length distribution and punctuation marks, every word trigram-sampled."""
+    _, puncts, lengths = _t5k_stats()
+    rng = random.Random(seed)
+    nrng = np.random.default_rng(seed)
+    pun_chars = list(puncts.keys())
+    pun_cum = np.cumsum(list(puncts.values())).tolist()
+    words_total = sum(_t5k_stats()[0].values())
+    p_punct = sum(puncts.values()) / max(words_total, 1)
+    targets = rng.choices(lengths, k=n)
+    need = int(sum(targets) / 4.8) + 2 * n + 1024
+    pool = _sample_words_trigram(nrng, need)
+    ppool = rng.choices(pun_chars, cum_weights=pun_cum, k=need)
+    coin = nrng.random(need)
+    out = []
+    k = 0
+    for t in targets:
+        parts = []
+        ln = 0
+        while ln < t:
+            if k == len(pool):  # the estimate fell short: top the three pools up
+                more = max(need // 8, 1024)
+                pool += _sample_words_trigram(nrng, more)
+                ppool += rng.choices(pun_chars, cum_weights=pun_cum, k=more)
+                coin = np.concatenate([coin, nrng.random(more)])
+            w = pool[k]
+            if coin[k] < p_punct:
+                w += ppool[k]
+            k += 1
+            parts.append(w)
+            ln += len(w) + 1
+        s = " ".join(parts)
+        out.append(s[:1].upper() + s[1:])
+    return out
+
+
+@lru_cache(maxsize=2)
+def s85k_open(n=85000, seed=85000):
+    """S85k-open: the section 8(d)2 stand-in for data/train-85k.json with an OPEN vocabulary (every word trigram-sampled)."""
+    return sentences_open(n, seed)
+
+
+def word_stats(sents):
+    """(words, distinct words) of the pre-tokenizer split approximated on the host: maximal alnum runs + single marks."""
+    c = Counter()
+    for s in sents:
+        cur = []
+        for ch in s.lower():
+            if ch.isalnum():
+                cur.append(ch)
+            else:
+                if cur:
+                    c["".join(cur)] += 1
+                    cur = []
+                if not ch.isspace():
+                    c[ch] += 1
+        if cur:
+            c["".join(cur)] += 1
+    return sum(c.values()), len(c)
+
+
 @lru_cache(maxsize=None)
 def v30k(seed=30000, n_new=10000):
     """V30k: the pretrained 20,000-token vocabulary + n_new prefixes / '##' suffixes of S85k words (config 3)."""
