@@ -62,7 +62,7 @@ int swt_device_count(void);
 /* multiprocessor count / name of the selected device (for launch sizing and reports) */
 int swt_device_info(int *n_cu, char *name, size_t name_cap);
 
-/* Kernel timing for bench.py's roofline line.  on = 1: every launch of a path's DOMINANT kernel (bpe_encode_kernel,
+/* Kernel timing for bench.py's roofline line (state of the CALLING THREAD, like the error text).  on = 1: every launch of a path's DOMINANT kernel (bpe_encode_kernel,
  * wp_encode_kernel, the training apply/argmax pair) is bracketed by two HIP events on the stream it is launched on;
  * on = 2: the bracket spans all kernels of one call instead (first launch .. last launch); 0 = off.
  * swt_profile_read waits for the events, returns the summed elapsed milliseconds and the number of brackets since
@@ -85,11 +85,16 @@ int swt_utf8_prepare(uint8_t *text, uint64_t n_bytes, const uint64_t *cp_off, ui
 int swt_utf8_lower_dev(uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off, uint64_t n_sent, uint8_t *d_need_host,
                        void *stream);
 
-/* Diagnostics and test switches.  which = 0: bit mask of phases the BPE encode kernel skips (ablation timing; results are
- * wrong while set); 1: bit 0 = never use the word-level dedup, bit 1 = use it whatever the batch size; 2: ablation of the
- * dedup front kernel; 3: tile size of FastBPE's unique-word pass; 4: log2 of the dedup word table's slots (tests: a tiny
- * table makes words overflow it; results stay exact). */
-int swt_debug_knob(int which, int value);
+/* Per-handle options of the two encoders (swt_bpe_table_set_option / swt_wp_trie_set_option).  Every choice gives the same
+ * output; they pick the path, for tests and measurements.
+ *   SWT_OPT_DEDUP             0 (default): batches above a size threshold encode each DISTINCT word once (word-level dedup);
+ *                             1: never; 2: always
+ *   SWT_OPT_DEDUP_TABLE_BITS  log2 of the dedup word table's slots, 4..24; 0 (default): sized from the batch.  A tiny table
+ *                             makes words overflow into their own slots; results stay exact
+ *   SWT_OPT_UNIQUE_TILE       (FastBPE) tile size of the pass over the unique words: 0 (default), 64 or 256 */
+#define SWT_OPT_DEDUP 1
+#define SWT_OPT_DEDUP_TABLE_BITS 2
+#define SWT_OPT_UNIQUE_TILE 3
 
 /* Code-point classes compiled into the library (fixture data probed from the wheel/interpreter the
  * reference runs on; tools/gen_unicode_tables.py).  bit0 pre-tokenizer whitespace, bit1 pre-tokenizer
@@ -112,6 +117,7 @@ typedef struct swt_bpe_table swt_bpe_table;
 int swt_bpe_table_create(const uint32_t *left, const uint32_t *right, const uint32_t *merged,
                          uint32_t n_merges, swt_bpe_table **out);
 void swt_bpe_table_destroy(swt_bpe_table *t);
+int swt_bpe_table_set_option(swt_bpe_table *t, int option, int value);
 
 /* Host-buffer form: copies in, encodes on the device, copies out.
  *   text[n_bytes], sent_off[n_sent+1] -> out_ids[<= out_cap], out_off[n_sent+1], *n_tokens
@@ -139,6 +145,7 @@ typedef struct swt_wp_trie swt_wp_trie;
 /* vocabulary as UTF-32 code points + n_vocab+1 offsets; token id = index (first wins on duplicates) */
 int swt_wp_trie_create(const uint32_t *vocab_cps, const uint64_t *vocab_off, uint32_t n_vocab, swt_wp_trie **out);
 void swt_wp_trie_destroy(swt_wp_trie *t);
+int swt_wp_trie_set_option(swt_wp_trie *t, int option, int value);
 int swt_wp_trie_stats(const swt_wp_trie *t, uint32_t *n_nodes, uint32_t *n_edges, uint32_t *n_pops);
 /* NaiveWP.encode_word("##") evaluated once at build: returns its length in ids (copied to out up to
  * cap), or -1 when the reference never returns from it. */
@@ -162,9 +169,11 @@ int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, c
  *
  * The caller keeps the string set and the stop test (`len(vocab) < max_vocab`, source/bpe.py:88,103):
  *   swt_bpe_train_create*  ->  loop { swt_bpe_train_best; intern(left+right); swt_bpe_train_apply }.
- * Device state: the unique-word symbol stream (uint32), word offsets/lengths/frequencies, and the pair
- * histogram (hash table of 64-bit pair keys with 64-bit counts) which is built once and then updated
- * incrementally by every merge -- the same counts the reference recomputes from scratch each round.
+ * Device state: the unique-word symbol stream (uint32; a merge leaves a hole, addresses are stable), word offsets and
+ * frequencies, the pair histogram (hash table of 64-bit pair keys with 64-bit counts) which is built once and then updated
+ * incrementally by every merge -- the same counts the reference recomputes from scratch each round -- an inverted index
+ * pair -> words so that a merge visits only the words that hold it, and the list of high-count candidates the argmax scans.
+ * All of a trainer's work is enqueued on one stream (the legacy default stream).
  */
 typedef struct swt_bpe_trainer swt_bpe_trainer;
 
@@ -197,8 +206,7 @@ int swt_bpe_train_base_symbols(const swt_bpe_trainer *t, uint32_t *out, uint32_t
  * *n_tied = number of pairs holding the maximum.  When it is 1, (left,right) is that pair and *first_pos is
  * ~0.  When it is > 1 the tie is broken by the earliest (word, position) in THIS handle's stream:
  * (left,right) is the pair found there and *first_pos = pos_base + its stream position; if none of the tied
- * pairs occurs in this shard, *first_pos = ~0 and left = right = 0xFFFFFFFF.  Sharded callers keep the
- * (first_pos, left, right) of the rank with the smallest first_pos. */
+ * pairs occurs in this handle's stream, *first_pos = ~0 and left = right = 0xFFFFFFFF. */
 int swt_bpe_train_best(swt_bpe_trainer *t, uint32_t *left, uint32_t *right, uint64_t *count, uint64_t *n_tied,
                        uint64_t *first_pos);
 /* Replace every L->R non-overlapping occurrence of (left,right) by merged (source/bpe.py:25-48,
@@ -216,15 +224,44 @@ int swt_bpe_train_export(swt_bpe_trainer *t, uint32_t *syms, uint64_t syms_cap, 
 /* Copies the histogram back: up to cap (key = left<<32|right, count) entries with count > 0. */
 int swt_bpe_train_histogram(swt_bpe_trainer *t, uint64_t *keys, uint64_t *counts, uint64_t cap, uint64_t *n);
 
-/* -- sharded training (one process per GPU; the caller moves the buffers with RCCL) --
- * Every rank keeps the histogram of the WHOLE corpus: after create, ranks exchange their local
- * histograms once (export_local / add_remote); after every apply they exchange the delta lists the
- * merge produced (take_deltas on each rank, all-gather, add_remote of the other ranks' lists).
- * The first take_deltas call switches the delta log on and returns the whole local histogram. */
-int swt_bpe_train_take_deltas(swt_bpe_trainer *t, uint64_t *d_keys, int64_t *d_vals, uint64_t cap, uint64_t *n,
-                              void *stream);
-int swt_bpe_train_add_remote(swt_bpe_trainer *t, const uint64_t *d_keys, const int64_t *d_vals, uint64_t n,
-                             void *stream);
+/* Diagnostics of the trainer's machinery (tests, bench.py): out[0..n) = re-plans of the candidate threshold so far, the
+ * threshold theta (0: full-table argmax), candidate list length, inverted-index log entries, pair-table slots, state flags
+ * (bit 0: the index was abandoned for whole-stream applies), steps enqueued, distinct keys in the table. */
+int swt_bpe_train_stats(const swt_bpe_trainer *t, uint64_t *out, uint32_t n);
+
+/* One row per merge performed by swt_bpe_train_run(_sharded) so far: rows[4 i ..] = the winning count (score bits for
+ * WordPiece), the number of pairs that held that maximum (> 1: the first-occurrence tie-break ran), the candidate list
+ * length, and the live symbols N_t before the merge (what the reference would have rescanned).
+ * rows may be NULL to query *n_rows. */
+int swt_bpe_train_trace(const swt_bpe_trainer *t, uint64_t *rows, uint64_t cap_rows, uint64_t *n_rows);
+
+/* ------------------------------------------------------------------------------------------------
+ * Corpus-sharded BPE training, one process per GPU over RCCL: the multi-GPU form of the merge loop of
+ * source/bpe.py:88-111 (the reference itself has no parallelism).  Every rank builds a trainer from ITS contiguous range of
+ * sentences (swt_bpe_train_create_text) and keeps the pair histogram of the whole corpus; per merge the runner issues ONE
+ * fixed-size ncclAllGather of packed (pair, delta) records and ONE 16-byte all-gather for the first-occurrence tie-break
+ * (source/bpe.py:102; ranks are ordered by their sentence ranges), enqueued on the training stream with no host round trip,
+ * up to 256 merges per call into the device.
+ *
+ *   rank 0: swt_dist_unique_id(id) -> the caller hands the 128 bytes to every rank (torch.distributed, MPI, a file ...)
+ *   every rank: swt_init(local device); swt_dist_init(rank, world, id, &comm);
+ *               swt_bpe_train_create_text(shard) -> t;  swt_bpe_train_shard_begin(&t, 1, comm, base, cap, &n_base);
+ *               loop { swt_bpe_train_run_sharded(&t, 1, comm, k, first_merged, left, right, count, &n_done); intern strings }
+ * The outputs are identical on every rank.  swt_dist_init_local makes a loop-back communicator whose `world` ranks are all
+ * trainers of the calling process (trainers[r] = rank r; device copies instead of RCCL): the same runner on one GPU. */
+typedef struct swt_dist swt_dist;
+int swt_dist_unique_id(uint8_t *out128);
+int swt_dist_init(int rank, int world, const uint8_t *unique_id128, swt_dist **out);
+int swt_dist_init_local(int world, swt_dist **out);
+void swt_dist_destroy(swt_dist *d);
+int swt_dist_info(const swt_dist *d, int *rank, int *world, int *is_local);
+/* Enters sharded mode: gathers the distinct initial symbols of ALL shards (the initial vocab, source/bpe.py:75; written to
+ * base_out[0..*n_base) ascending when base_out is not NULL) and reduces the local histograms into every replica. */
+int swt_bpe_train_shard_begin(swt_bpe_trainer **trainers, uint32_t n_local, swt_dist *d, uint32_t *base_out, uint32_t base_cap,
+                              uint32_t *n_base);
+/* As swt_bpe_train_run, over all shards. */
+int swt_bpe_train_run_sharded(swt_bpe_trainer **trainers, uint32_t n_local, swt_dist *d, uint32_t max_steps, uint32_t first_merged,
+                              uint32_t *left, uint32_t *right, uint64_t *count, uint32_t *n_done);
 #ifdef __cplusplus
 }
 #endif

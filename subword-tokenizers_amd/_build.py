@@ -12,8 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "_lib")
 LIB_PATH = os.path.join(LIB_DIR, "libswt_hip.so")
-SOURCES = ["swt_core.hip", "swt_tile.hip", "swt_dedup.hip", "swt_bpe_encode.hip", "swt_wp.hip", "swt_words.hip", "swt_bpe_train.hip", "swt_lower.hip"]
-HEADERS = ["swt_common.h", "swt_tile.h", "swt_dedup.h", "swt_words.h", "unicode_classes.inc", "unicode_lower.inc", os.path.join("..", "..", "include", "swt.h")]
+SOURCES = ["swt_core.hip", "swt_tile.hip", "swt_dedup.hip", "swt_bpe_encode.hip", "swt_wp.hip", "swt_words.hip", "swt_bpe_train.hip", "swt_dist.hip", "swt_lower.hip"]
+HEADERS = ["swt_common.h", "swt_tile.h", "swt_dedup.h", "swt_words.h", "swt_train.h", "unicode_classes.inc", "unicode_lower.inc", os.path.join("..", "..", "include", "swt.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -58,7 +58,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out))
         if verbose and out.strip():
             print(out)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout)

@@ -35,12 +35,13 @@ SIGNATURES = {
     "swt_init": (C.c_int, [C.c_int]),
     "swt_device_count": (C.c_int, []),
     "swt_device_info": (C.c_int, [C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
-    "swt_debug_knob": (C.c_int, [C.c_int, C.c_int]),
     "swt_profile_enable": (C.c_int, [C.c_int]),
     "swt_profile_read": (C.c_int, [C.POINTER(C.c_double), u64p]),
     "swt_class_of": (C.c_uint, [C.c_uint32]),
     "swt_bpe_table_create": (C.c_int, [u32p, u32p, u32p, C.c_uint32, vpp]),
     "swt_bpe_table_destroy": (None, [C.c_void_p]),
+    "swt_bpe_table_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "swt_wp_trie_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "swt_bpe_encode": (C.c_int, [C.c_void_p, u8p, u64p, C.c_uint64, u32p, C.c_uint64, u64p, u64p, C.c_uint32]),
     "swt_bpe_encode_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_uint32, C.c_void_p]),
@@ -69,8 +70,15 @@ SIGNATURES = {
     "swt_bpe_train_run": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u32p, u32p, u64p, u32p]),
     "swt_bpe_train_export": (C.c_int, [C.c_void_p, u32p, C.c_uint64, u64p, u32p]),
     "swt_bpe_train_histogram": (C.c_int, [C.c_void_p, u64p, u64p, C.c_uint64, u64p]),
-    "swt_bpe_train_take_deltas": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, u64p, C.c_void_p]),
-    "swt_bpe_train_add_remote": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "swt_bpe_train_stats": (C.c_int, [C.c_void_p, u64p, C.c_uint32]),
+    "swt_bpe_train_trace": (C.c_int, [C.c_void_p, u64p, C.c_uint64, u64p]),
+    "swt_dist_unique_id": (C.c_int, [u8p]),
+    "swt_dist_init": (C.c_int, [C.c_int, C.c_int, u8p, vpp]),
+    "swt_dist_init_local": (C.c_int, [C.c_int, vpp]),
+    "swt_dist_destroy": (None, [C.c_void_p]),
+    "swt_dist_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "swt_bpe_train_shard_begin": (C.c_int, [vpp, C.c_uint32, C.c_void_p, u32p, C.c_uint32, u32p]),
+    "swt_bpe_train_run_sharded": (C.c_int, [vpp, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, u32p, u32p, u64p, u32p]),
 }
 
 
@@ -138,8 +146,8 @@ def init(device=0):
     check(lib().swt_init(device))
 
 
-def debug_knob(which, value):
-    check(lib().swt_debug_knob(which, value))
+OPT_DEDUP, OPT_DEDUP_TABLE_BITS, OPT_UNIQUE_TILE = 1, 2, 3
+DEDUP_AUTO, DEDUP_NEVER, DEDUP_ALWAYS = 0, 1, 2
 
 
 def profile_enable(on=True):
@@ -237,6 +245,9 @@ class BpeTable:
 
     __del__ = close
 
+    def set_option(self, option, value):
+        check(lib().swt_bpe_table_set_option(self._h, option, value))
+
     def encode(self, text_u8, sent_off, flags=0):
         """host buffers in -> (ids uint32, offsets uint64[n+1])"""
         n_sent = int(sent_off.size - 1)
@@ -269,6 +280,9 @@ class WpTrie:
         self._h = None
 
     __del__ = close
+
+    def set_option(self, option, value):
+        check(lib().swt_wp_trie_set_option(self._h, option, value))
 
     def stats(self):
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
@@ -405,10 +419,74 @@ class BpeTrainer:
         check(lib().swt_bpe_train_histogram(self._h, ptr(keys, u64p), ptr(cnts, u64p), cap, C.byref(n)))
         return keys[:n.value], cnts[:n.value]
 
-    def take_deltas(self, d_keys, d_vals, cap, stream=0):
+    def step_trace(self):
+        """uint64[n_merges, 4]: winning count, pairs tied at it, candidate list length, live symbols before the merge"""
         n = C.c_uint64()
-        check(lib().swt_bpe_train_take_deltas(self._h, d_keys, d_vals, cap, C.byref(n), stream))
-        return n.value
+        check(lib().swt_bpe_train_trace(self._h, None, 0, C.byref(n)))
+        rows = np.zeros((max(n.value, 1), 4), dtype=np.uint64)
+        check(lib().swt_bpe_train_trace(self._h, ptr(rows, u64p), n.value, C.byref(n)))
+        return rows[:n.value]
 
-    def add_remote(self, d_keys, d_vals, n, stream=0):
-        check(lib().swt_bpe_train_add_remote(self._h, d_keys, d_vals, n, stream))
+    def stats(self):
+        out = np.zeros(8, dtype=np.uint64)
+        check(lib().swt_bpe_train_stats(self._h, ptr(out, u64p), 8))
+        names = ("replans", "theta", "candidates", "index_entries", "table_slots", "flags", "steps", "keys")
+        return dict(zip(names, map(int, out)))
+
+
+class Dist:
+    """Communicator of corpus-sharded training (swt_dist): RCCL between processes (one per GPU), or a loop-back whose ranks
+    are all trainers of this process (one-GPU tests)."""
+
+    def __init__(self, handle, rank, world, local):
+        self._h, self.rank, self.world, self.local = handle, rank, world, local
+
+    @staticmethod
+    def unique_id():
+        """128 bytes made by rank 0 (ncclGetUniqueId); hand them to every rank"""
+        buf = np.zeros(128, dtype=np.uint8)
+        check(lib().swt_dist_unique_id(ptr(buf, u8p)))
+        return buf
+
+    @classmethod
+    def rccl(cls, rank, world, unique_id):
+        uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        h = C.c_void_p()
+        check(lib().swt_dist_init(rank, world, ptr(uid, u8p), C.byref(h)))
+        return cls(h, rank, world, False)
+
+    @classmethod
+    def loopback(cls, world):
+        h = C.c_void_p()
+        check(lib().swt_dist_init_local(world, C.byref(h)))
+        return cls(h, 0, world, True)
+
+    def close(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.swt_dist_destroy(self._h)
+        self._h = None
+
+    __del__ = close
+
+    def _handles(self, trainers):
+        arr = (C.c_void_p * len(trainers))(*[t._h for t in trainers])
+        return C.cast(arr, vpp), arr
+
+    def shard_begin(self, trainers):
+        """-> the distinct initial symbols of the whole corpus (uint32, ascending)"""
+        hp, keep = self._handles(trainers)
+        out = np.zeros(0x110000 + 4096, dtype=np.uint32)
+        n = C.c_uint32()
+        check(lib().swt_bpe_train_shard_begin(hp, len(trainers), self._h, ptr(out, u32p), out.size, C.byref(n)))
+        return out[:n.value].copy()
+
+    def run(self, trainers, max_steps, first_merged):
+        """-> (left, right, count) of the merges done (fewer than max_steps: no pair was left)"""
+        hp, keep = self._handles(trainers)
+        left = np.zeros(max(max_steps, 1), dtype=np.uint32)
+        right = np.zeros(max(max_steps, 1), dtype=np.uint32)
+        count = np.zeros(max(max_steps, 1), dtype=np.uint64)
+        n = C.c_uint32()
+        check(lib().swt_bpe_train_run_sharded(hp, len(trainers), self._h, max_steps, first_merged, ptr(left, u32p), ptr(right, u32p),
+                                              ptr(count, u64p), C.byref(n)))
+        return left[:n.value], right[:n.value], count[:n.value]

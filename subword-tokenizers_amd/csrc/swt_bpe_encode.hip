@@ -604,6 +604,7 @@ struct swt_bpe_table {
   DedupEngine dd;
   PinnedBuf pin;       // small host calls: inputs and outputs staged in one pinned buffer, one copy each way
   DevBuf small_in, small_out;
+  int opt_unique_tile = 0;  // SWT_OPT_UNIQUE_TILE
 };
 
 static int bpe_upload(swt_bpe_table *t) {
@@ -625,7 +626,7 @@ static void launch_encode_kernel_as(swt_bpe_table *t, uint64_t n_tiles, const Ti
   hipLaunchKernelGGL((bpe_encode_kernel<Packed, Cap>), dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
                      ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, ws.scratch.as<uint32_t>(),
                      ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, DirectOut{nullptr, nullptr, 0},
-                     (uint32_t)debug_knob(0));
+                     (uint32_t)ablation_knob(0));
 }
 
 extern "C" {
@@ -673,6 +674,25 @@ int swt_bpe_table_create(const uint32_t *left, const uint32_t *right, const uint
       if (sl.key != kEmptyKey) sl.rank = (sl.rank << 16) | (sl.merged - SWT_SYM_BASE);
   *out = t;
   return SWT_OK;
+}
+
+int swt_bpe_table_set_option(swt_bpe_table *t, int option, int value) {
+  if (!t) return fail(SWT_ERR_INVALID, "null table");
+  switch (option) {
+    case SWT_OPT_DEDUP:
+      if (value < 0 || value > 2) return fail(SWT_ERR_INVALID, "SWT_OPT_DEDUP takes 0, 1 or 2");
+      t->dd.opt_mode = value;
+      return SWT_OK;
+    case SWT_OPT_DEDUP_TABLE_BITS:
+      if (value != 0 && (value < 4 || value > 24)) return fail(SWT_ERR_INVALID, "SWT_OPT_DEDUP_TABLE_BITS takes 0 or 4..24");
+      t->dd.opt_table_bits = (uint32_t)value;
+      return SWT_OK;
+    case SWT_OPT_UNIQUE_TILE:
+      if (value != 0 && value != 64 && value != 256) return fail(SWT_ERR_INVALID, "SWT_OPT_UNIQUE_TILE takes 0, 64 or 256");
+      t->opt_unique_tile = value;
+      return SWT_OK;
+  }
+  return fail(SWT_ERR_INVALID, "no such option");
 }
 
 void swt_bpe_table_destroy(swt_bpe_table *t) {
@@ -745,7 +765,7 @@ constexpr uint64_t kUMaxTiles = 8192;  // its launch size: 256 CUs x 32 single-w
 static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off, uint64_t n_sent,
                             uint32_t *d_out_ids, uint64_t *d_out_off, uint64_t *d_n_tokens, const uint8_t *d_cls, hipStream_t st) {
   int rc;
-  const uint32_t tile2 = debug_knob(3) == 256 ? 256u : (debug_knob(3) == 64 ? 64u : (uint32_t)kUTile);
+  const uint32_t tile2 = t->opt_unique_tile == 256 ? 256u : (t->opt_unique_tile == 64 ? 64u : (uint32_t)kUTile);
   uint64_t n_tiles2 = tile_count(n_bytes, tile2);  // the unique words together are no longer than the text
   if (n_tiles2 > kUMaxTiles) n_tiles2 = kUMaxTiles;
   if (n_bytes > kDedupMaxBytes) return 1;
@@ -782,7 +802,7 @@ int swt_bpe_encode_dev(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes
   }
   const bool raw = (flags & SWT_BPE_RAW_WORDS) != 0;
   // debug knob 1: bit 0 = never dedup, bit 1 = dedup whatever the batch size (tests)
-  if (!raw && !(flags & SWT_BPE_NO_DEDUP) && (n_bytes >= kDedupMinBytes || (debug_knob(1) & 2)) && !(debug_knob(1) & 1)) {
+  if (!raw && !(flags & SWT_BPE_NO_DEDUP) && (n_bytes >= kDedupMinBytes || t->dd.opt_mode == 2) && t->dd.opt_mode != 1) {
     rc = bpe_encode_dedup(t, d_text, n_bytes, d_sent_off, n_sent, d_out_ids, d_out_off, d_n_tokens, d_cls, st);
     if (rc <= 0) return rc;  // done, or a real error
   }

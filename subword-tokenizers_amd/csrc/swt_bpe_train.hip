@@ -1,54 +1,57 @@
-// swt_bpe_train.hip -- BPE training merge loop on gfx950.
+// swt_bpe_train.hip -- BPE / WordPiece training merge loop on gfx950.
 //
 // Replaces NaiveBPE.train's loop (FastBPE.train inherits it):
-//   word dedup + symbolisation   /root/reference/source/bpe.py:73-81   (host C++ here; device later)
+//   word dedup + symbolisation   /root/reference/source/bpe.py:73-81   (swt_words.hip, on the device)
 //   pair histogram               /root/reference/source/bpe.py:90-95
 //   argmax with first-seen tie   /root/reference/source/bpe.py:98-102
 //   merge-apply (_replace_pair)  /root/reference/source/bpe.py:25-48, 108-111
 //
-// Device state
-//   sym[]   packed uint32 symbol stream of the UNIQUE words, word w at [woff[w], woff[w]+wlen[w]); a merge
-//           rewrites the word in place (its slot keeps its offset, only wlen shrinks), so stream order = the
-//           reference's scan order and a position woff[w]+i is a valid first-occurrence key.
-//   pair histogram: open-addressing hash, keys[] (left<<32|right) + cnt[] (64-bit, weighted by word
-//           frequency).  Built once by a full scan, then kept exact incrementally: a merge only touches pairs
-//           adjacent to its occurrences, so each step subtracts the pairs it destroys and adds the pairs it
-//           creates (atomicAdd on the table) -- the same counts the reference recomputes from scratch.
-// Per merge: argmax over cnt[] (max via atomicMax, then tie census); only when the maximum is tied, one read-only
-// scan finds the earliest (word, position) among the tied pairs (bpe.py:102: Counter.most_common(1) returns
-// the first-inserted maximum).  One host round trip per merge: the caller owns the string set and the stop test.
+// The reference recounts every pair and rewrites every word on every merge.  Here NOTHING is rescanned per merge:
 //
-// WordPiece mode (NaiveWP.train, /root/reference/source/wordpiece.py:29-103): the same stream, histogram
-// and merge-apply; symbols are the word's first character and "##c" (= 0x110000 + c) for the others; a dense
+//   sym[]    packed uint32 symbol stream of the UNIQUE words, word w at [woff[w], woff[w+1]).  A merge writes the merged
+//            symbol over `left` and a HOLE over `right`: addresses never move, so (word, offset) is a stable first-occurrence
+//            key (bpe.py:102) and an index of word ids never goes stale by position.
+//   pair histogram   open-addressing hash keys[] (left<<32|right) + cnt[] (64-bit, weighted by word frequency), built once
+//            (LDS-staged per-wave pair counters, flushed with one global atomic per distinct key), then kept exact
+//            incrementally: a merge subtracts the pairs it destroys and adds the pairs it creates.
+//   inverted index   pair -> words that hold it.  Every occurrence of a pair (x, y) is created in ONE step -- the step that
+//            created the later-born of x and y -- and only disappears afterwards.  So the index is: a static table grouped by
+//            key for the pairs of initial symbols (k0), plus one log segment per merge step holding (tag, word) for every
+//            new-pair occurrence that step created.  apply_kernel visits only those words (a stale entry is a word that no
+//            longer holds the pair: skipped); a word is claimed by atomicMax on its stamp and rewritten by one lane.
+//   candidates   (BPE) the slots whose count is >= theta.  Counts only fall, except for the pairs a merge creates, whose
+//            count is caught as it crosses theta; so the maximum of the table is the maximum of the candidate list while
+//            that maximum stays >= theta.  The argmax scans a few thousand candidates instead of the table; when the list
+//            runs dry (or overflows) the step reports it and the host re-plans theta from a histogram of the counts.
+//            WordPiece scores rise and fall with the symbol frequencies, so that mode keeps the full-table argmax.
+//   tie-break    bpe.py:102: among the pairs holding the maximum, the one whose first occurrence in scan order comes first.
+//            Words are scanned from a cursor: while the maximum stays at one level c, every pair with count c lies at or
+//            after the word where the last tie-break found its winner (new pairs appear only in words a merge touched, and
+//            the cursor is pulled back to the first touched word), so a plateau of k tied pairs costs one sweep, not k.
+//
+// Per merge, enqueued back to back with no host round trip (swt_bpe_train_run, up to 256 merges per batch):
+//   cand_argmax (or argmax_full) -> tie_kernel -> decide_kernel -> apply_kernel
+// Workgroup partials are combined redundantly by the consumers (a kernel boundary is the barrier; no tickets, no
+// __threadfence chains).
+//
+// WordPiece mode (NaiveWP.train, /root/reference/source/wordpiece.py:29-103): the same stream, histogram,
+// index and merge-apply; symbols are the word's first character and "##c" (= 0x110000 + c) for the others; a dense
 // symbol-frequency array is kept exact beside the pair histogram, and the argmax key is the likelihood score
 // freq / (f_left * f_right) -- Python's int / int, i.e. the correctly rounded quotient -- compared as a bit pattern.
+//
+// Sharded training (one process per GPU, swt_dist.hip): every rank keeps the histogram of the WHOLE corpus.  apply_kernel
+// then accumulates its deltas per table slot in pend[] and lists the touched slots; the runner packs them into a fixed-size
+// record block, all-gathers the blocks (RCCL) and every rank adds every block to its replica.
 #include <algorithm>
-#include <unordered_map>
 
 #include "swt_common.h"
+#include "swt_train.h"
 #include "swt_words.h"
 
 namespace swt {
 
 constexpr int kTrainThreads = 256;
-constexpr int kArgBlocks = 1024;
-constexpr uint32_t kMaxRunSteps = 512;
-constexpr uint32_t kRunBatch = 256;
-
-struct TrainResult {
-  unsigned long long max_count;
-  unsigned long long n_tied;
-  unsigned long long best_pos;   // local stream position of the winner (kEmptyKey: none found locally)
-  unsigned long long best_key;   // a key with count == max (the winner when n_tied == 1)
-  unsigned long long n_used;     // distinct keys ever inserted in the table
-  unsigned long long n_log;      // delta-log entries of the last apply
-  unsigned long long n_syms;     // live symbols after the last apply
-  unsigned long long win_key;    // pair at best_pos (tie winner)
-};
-
-struct StepCmd {
-  uint32_t l, r, m, valid;
-};
+constexpr uint32_t kHole = 0xFFFFFFFFu;
 
 // ---- WordPiece score (wordpiece.py:84-87) --------------------------------------------------------------------------
 constexpr uint32_t kWpCont = 0x110000u;         // "##c" = kWpCont + c
@@ -86,40 +89,66 @@ __device__ __forceinline__ unsigned long long pair_value(unsigned long long key,
   if (!sfreq) return (unsigned long long)cnt;
   return wp_score_bits((unsigned long long)cnt, (unsigned long long)sfreq[key >> 32], (unsigned long long)sfreq[(uint32_t)key]);
 }
-struct StepLog {
-  uint32_t l, r;
-  unsigned long long count;
-  unsigned long long flag;  // 0 merged, 1 tied maximum (the host breaks the tie), 2 no pair left
-};
 
-struct PairTable {
-  unsigned long long *keys;
-  long long *cnt;
-  uint32_t bits;
-};
-
-__device__ __forceinline__ void table_add(const PairTable &T, unsigned long long key, long long delta, TrainResult *res) {
-  const uint32_t mask = (1u << T.bits) - 1u;
+// ---- pair table --------------------------------------------------------------------------------------------------------
+// Insert-or-find; returns the slot.  Keys are never removed (a rehash drops the dead ones).
+__device__ __forceinline__ uint32_t table_slot(const PairTable &T, unsigned long long key, TrainState *st) {
+  const uint32_t mask = (uint32_t)((1ull << T.bits) - 1ull);
   uint32_t h = hash_slot(key, T.bits);
   for (;;) {
     unsigned long long k = __hip_atomic_load(&T.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (k == kEmptyKey) {
       k = atomicCAS(&T.keys[h], kEmptyKey, key);
       if (k == kEmptyKey) {
-        atomicAdd(&res->n_used, 1ull);
+        atomicAdd(&st->n_used, 1ull);
         k = key;
       }
     }
-    if (k == key) {
-      atomicAdd(reinterpret_cast<unsigned long long *>(&T.cnt[h]), (unsigned long long)delta);
-      return;
-    }
+    if (k == key) return h;
     h = (h + 1) & mask;
   }
 }
 
+__device__ __forceinline__ void cand_push(const TrainCtx &C, uint32_t slot) {
+  // past the capacity the list has lost a candidate: n_cand says so, and the next argmax refuses to answer (the flag is not
+  // raised here: workgroups of the apply launch that is running must not see it change)
+  const unsigned long long k = atomicAdd(&C.st->n_cand, 1ull);
+  if (k < C.cand_cap) C.cand[k] = slot;
+}
+
+// count += delta with the candidate invariant kept: a count that crosses theta upwards joins the list (only the pairs a
+// merge creates ever rise)
+__device__ __forceinline__ void count_add(const TrainCtx &C, uint32_t slot, long long delta) {
+  if (C.cidx) {  // a listed pair keeps its compact copy in step
+    const uint32_t ci = C.cidx[slot];
+    if (ci != 0xFFFFFFFFu)
+      (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&C.ccnt[ci]), (unsigned long long)delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (delta > 0 && C.theta) {
+    const long long o = (long long)atomicAdd(reinterpret_cast<unsigned long long *>(&C.T.cnt[slot]), (unsigned long long)delta);
+    if (o < (long long)C.theta && o + delta >= (long long)C.theta) cand_push(C, slot);
+  } else {
+    (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&C.T.cnt[slot]), (unsigned long long)delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// one histogram delta of a merge: straight into the replica (single GPU), or into pend[] + the touched list (sharded: the
+// exchange adds every rank's record block, this rank's included, to every replica)
+__device__ __forceinline__ void table_add(const TrainCtx &C, unsigned long long key, long long delta) {
+  const uint32_t h = table_slot(C.T, key, C.st);
+  if (!C.pend) {
+    count_add(C, h, delta);
+    return;
+  }
+  atomicAdd(reinterpret_cast<unsigned long long *>(&C.pend[h]), (unsigned long long)delta);
+  if (atomicMax(&C.tstamp[h], C.step) < C.step) {
+    const unsigned long long k = atomicAdd(&C.st->n_touched, 1ull);
+    if (k < C.touched_cap) C.touched[k] = h;
+  }
+}
+
 __device__ __forceinline__ long long table_get(const PairTable &T, unsigned long long key) {
-  const uint32_t mask = (1u << T.bits) - 1u;
+  const uint32_t mask = (uint32_t)((1ull << T.bits) - 1ull);
   uint32_t h = hash_slot(key, T.bits);
   for (;;) {
     const unsigned long long k = T.keys[h];
@@ -136,45 +165,168 @@ __global__ void table_clear_kernel(unsigned long long *keys, long long *cnt, uin
   }
 }
 
-// bpe.py:90-95 -- every adjacent pair of every unique word, weighted by the word's frequency
+// ---- bpe.py:90-95 once -------------------------------------------------------------------------------------------------
+// Every adjacent pair of every unique word, weighted by the word's frequency.  One lane per word, one wave per run of 64
+// words; the wave's pair counters are staged in LDS (a 512-slot table per wave, linear probing): the pairs of natural text
+// are Zipfian, so most additions meet an LDS counter and only the distinct keys of a wave's words reach the global table,
+// one atomicAdd each.
+constexpr int kHistSlots = 512;
 __global__ __launch_bounds__(kTrainThreads) void hist_build_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
-                                                                   const uint32_t *__restrict__ wlen, const uint32_t *__restrict__ freq,
-                                                                   uint64_t n_words, PairTable T, TrainResult *res) {
+                                                                   const uint32_t *__restrict__ freq, uint64_t n_words, TrainCtx C) {
+  __shared__ unsigned long long lk[kTrainThreads / 64][kHistSlots];
+  __shared__ unsigned long long lc[kTrainThreads / 64][kHistSlots];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = lane; i < kHistSlots; i += 64) { lk[wave][i] = kEmptyKey; lc[wave][i] = 0; }
+  __syncthreads();
   const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= n_words) return;
-  const uint32_t n = wlen[w];
-  if (n < 2) return;
-  const uint32_t *s = sym + woff[w];
-  const long long f = freq[w];
-  uint32_t a = s[0];
-  for (uint32_t i = 1; i < n; i++) {
-    const uint32_t b = s[i];
-    table_add(T, pair_key(a, b), f, res);
-    a = b;
+  if (w < n_words) {
+    const uint64_t b0 = woff[w], b1 = woff[w + 1];
+    const unsigned long long f = freq[w];
+    uint32_t a = b0 < b1 ? sym[b0] : 0;
+    for (uint64_t i = b0 + 1; i < b1; i++) {
+      const uint32_t b = sym[i];
+      const unsigned long long key = pair_key(a, b);
+      a = b;
+      uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 55);  // 9 bits
+      bool done = false;
+      for (int probe = 0; probe < 8 && !done; probe++) {
+        unsigned long long k = lk[wave][h];
+        if (k == kEmptyKey) {
+          k = atomicCAS(&lk[wave][h], kEmptyKey, key);
+          if (k == kEmptyKey) k = key;
+        }
+        if (k == key) { atomicAdd(&lc[wave][h], f); done = true; }
+        h = (h + 1) & (kHistSlots - 1);
+      }
+      if (!done) count_add(C, table_slot(C.T, key, C.st), (long long)f);  // the wave's table is crowded: straight to global
+    }
+  }
+  __syncthreads();
+  for (int i = lane; i < kHistSlots; i += 64) {
+    const unsigned long long k = lk[wave][i];
+    if (k != kEmptyKey) count_add(C, table_slot(C.T, k, C.st), (long long)lc[wave][i]);
   }
 }
 
-struct ArgPart {
-  unsigned long long mx, cnt, key;
-};
+// ---- the static index of the initial pairs (k0) ------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t k0_find(const K0Index &K, unsigned long long key) {
+  const uint32_t mask = (uint32_t)((1ull << K.bits) - 1ull);
+  uint32_t h = hash_slot(key, K.bits);
+  for (;;) {
+    const unsigned long long k = K.keys[h];
+    if (k == key) return h;
+    if (k == kEmptyKey) return 0xFFFFFFFFu;
+    h = (h + 1) & mask;
+  }
+}
 
+// pass 0: occurrences per key; pass 1: fill the lists (start[] holds each list's base by then)
+__global__ __launch_bounds__(kTrainThreads) void k0_pass_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
+                                                                uint64_t n_words, K0Index K, int pass) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  const uint64_t b0 = woff[w], b1 = woff[w + 1];
+  if (b1 - b0 < 2) return;
+  uint32_t a = sym[b0];
+  for (uint64_t i = b0 + 1; i < b1; i++) {
+    const uint32_t b = sym[i];
+    const uint32_t h = k0_find(K, pair_key(a, b));
+    a = b;
+    if (h == 0xFFFFFFFFu) continue;
+    const uint32_t k = atomicAdd(&K.fill[h], 1u);
+    if (pass == 1) K.words[(uint64_t)K.start[h] + k] = (uint32_t)w;
+  }
+}
+
+// list bases by wave-aggregated allocation (the order of the lists is irrelevant): len[] = fill[] of pass 0
+__global__ __launch_bounds__(kTrainThreads) void k0_alloc_kernel(K0Index K, unsigned long long *cursor) {
+  const uint64_t cap = 1ull << K.bits;
+  const int lane = threadIdx.x & 63;
+  for (uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < cap; i0 += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = i0 + lane;
+    const uint32_t n = i < cap ? K.fill[i] : 0u;
+    uint32_t x = n;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    const uint32_t total = __shfl(x, 63);
+    unsigned long long base = 0;
+    if (lane == 0 && total) base = atomicAdd(cursor, (unsigned long long)total);
+    base = __shfl(base, 0);
+    if (i < cap) {
+      K.start[i] = (uint32_t)(base + x - n);
+      K.len[i] = n;
+      K.fill[i] = 0;
+    }
+  }
+}
+
+// ---- argmax ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void arg_combine(unsigned long long &m, unsigned long long &c, unsigned long long &k,
                                             unsigned long long m2, unsigned long long c2, unsigned long long k2) {
   if (m2 > m) { m = m2; c = c2; k = k2; }
   else if (m2 == m) { c += c2; k = k2 < k ? k2 : k; }
 }
 
-// bpe.py:98-102 in one launch: maximum count, how many pairs hold it, and the smallest such key.  Every workgroup
-// reduces its share of the table and publishes a partial; the last one to arrive (ticket) combines the partials
-// and resets the tie-break fields of the result.
-__global__ __launch_bounds__(256) void argmax_kernel(const unsigned long long *__restrict__ keys, const long long *__restrict__ cnt,
-                                                     uint64_t cap, ArgPart *__restrict__ parts, unsigned int *__restrict__ ticket,
-                                                     TrainResult *res, const long long *__restrict__ sfreq) {
+__device__ __forceinline__ void arg_wave_reduce(unsigned long long &m, unsigned long long &c, unsigned long long &k) {
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long m2 = __shfl_xor(m, d), c2 = __shfl_xor(c, d), k2 = __shfl_xor(k, d);
+    arg_combine(m, c, k, m2, c2, k2);
+  }
+}
+
+// the workgroup's (max, pairs holding it, smallest such key) -> parts[blockIdx.x]
+__device__ __forceinline__ void arg_publish(unsigned long long m, unsigned long long c, unsigned long long k, ArgPart *__restrict__ parts) {
   __shared__ unsigned long long sm[4], sc[4], sk[4];
-  __shared__ bool is_last;
+  arg_wave_reduce(m, c, k);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sm[wave] = m; sc[wave] = c; sk[wave] = k; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); w++) arg_combine(m, c, k, sm[w], sc[w], sk[w]);
+    parts[blockIdx.x].mx = m;
+    parts[blockIdx.x].cnt = c;
+    parts[blockIdx.x].key = k;
+  }
+}
+
+// every consumer combines the producer's partials itself (one wave, n_parts <= kArgParts): the kernel boundary is the barrier
+__device__ __forceinline__ void arg_collect(const ArgPart *__restrict__ parts, uint32_t n_parts, unsigned long long &m,
+                                            unsigned long long &c, unsigned long long &k) {
+  const int lane = threadIdx.x & 63;
+  m = 0; c = 0; k = kEmptyKey;
+  for (uint32_t j = lane; j < n_parts; j += 64) {
+    const unsigned long long m2 = parts[j].mx;
+    if (m2 > 0) arg_combine(m, c, k, m2, parts[j].cnt, parts[j].key);
+  }
+  arg_wave_reduce(m, c, k);
+}
+
+// the candidate list cannot answer: it overflowed, or its maximum fell below theta (theta 1 lists every live pair)
+__device__ __forceinline__ bool cand_dry(const TrainCtx &C, unsigned long long mx) {
+  return C.theta && ((C.st->flags & kFlagReplan) || C.st->n_cand > C.cand_cap || (mx < C.theta && C.theta > 1));
+}
+
+// BPE: maximum over the candidate list (the slots whose count is >= theta)
+__global__ __launch_bounds__(256) void cand_argmax_kernel(TrainCtx C, ArgPart *__restrict__ parts) {
   unsigned long long m = 0, c = 0, k = kEmptyKey;
-  // the counts are streamed two per load, four loads in flight per lane (cap is a power of two >= 1024); a key is only
-  // fetched for a count that can still win
+  unsigned long long n = C.st->n_cand;
+  if (n > C.cand_cap) n = C.cand_cap;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t slot = C.cand[i];
+    const long long v = C.T.cnt[slot];
+    if (v > 0 && (unsigned long long)v >= m) arg_combine(m, c, k, (unsigned long long)v, 1ull, C.T.keys[slot]);
+  }
+  arg_publish(m, c, k, parts);
+}
+
+// WordPiece (and the BPE fallback): maximum over the whole table.  The counts are streamed two per load, four loads in
+// flight per lane (cap is a power of two >= 1024); a key is only fetched for a count that can still win.
+__global__ __launch_bounds__(256) void argmax_full_kernel(const unsigned long long *__restrict__ keys, const long long *__restrict__ cnt,
+                                                          uint64_t cap, ArgPart *__restrict__ parts, const long long *__restrict__ sfreq) {
+  unsigned long long m = 0, c = 0, k = kEmptyKey;
   const uint64_t n2 = cap >> 1;
   const longlong2 *cnt2 = reinterpret_cast<const longlong2 *>(cnt);
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -201,53 +353,47 @@ __global__ __launch_bounds__(256) void argmax_kernel(const unsigned long long *_
       }
     }
   }
-  for (int d = 32; d >= 1; d >>= 1) {
-    const unsigned long long m2 = __shfl_xor(m, d), c2 = __shfl_xor(c, d), k2 = __shfl_xor(k, d);
-    arg_combine(m, c, k, m2, c2, k2);
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { sm[wave] = m; sc[wave] = c; sk[wave] = k; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; w++) arg_combine(m, c, k, sm[w], sc[w], sk[w]);
-    parts[blockIdx.x].mx = m;
-    parts[blockIdx.x].cnt = c;
-    parts[blockIdx.x].key = k;
-    __threadfence();  // agent-scope release before the ticket
-    is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!is_last) return;
-  __threadfence();  // agent-scope acquire
-  m = 0; c = 0; k = kEmptyKey;
-  for (uint32_t j = threadIdx.x; j < gridDim.x; j += blockDim.x) {
-    const unsigned long long m2 = __hip_atomic_load(&parts[j].mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long c2 = __hip_atomic_load(&parts[j].cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long k2 = __hip_atomic_load(&parts[j].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (m2 > 0) arg_combine(m, c, k, m2, c2, k2);
-  }
-  for (int d = 32; d >= 1; d >>= 1) {
-    const unsigned long long m2 = __shfl_xor(m, d), c2 = __shfl_xor(c, d), k2 = __shfl_xor(k, d);
-    arg_combine(m, c, k, m2, c2, k2);
+  arg_publish(m, c, k, parts);
+}
+
+// ---- bpe.py:102 tie-break ----------------------------------------------------------------------------------------------
+// The earliest (word, offset) whose pair holds the maximum.  An untied step costs a handful of workgroups that return at once.
+// best_pos = word << 32 | offset of the pair's left symbol inside the word.
+__global__ __launch_bounds__(kTrainThreads) void tie_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
+                                                            uint64_t n_words, TrainCtx C, const ArgPart *__restrict__ parts, uint32_t n_parts) {
+  __shared__ unsigned long long s_mx, s_tied;
+  if (threadIdx.x < 64) {
+    unsigned long long m, c, k;
+    arg_collect(parts, n_parts, m, c, k);
+    if (threadIdx.x == 0) { s_mx = m; s_tied = c; }
   }
   __syncthreads();
-  if (lane == 0) { sm[wave] = m; sc[wave] = c; sk[wave] = k; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; w++) arg_combine(m, c, k, sm[w], sc[w], sk[w]);
-    res->max_count = m;
-    res->n_tied = m ? c : 0;
-    res->best_key = k;
-    res->best_pos = kEmptyKey;
-    res->win_key = kEmptyKey;
-    *ticket = 0;
+  if (s_tied < 2 || s_mx == 0) return;
+  if (cand_dry(C, s_mx)) return;  // decide_kernel reports it
+  const unsigned long long mx = s_mx;
+  // plateau cursor (BPE only: a WordPiece score moves whenever a symbol frequency does)
+  const uint64_t start = (!C.sfreq && C.st->plateau == mx) ? (uint64_t)C.st->cursor_w : 0ull;
+  for (uint64_t w = start + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+    if ((w << 32) >= __hip_atomic_load(&C.st->best_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;  // words only get later
+    const uint64_t b0 = woff[w], b1 = woff[w + 1];
+    uint32_t a = kHole;
+    uint64_t ai = 0;
+    for (uint64_t i = b0; i < b1; i++) {
+      const uint32_t b = sym[i];
+      if (b == kHole) continue;
+      if (a != kHole) {
+        const unsigned long long key = pair_key(a, b);
+        if (pair_value(key, table_get(C.T, key), C.sfreq) == mx) {
+          atomicMin(&C.st->best_pos, (unsigned long long)((w << 32) | (ai - b0)));
+          break;
+        }
+      }
+      a = b;
+      ai = i;
+    }
   }
 }
 
-// bpe.py:102 tie-break: the earliest (word, position) whose pair holds the maximum count.  Grid-stride over the
-// words, so an untied step costs a handful of workgroups that return at once.
-// Device-driven mode (cmd != null, swt_bpe_train_run): this kernel also turns the result into the step's merge command
-// for apply_kernel and logs it -- workgroup 0 when the maximum is unique, the last workgroup of the scan when tied.
 // WordPiece: the symbol frequencies follow the merge.  A pair of two different symbols cannot overlap itself, so the merge
 // happens exactly count(l, r) times (weighted); a twin pair (a, a) is counted by apply_kernel, occurrence by occurrence.
 __device__ __forceinline__ void wp_move_freq(const PairTable &T, uint32_t l, uint32_t r, uint32_t m, long long *sfreq) {
@@ -258,78 +404,98 @@ __device__ __forceinline__ void wp_move_freq(const PairTable &T, uint32_t l, uin
   sfreq[m] += c;
 }
 
-__device__ __forceinline__ void write_cmd(unsigned long long key, unsigned long long mx, StepCmd *cmd, StepLog *log, uint32_t step,
-                                          uint32_t merged, const PairTable &T, long long *sfreq) {
-  const bool ok = mx > 0 && key != kEmptyKey;
+__device__ __forceinline__ uint32_t seg_of_symbol(const TrainCtx &C, uint32_t s) {
+  if (s < C.id_base) return 0u;
+  const uint32_t k = s - C.id_base;
+  if (k >= C.seg_cap) return 0u;
+  const uint32_t v = C.seg_of[k];
+  return v == kSegBase ? 0u : v;
+}
+
+// the pair at a tie position: the symbol there and the next live one of its word
+__device__ __forceinline__ unsigned long long pair_at(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff, unsigned long long pos) {
+  const uint64_t w = pos >> 32, b1 = woff[w + 1];
+  uint64_t i = woff[w] + (uint32_t)pos;
+  const uint32_t a = sym[i];
+  uint32_t b = kHole;
+  for (i++; i < b1; i++) {
+    b = sym[i];
+    if (b != kHole) break;
+  }
+  return pair_key(a, b);
+}
+
+// a step begins: its index segment starts where the log stands (and ends where the next step's begins); the merged symbol is
+// born in this step
+__device__ __forceinline__ void open_step(const TrainCtx &C, uint32_t merged, bool valid) {
+  TrainState *st = C.st;
+  C.seg_start[C.step] = st->idx_cursor;
+  if (st->idx_cursor > C.idx_cap) st->flags |= kFlagIndexBroken;  // entries were dropped: whole-stream applies from here on
+  if (!valid) return;
+  if (merged >= C.id_base && merged - C.id_base < C.seg_cap && C.seg_of[merged - C.id_base] == 0) C.seg_of[merged - C.id_base] = C.step;
+  else st->flags |= kFlagIndexBroken;  // the id already names a symbol: its pairs are no longer born in one step
+}
+
+// One wave: the step's decision.  Combines the partials, resolves a tie from best_pos, writes the merge command for
+// apply_kernel and the step's log line, registers the merged symbol's index segment, moves the plateau cursor.
+// cmd == nullptr: host-driven swt_bpe_train_best -- only the result fields are written.
+__global__ __launch_bounds__(64) void decide_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff, TrainCtx C,
+                                                    const ArgPart *__restrict__ parts, uint32_t n_parts, StepCmd *cmd, StepLog *log,
+                                                    uint32_t log_i, uint32_t merged) {
+  unsigned long long mx, tied, key;
+  arg_collect(parts, n_parts, mx, tied, key);
+  if (threadIdx.x != 0) return;
+  TrainState *st = C.st;
+  const bool dry = cand_dry(C, mx);
+  unsigned long long pos = kEmptyKey;
+  if (!dry && mx && tied >= 2) {
+    pos = st->best_pos;
+    key = pos != kEmptyKey ? pair_at(sym, woff, pos) : kEmptyKey;  // kEmptyKey: none of the tied pairs occurs in this shard
+  }
+  st->max_count = dry ? 0 : mx;
+  st->n_tied = (dry || !mx) ? 0 : tied;
+  st->best_key = key;
+  st->win_key = key;
+  st->res_pos = pos;
+  st->best_pos = kEmptyKey;
+  if (dry) st->flags |= kFlagReplan;
+  if (!dry && !C.sfreq) {
+    if (tied >= 2 && pos != kEmptyKey) { st->plateau = mx; st->cursor_w = (uint32_t)(pos >> 32); }
+    else if (st->plateau != mx) { st->plateau = mx; st->cursor_w = 0; }
+  }
+  if (!cmd) return;
+  const bool ok = !dry && mx > 0 && key != kEmptyKey;
   cmd->l = (uint32_t)(key >> 32);
   cmd->r = (uint32_t)key;
   cmd->m = merged;
   cmd->valid = ok ? 1u : 0u;
-  if (ok && sfreq) wp_move_freq(T, cmd->l, cmd->r, merged, sfreq);
-  log[step].l = cmd->l;
-  log[step].r = cmd->r;
-  log[step].count = mx;
-  log[step].flag = ok ? 0ull : 2ull;
+  open_step(C, merged, ok);
+  if (ok && C.sfreq) wp_move_freq(C.T, cmd->l, cmd->r, merged, C.sfreq);
+  log[log_i].l = cmd->l;
+  log[log_i].r = cmd->r;
+  log[log_i].count = mx;
+  log[log_i].flag = ok ? 0ull : (dry ? 3ull : 2ull);
+  log[log_i].n_syms = st->n_syms;
+  log[log_i].n_tied = tied;
+  log[log_i].n_cand = st->n_cand;
 }
 
-__global__ __launch_bounds__(kTrainThreads) void first_pos_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
-                                                                  const uint32_t *__restrict__ wlen, uint64_t n_words, PairTable T,
-                                                                  TrainResult *res, StepCmd *cmd, StepLog *log, uint32_t step,
-                                                                  uint32_t merged, unsigned int *ticket, long long *sfreq) {
-  __shared__ bool is_last;
-  if (res->n_tied < 2) {
-    if (cmd && blockIdx.x == 0 && threadIdx.x == 0) write_cmd(res->best_key, res->max_count, cmd, log, step, merged, T, sfreq);
-    return;
-  }
-  const unsigned long long mx = res->max_count;
-  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t n = wlen[w];
-    if (n < 2) continue;
-    const uint64_t base = woff[w];
-    if (base >= __hip_atomic_load(&res->best_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;  // words only get later
-    const uint32_t *s = sym + base;
-    uint32_t a = s[0];
-    for (uint32_t i = 1; i < n; i++) {
-      const uint32_t b = s[i];
-      const unsigned long long key = pair_key(a, b);
-      if (pair_value(key, table_get(T, key), sfreq) == mx) {
-        atomicMin(&res->best_pos, (unsigned long long)(base + i - 1));
-        break;
-      }
-      a = b;
-    }
-  }
-  if (!cmd) return;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!is_last || threadIdx.x != 0) return;
-  __threadfence();
-  const unsigned long long pos = __hip_atomic_load(&res->best_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long key = pos != kEmptyKey ? pair_key(sym[pos], sym[pos + 1]) : kEmptyKey;
-  res->win_key = key;
-  write_cmd(key, res->max_count, cmd, log, step, merged, T, sfreq);
-  *ticket = 0;
+// host-driven step (swt_bpe_train_apply): the command comes from the caller
+__global__ void set_cmd_kernel(TrainCtx C, StepCmd *cmd, uint32_t l, uint32_t r, uint32_t m) {
+  cmd->l = l; cmd->r = r; cmd->m = m; cmd->valid = 1u;
+  open_step(C, m, true);
+  if (C.sfreq) wp_move_freq(C.T, l, r, m, C.sfreq);
 }
-
-// host-driven WordPiece step (swt_bpe_train_apply): the frequency move of write_cmd as a launch of its own, BEFORE apply_kernel
-__global__ void wp_move_freq_kernel(PairTable T, uint32_t l, uint32_t r, uint32_t m, long long *sfreq) { wp_move_freq(T, l, r, m, sfreq); }
 
 // wordpiece.py:78-81 once: symbol frequencies, weighted by the word's frequency
 __global__ __launch_bounds__(kTrainThreads) void sym_hist_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
-                                                                 const uint32_t *__restrict__ wlen, const uint32_t *__restrict__ freq,
-                                                                 uint64_t n_words, long long *__restrict__ sfreq, uint64_t sym_cap,
-                                                                 unsigned int *__restrict__ bad) {
+                                                                 const uint32_t *__restrict__ freq, uint64_t n_words,
+                                                                 long long *__restrict__ sfreq, uint64_t sym_cap, unsigned int *__restrict__ bad) {
   const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n_words) return;
-  const uint32_t n = wlen[w];
-  const uint32_t *s = sym + woff[w];
   const unsigned long long f = freq[w];
-  for (uint32_t i = 0; i < n; i++) {
-    if (s[i] < sym_cap) atomicAdd(reinterpret_cast<unsigned long long *>(&sfreq[s[i]]), f);
+  for (uint64_t i = woff[w]; i < woff[w + 1]; i++) {
+    if (sym[i] < sym_cap) atomicAdd(reinterpret_cast<unsigned long long *>(&sfreq[sym[i]]), f);
     else *bad = 1u;
   }
 }
@@ -351,136 +517,638 @@ __global__ void wp_live_symbols_kernel(const long long *__restrict__ sfreq, uint
     }
 }
 
-__global__ void winner_kernel(const uint32_t *__restrict__ sym, TrainResult *res) {
-  if (res->n_tied < 2 || res->best_pos == kEmptyKey) return;
-  res->win_key = pair_key(sym[res->best_pos], sym[res->best_pos + 1]);
-}
-
-// bpe.py:108-111 + _replace_pair (bpe.py:25-48), with the histogram kept exact:
+// ---- bpe.py:108-111 + _replace_pair (bpe.py:25-48), with the histogram kept exact ---------------------------------------
 //   an old pair (x[i],x[i+1]) disappears iff x[i] or x[i+1] is consumed by an occurrence;
 //   a new pair (y[j],y[j+1]) appears iff y[j] or y[j+1] is a freshly merged symbol.
-__global__ __launch_bounds__(kTrainThreads) void apply_kernel(uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
-                                                              uint32_t *__restrict__ wlen, const uint32_t *__restrict__ freq,
-                                                              uint64_t n_words, uint32_t l, uint32_t r, uint32_t m, PairTable T,
-                                                              TrainResult *res, unsigned long long *__restrict__ log_keys,
-                                                              long long *__restrict__ log_vals, uint64_t log_cap,
-                                                              const StepCmd *__restrict__ cmd, long long *__restrict__ sfreq) {
-  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= n_words) return;
-  if (cmd) {  // device-driven step: the pair comes from decide_kernel
-    if (!cmd->valid) return;
-    l = cmd->l; r = cmd->r; m = cmd->m;
-  }
-  const uint32_t n = wlen[w];
-  if (n < 2) return;
-  uint32_t *s = sym + woff[w];
-  // cheap reject: does the word hold an occurrence at all?
-  bool any = false;
-  {
-    uint32_t a = s[0];
-    for (uint32_t i = 1; i < n; i++) {
-      const uint32_t b = s[i];
-      any |= (a == l) & (b == r);
-      a = b;
-    }
-  }
-  if (!any) return;
-  const long long f = freq[w];
-#define EMIT(key, delta)                                              \
-  do {                                                                \
-    table_add(T, (key), (delta), res);                                \
-    if (log_keys) {                                                   \
-      const unsigned long long k_ = atomicAdd(&res->n_log, 1ull);     \
-      if (k_ < log_cap) { log_keys[k_] = (key); log_vals[k_] = (delta); } \
-    }                                                                 \
-  } while (0)
-  uint32_t i = 0, j = 0;
-  uint32_t po = 0, pn = 0;      // previous old / new symbol
+// One lane per index entry (a word that held the pair when the pair was born).  The lane claims the word and walks it once,
+// left to right through the holes, rewriting it in place; the histogram deltas it meets are parked in LDS (kEmitCap per
+// lane), because each one costs a dependent trip to the pair table (~0.2 us: the table lives in the Infinity Cache) and
+// issued one by one they would be the whole cost of a merge.  After the walk the wave reserves its new index entries with
+// one atomic, and every lane flushes its parked deltas four at a time: four independent probes, then four atomics.
+constexpr int kEmitCap = 12;
+constexpr unsigned long long kEmitNew = 1ull << 63;  // symbol ids stay below 2^31, so bit 63 of a pair key is free
+
+// the slot of a key that is very likely in the table already: one plain load; anything else goes the insert-or-find way
+__device__ __forceinline__ uint32_t slot_hint(const PairTable &T, unsigned long long key) { return hash_slot(key, T.bits); }
+
+__device__ __forceinline__ void index_entry(const TrainCtx &C, uint64_t at, unsigned long long key, uint32_t m, uint32_t w) {
+  if (at >= C.idx_cap) return;
+  const uint32_t a = (uint32_t)(key >> 32), b = (uint32_t)key;
+  C.idx_tag[at] = (a == m) ? ((b << 1) | 1u) : (a << 1);  // the symbol beside m, and the side m is on
+  C.idx_word[at] = w;
+}
+
+// walk one claimed word: rewrite in place, park the deltas.  Returns merges done; n_parked / n_new_parked by reference.
+// Deltas beyond kEmitCap are applied on the spot (a new pair then takes its index entry with an atomic of its own).
+__device__ __forceinline__ uint32_t walk_word(uint32_t *__restrict__ sym, uint64_t b0, uint64_t b1, uint32_t l, uint32_t r, uint32_t m,
+                                              long long f, const TrainCtx &C, uint32_t w, unsigned long long *park, int &n_park,
+                                              int &n_new) {
+  uint32_t n_merged = 0;
+  uint32_t po = 0, pn = 0;  // previous old / new symbol
   bool po_cov = false, pn_new = false, have = false;
-  while (i < n) {
-    const uint32_t x = s[i];
-    const bool occ = (i + 1 < n) && x == l && s[i + 1] == r;
+  uint64_t i = b0;
+  while (i < b1 && sym[i] == kHole) i++;
+#define EMIT(a_, b_, new_)                                                           \
+  do {                                                                               \
+    const unsigned long long key_ = pair_key((a_), (b_));                            \
+    if (n_park < kEmitCap) {                                                         \
+      park[n_park++] = key_ | ((new_) ? kEmitNew : 0ull);                            \
+      n_new += (new_) ? 1 : 0;                                                       \
+    } else {                                                                         \
+      table_add(C, key_, (new_) ? f : -f);                                           \
+      if (new_) index_entry(C, atomicAdd(&C.st->idx_cursor, 1ull), key_, m, w);      \
+    }                                                                                \
+  } while (0)
+  while (i < b1) {
+    const uint32_t x = sym[i];
+    uint64_t j = i + 1;
+    while (j < b1 && sym[j] == kHole) j++;
+    const bool occ = j < b1 && x == l && sym[j] == r;
     if (occ) {
-      if (have) EMIT(pair_key(po, x), -f);      // (prev, l): l is consumed
-      EMIT(pair_key(x, r), -f);                 // (l, r) itself
-      if (have) EMIT(pair_key(pn, m), f);       // (prev_new, merged)
+      if (have) EMIT(po, x, false);    // (prev, l): l is consumed
+      EMIT(x, r, false);               // (l, r) itself
+      if (have) EMIT(pn, m, true);     // (prev_new, merged)
       po = r; po_cov = true; pn = m; pn_new = true; have = true;
-      s[j++] = m;
-      i += 2;
+      sym[i] = m;
+      sym[j] = kHole;
+      n_merged++;
+      i = j + 1;
+      while (i < b1 && sym[i] == kHole) i++;
     } else {
       if (have) {
-        if (po_cov) EMIT(pair_key(po, x), -f);  // (r, x): r was consumed
-        if (pn_new) EMIT(pair_key(pn, x), f);   // (merged, x)
+        if (po_cov) EMIT(po, x, false);  // (r, x): r was consumed
+        if (pn_new) EMIT(pn, x, true);   // (merged, x)
       }
       po = x; po_cov = false; pn = x; pn_new = false; have = true;
-      s[j++] = x;
-      i += 1;
+      i = j;
     }
   }
 #undef EMIT
-  if (sfreq && l == r) {  // twin pair: (n - j) merges happened in this word (see wp_move_freq)
-    const unsigned long long d = (unsigned long long)(n - j) * (unsigned long long)f;
-    atomicAdd(reinterpret_cast<unsigned long long *>(&sfreq[l]), (unsigned long long)0 - 2 * d);
-    atomicAdd(reinterpret_cast<unsigned long long *>(&sfreq[m]), d);
+  return n_merged;
+}
+
+__device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff, const uint32_t *__restrict__ freq,
+                                           uint64_t n_words, const TrainCtx &C, uint32_t l, uint32_t r, uint32_t m) {
+  __shared__ unsigned long long park_s[kTrainThreads * kEmitCap];
+  unsigned long long *park = park_s + (size_t)threadIdx.x * kEmitCap;
+  TrainState *st = C.st;
+  const int lane = threadIdx.x & 63;
+  // where the words of (l, r) are listed
+  const uint32_t *list = nullptr;  // word ids
+  const uint32_t *tags = nullptr;  // log segment: entries of other pairs are skipped by tag
+  uint64_t n_ent = 0;
+  uint32_t want_tag = 0;
+  if (st->flags & kFlagIndexBroken) {
+    n_ent = n_words;  // every word (only after a symbol id was reused: never on trained tables)
+  } else {
+    const uint32_t sl = seg_of_symbol(C, l), sr = seg_of_symbol(C, r);
+    const uint32_t seg = sl > sr ? sl : sr;
+    if (seg == 0) {
+      const uint32_t h = k0_find(C.K, pair_key(l, r));
+      if (h != 0xFFFFFFFFu) { list = C.K.words + C.K.start[h]; n_ent = C.K.len[h]; }
+      else list = C.K.words;
+    } else {
+      const uint64_t s0 = C.seg_start[seg], s1 = C.seg_start[seg + 1];
+      list = C.idx_word + s0;
+      tags = C.idx_tag + s0;
+      n_ent = s1 - s0;
+      want_tag = (sl >= sr) ? ((r << 1) | 1u) : (l << 1);  // the later-born symbol is the segment's m; (m, m) counts as m left
+    }
   }
-  wlen[w] = j;
-  atomicAdd(&res->n_syms, (unsigned long long)0 - (unsigned long long)(n - j));
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  unsigned long long removed = 0;
+  uint32_t min_w = 0xFFFFFFFFu;
+  for (uint64_t e0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; e0 < n_ent; e0 += stride) {
+    const uint64_t e = e0 + lane;
+    uint32_t w = 0xFFFFFFFFu;
+    if (e < n_ent) {
+      if (!list) {
+        w = (uint32_t)e;
+      } else {
+        const uint32_t we = list[e];  // both loads go out together
+        if (!tags || tags[e] == want_tag) w = we;
+      }
+    }
+    int n_park = 0, n_new = 0;
+    if (w != 0xFFFFFFFFu) {
+      // the word's bounds and frequency travel beside the claim
+      const uint64_t b0 = woff[w], b1 = woff[w + 1];
+      const long long f = freq[w];
+      if (atomicMax(&C.wstamp[w], C.step) < C.step) {
+        const uint32_t nm = walk_word(sym, b0, b1, l, r, m, f, C, w, park, n_park, n_new);
+        if (nm) {
+          removed += nm;
+          min_w = w < min_w ? w : min_w;
+          if (C.sfreq && l == r) {  // twin pair: nm merges happened in this word (see wp_move_freq)
+            const unsigned long long d = (unsigned long long)nm * (unsigned long long)f;
+            atomicAdd(reinterpret_cast<unsigned long long *>(&C.sfreq[l]), (unsigned long long)0 - 2 * d);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&C.sfreq[m]), d);
+          }
+        }
+      } else {
+        w = 0xFFFFFFFFu;  // another lane has this word
+      }
+    }
+    // room in the index log for the wave's new entries: one atomic per wave (lanes without a word take part with zero)
+    uint32_t x = (uint32_t)n_new;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    const uint32_t total = __shfl(x, 63);
+    unsigned long long base = 0;
+    if (lane == 0 && total) base = atomicAdd(&st->idx_cursor, (unsigned long long)total);
+    base = __shfl(base, 0);
+    if (w != 0xFFFFFFFFu && n_park) {
+      const long long f = freq[w];  // L1: loaded a moment ago
+      uint64_t at = base + x - (uint32_t)n_new;
+      for (int j0 = 0; j0 < n_park; j0 += 4) {
+        unsigned long long key[4], seen[4];
+        uint32_t h[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          key[u] = j0 + u < n_park ? park[j0 + u] : 0ull;
+          h[u] = slot_hint(C.T, key[u] & ~kEmitNew);
+          seen[u] = j0 + u < n_park ? C.T.keys[h[u]] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (j0 + u >= n_park) continue;
+          const unsigned long long k = key[u] & ~kEmitNew;
+          const bool is_new = (key[u] & kEmitNew) != 0;
+          const uint32_t slot = seen[u] == k ? h[u] : table_slot(C.T, k, st);
+          if (!C.pend) {
+            count_add(C, slot, is_new ? f : -f);
+          } else {
+            (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&C.pend[slot]), (unsigned long long)(is_new ? f : -f),
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (atomicMax(&C.tstamp[slot], C.step) < C.step) {
+              const unsigned long long q = atomicAdd(&st->n_touched, 1ull);
+              if (q < C.touched_cap) C.touched[q] = slot;
+            }
+          }
+          if (is_new) index_entry(C, at++, k, m, w);
+        }
+      }
+    }
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    removed += __shfl_xor(removed, d);
+    const uint32_t o = __shfl_xor(min_w, d);
+    min_w = o < min_w ? o : min_w;
+  }
+  if (lane == 0 && removed) {
+    atomicAdd(&st->n_syms, (unsigned long long)0 - removed);
+    atomicMin(&st->cursor_w, min_w);  // new pairs were born in these words: the tie scan may not start after them
+  }
 }
 
-__global__ void add_remote_kernel(const unsigned long long *__restrict__ keys, const long long *__restrict__ vals, uint64_t n,
-                                  PairTable T, TrainResult *res) {
+__global__ __launch_bounds__(kTrainThreads) void apply_kernel(uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
+                                                              const uint32_t *__restrict__ freq, uint64_t n_words, TrainCtx C,
+                                                              const StepCmd *__restrict__ cmd) {
+  if (!cmd->valid) return;
+  apply_body(sym, woff, freq, n_words, C, cmd->l, cmd->r, cmd->m);
+}
+
+// ---- the fast path of unsharded BPE: two launches per merge ---------------------------------------------------------------
+// The candidate list is short (kCandTarget at a re-plan), so EVERY workgroup of the tie launch finds the maximum over it by
+// itself -- no argmax launch, no partials, no decide launch:
+//   fast_tie_kernel    workgroup argmax (workgroup 0 publishes it); when the maximum is tied, the tied pairs go into an LDS
+//                      set and the words are scanned from the plateau cursor for the earliest one (membership = an LDS probe,
+//                      not a table probe); the finder leaves the pair in wkey[word], the position in best2[step parity]
+//   fast_apply_kernel  reads the published maximum and the winner (best2 / wkey) -- it may not look at the counts itself,
+//                      its own workgroups are already moving them -- then apply_body; workgroup 0 also writes the step's log
+//                      line, the plateau cursor, the merged symbol's birth step, and resets the other best2
+struct BlockArg {
+  unsigned long long mx, tied, key;
+};
+
+constexpr int kTieSetSlots = 1024;  // LDS set of the tied pairs: kTieSet keys at most, load factor 1/4
+constexpr int kCandRegs = 8;        // candidates a lane holds in registers: kTrainThreads * kCandRegs = kCandHigh
+
+__device__ __forceinline__ void tset_insert(unsigned long long *tset, unsigned long long key) {
+  uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 54);
+  for (;;) {  // a slot may be listed twice: the set takes a key once
+    const unsigned long long old = atomicCAS(&tset[h], kEmptyKey, key);
+    if (old == kEmptyKey || old == key) break;
+    h = (h + 1) & (kTieSetSlots - 1);
+  }
+}
+
+__device__ __forceinline__ bool tset_has(const unsigned long long *tset, unsigned long long key) {
+  uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 54);
+  for (;;) {
+    const unsigned long long k = tset[h];
+    if (k == key) return true;
+    if (k == kEmptyKey) return false;
+    h = (h + 1) & (kTieSetSlots - 1);
+  }
+}
+
+__device__ __forceinline__ BlockArg block_reduce(unsigned long long m, unsigned long long c, unsigned long long k) {
+  __shared__ unsigned long long sm[4], sc[4], sk[4];
+  arg_wave_reduce(m, c, k);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sm[wave] = m; sc[wave] = c; sk[wave] = k; }
+  __syncthreads();
+  m = sm[0]; c = sc[0]; k = sk[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); w++) arg_combine(m, c, k, sm[w], sc[w], sk[w]);
+  __syncthreads();
+  return BlockArg{m, c, k};
+}
+
+// The workgroup's maximum over the candidate list, and (when tset != nullptr and the maximum is tied among at most kTieSet
+// pairs) the tied pairs in the LDS set.  The latency of a dependent access to the pair table is what this costs (~0.2 us
+// each: the table lives in the Infinity Cache), so a lane takes its candidates as three rounds of independent loads -- the
+// slots, their counts, the keys of its own maxima -- instead of a chain per candidate.
+__device__ __forceinline__ BlockArg block_argmax(const TrainCtx &C, unsigned long long n_cand, unsigned long long n_synced,
+                                                 unsigned long long *tset) {
+  if (n_cand <= (unsigned long long)kTrainThreads * kCandRegs) {
+    long long v[kCandRegs];
+    unsigned long long key[kCandRegs];
+    // the mirrored part of the list is a coalesced stream; the few candidates pushed since the last step are still gathered
+    long long lm = 0;
+#pragma unroll
+    for (int u = 0; u < kCandRegs; u++) {
+      const uint64_t i = threadIdx.x + (uint64_t)u * kTrainThreads;
+      v[u] = i < n_synced ? C.ccnt[i] : (i < n_cand ? C.T.cnt[C.cand[i]] : 0);
+      lm = v[u] > lm ? v[u] : lm;
+    }
+    unsigned long long m = 0, c = 0, k = kEmptyKey;
+#pragma unroll
+    for (int u = 0; u < kCandRegs; u++) {
+      const uint64_t i = threadIdx.x + (uint64_t)u * kTrainThreads;
+      key[u] = (lm > 0 && v[u] == lm) ? (i < n_synced ? C.ckey[i] : C.T.keys[C.cand[i]]) : kEmptyKey;
+      if (key[u] != kEmptyKey) arg_combine(m, c, k, (unsigned long long)lm, 1ull, key[u]);
+    }
+    const BlockArg a = block_reduce(m, c, k);
+    if (tset && a.tied >= 2 && a.tied <= kTieSet && a.mx) {
+      for (int i = threadIdx.x; i < kTieSetSlots; i += blockDim.x) tset[i] = kEmptyKey;
+      __syncthreads();
+      if ((unsigned long long)lm == a.mx) {
+#pragma unroll
+        for (int u = 0; u < kCandRegs; u++)
+          if (key[u] != kEmptyKey) tset_insert(tset, key[u]);
+      }
+      __syncthreads();
+    }
+    return a;
+  }
+  // a list that pushes have grown past the register budget (the host re-plans it at the next batch boundary)
+  unsigned long long m = 0, c = 0, k = kEmptyKey;
+  for (uint64_t i = threadIdx.x; i < n_cand; i += blockDim.x) {
+    const uint32_t slot = C.cand[i];
+    const long long v = C.T.cnt[slot];
+    if (v > 0 && (unsigned long long)v >= m) arg_combine(m, c, k, (unsigned long long)v, 1ull, C.T.keys[slot]);
+  }
+  const BlockArg a = block_reduce(m, c, k);
+  if (tset && a.tied >= 2 && a.tied <= kTieSet && a.mx) {
+    for (int i = threadIdx.x; i < kTieSetSlots; i += blockDim.x) tset[i] = kEmptyKey;
+    __syncthreads();
+    for (uint64_t i = threadIdx.x; i < n_cand; i += blockDim.x) {
+      const uint32_t slot = C.cand[i];
+      if ((unsigned long long)C.T.cnt[slot] == a.mx) tset_insert(tset, C.T.keys[slot]);
+    }
+    __syncthreads();
+  }
+  return a;
+}
+
+__global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
+                                                                 uint64_t n_words, TrainCtx C) {
+  __shared__ unsigned long long tset[kTieSetSlots];
+  TrainState *st = C.st;
+  const unsigned int flags = st->flags;
+  const unsigned long long n_cand = st->n_cand, n_synced = st->n_synced, plateau = st->plateau, idx_cursor = st->idx_cursor;
+  const uint64_t cursor_w = st->cursor_w;
+  if (flags & kFlagReplan) return;  // a dry batch: fast_apply_kernel logs it
+  const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+  if (lead) {
+    // the step's index segment begins where the log stands (no apply is in flight); a merged id that was reused in the last
+    // step voids the index from this step on
+    C.seg_start[C.step] = idx_cursor;
+    if (idx_cursor > C.idx_cap || (flags & kFlagBrokenPending)) atomicOr(&st->flags, kFlagIndexBroken);
+  }
+  if (n_cand > C.cand_cap) {  // the list lost a candidate
+    if (lead) atomicOr(&st->flags, kFlagReplan);
+    return;
+  }
+  if (blockIdx.x == 0) {
+    // the candidates the last merge pushed get their compact copy now (no count moves while this launch runs); every
+    // workgroup of THIS launch still gathers them from the table, fast_apply_kernel then moves n_synced up
+    for (uint64_t i = n_synced + threadIdx.x; i < n_cand; i += blockDim.x) {
+      const uint32_t slot = C.cand[i];
+      C.ccnt[i] = C.T.cnt[slot];
+      C.ckey[i] = C.T.keys[slot];
+      C.cidx[slot] = (uint32_t)i;
+    }
+    if (lead) st->n_synced_next = n_cand;
+  }
+  // the word this lane will scan first if the maximum is tied at the plateau's level (the common case late in training):
+  // its bounds are requested now, so that they travel while the argmax waits for the candidate list
+  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t w_spec = cursor_w + gid;
+  uint64_t sb0 = 0, sb1 = 0;
+  if (w_spec < n_words) { sb0 = woff[w_spec]; sb1 = woff[w_spec + 1]; }
+  const BlockArg a = block_argmax(C, n_cand, n_synced, tset);
+  const bool dry = a.mx < C.theta && C.theta > 1;
+  if (lead) {
+    st->max_count = a.mx;
+    st->n_tied = a.mx ? a.tied : 0;
+    st->best_key = a.key;
+    if (dry) atomicOr(&st->flags, kFlagReplan);
+  }
+  if (dry || a.tied < 2 || a.mx == 0) return;
+  const unsigned long long mx = a.mx;
+  const bool use_set = a.tied <= kTieSet;
+  unsigned long long *best = &st->best2[C.step & 1];
+  const uint64_t start = plateau == mx ? cursor_w : 0ull;
+  bool first = true;
+  for (uint64_t w = start + gid; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+    // words only get later: once a hit is in, lanes past it stop (on its first word a lane does not ask: nothing is in yet)
+    if (!first && (w << 32) >= __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    const bool spec = first && w == w_spec;
+    first = false;
+    const uint64_t b0 = spec ? sb0 : woff[w], b1 = spec ? sb1 : woff[w + 1];
+    uint32_t x = kHole;
+    uint64_t xi = 0;
+    bool found = false;
+    for (uint64_t base = b0; base < b1 && !found; base += 16) {  // sixteen symbols per round of loads
+      uint32_t y16[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) y16[u] = base + u < b1 ? sym[base + u] : kHole;
+      // the pairs of the round, then their set probes as one batch of independent LDS reads
+      unsigned long long key16[16], got16[16];
+      uint32_t h16[16];
+      uint32_t px = x;
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        key16[u] = (y16[u] != kHole && px != kHole) ? pair_key(px, y16[u]) : kEmptyKey;
+        if (y16[u] != kHole) px = y16[u];
+        h16[u] = (uint32_t)((key16[u] * 0x9E3779B97F4A7C15ull) >> 54);
+      }
+      if (use_set) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) got16[u] = tset[h16[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const uint32_t y = y16[u];
+        if (y == kHole || found) continue;
+        if (x != kHole) {
+          const unsigned long long key = key16[u];
+          bool hit;
+          if (!use_set) hit = (unsigned long long)table_get(C.T, key) == mx;
+          else if (got16[u] == key) hit = true;
+          else if (got16[u] == kEmptyKey) hit = false;
+          else hit = tset_has(tset, key);  // a collision on the first probe: walk on
+          if (hit) {
+            C.wkey[w] = key;
+            atomicMin(best, (unsigned long long)((w << 32) | (xi - b0)));
+            found = true;
+          }
+        }
+        x = y;
+        xi = base + u;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kTrainThreads) void fast_apply_kernel(uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
+                                                                   const uint32_t *__restrict__ freq, uint64_t n_words, TrainCtx C,
+                                                                   StepLog *__restrict__ log, uint32_t log_i, uint32_t merged) {
+  TrainState *st = C.st;
+  const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+  if (st->flags & kFlagReplan) {  // dry (this step or an earlier one of the batch): nothing runs until the host re-plans
+    if (lead) { log[log_i].l = 0; log[log_i].r = 0; log[log_i].count = 0; log[log_i].flag = 3ull; log[log_i].n_syms = st->n_syms; log[log_i].n_tied = 0; log[log_i].n_cand = st->n_cand; }
+    return;
+  }
+  const unsigned long long mx = st->max_count, tied = st->n_tied;
+  unsigned long long key = st->best_key, pos = kEmptyKey;
+  if (mx && tied >= 2) {
+    pos = st->best2[C.step & 1];
+    key = pos != kEmptyKey ? C.wkey[pos >> 32] : kEmptyKey;
+  }
+  const bool ok = mx > 0 && key != kEmptyKey;
+  const uint32_t l = (uint32_t)(key >> 32), r = (uint32_t)key;
+  if (lead) {
+    st->res_pos = pos;
+    st->win_key = key;
+    st->best2[(C.step + 1) & 1] = kEmptyKey;  // the next step's scan starts from a clean minimum
+    st->n_synced = st->n_synced_next;          // the tie launch mirrored the candidates up to there
+    // the plateau cursor: a plain store beside the other workgroups' atomicMin of the words they touch -- both orders leave a
+    // valid lower bound (the winner's first word is the first word this merge touches)
+    if (tied >= 2 && pos != kEmptyKey) { st->plateau = mx; st->cursor_w = (uint32_t)(pos >> 32); }
+    else if (st->plateau != mx) { st->plateau = mx; st->cursor_w = 0; }
+    if (ok) {
+      if (merged >= C.id_base && merged - C.id_base < C.seg_cap && C.seg_of[merged - C.id_base] == 0) C.seg_of[merged - C.id_base] = C.step;
+      else atomicOr(&st->flags, kFlagBrokenPending);  // the next step's tie launch turns it into kFlagIndexBroken
+    }
+    log[log_i].l = l;
+    log[log_i].r = r;
+    log[log_i].count = mx;
+    log[log_i].flag = ok ? 0ull : 2ull;
+    log[log_i].n_syms = st->n_syms;
+    log[log_i].n_tied = tied;
+    log[log_i].n_cand = st->n_cand;
+  }
+  if (!ok) return;
+  apply_body(sym, woff, freq, n_words, C, l, r, merged);
+}
+
+// ---- candidates --------------------------------------------------------------------------------------------------------
+// histogram of the live counts over 8 sub-buckets per octave: the host picks theta so that ~kCandTarget pairs pass it
+__device__ __forceinline__ uint32_t count_bucket(unsigned long long c) {
+  const int e = 63 - __builtin_clzll(c);
+  const uint32_t sub = e >= 3 ? (uint32_t)((c >> (e - 3)) & 7u) : (uint32_t)((c << (3 - e)) & 7u);
+  return (uint32_t)e * 8u + sub;
+}
+
+__global__ __launch_bounds__(256) void cand_hist_kernel(const long long *__restrict__ cnt, uint64_t cap, unsigned long long *__restrict__ buckets) {
+  __shared__ unsigned int lb[512];
+  for (int i = threadIdx.x; i < 512; i += blockDim.x) lb[i] = 0;
+  __syncthreads();
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
+    const long long c = cnt[i];
+    if (c > 0) atomicAdd(&lb[count_bucket((unsigned long long)c)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 512; i += blockDim.x)
+    if (lb[i]) atomicAdd(&buckets[i], (unsigned long long)lb[i]);
+}
+
+__global__ __launch_bounds__(256) void cand_build_kernel(TrainCtx C, uint64_t cap) {
+  const int lane = threadIdx.x & 63;
+  for (uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < cap; i0 += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = i0 + lane;
+    const bool in = i < cap && C.T.cnt[i] >= (long long)C.theta && C.T.keys[i] != kEmptyKey;
+    const unsigned long long mask = __ballot(in);
+    if (!mask) continue;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&C.st->n_cand, (unsigned long long)__popcll(mask));
+    base = __shfl(base, 0);
+    if (in) {
+      const unsigned long long k = base + __popcll(mask & ((1ull << lane) - 1ull));
+      if (k < C.cand_cap) {
+        C.cand[k] = (uint32_t)i;
+        C.ccnt[k] = C.T.cnt[i];
+        C.ckey[k] = C.T.keys[i];
+        C.cidx[i] = (uint32_t)k;
+      }
+    }
+  }
+}
+
+// ---- table maintenance, export -----------------------------------------------------------------------------------------
+__global__ void add_records_kernel(const DeltaRec *__restrict__ recs, uint64_t n, TrainCtx C) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-    if (vals[i] != 0) table_add(T, keys[i], vals[i], res);
+    if (recs[i].delta != 0) count_add(C, table_slot(C.T, recs[i].key, C.st), recs[i].delta);
 }
 
-// live entries -> (keys, counts) list
+// live entries -> (key, count) records
 __global__ void table_export_kernel(const unsigned long long *__restrict__ keys, const long long *__restrict__ cnt, uint64_t cap,
-                                    unsigned long long *__restrict__ out_keys, long long *__restrict__ out_vals, uint64_t out_cap,
-                                    unsigned long long *n_out) {
+                                    DeltaRec *__restrict__ out, uint64_t out_cap, unsigned long long *n_out) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
     if (keys[i] != kEmptyKey && cnt[i] != 0) {
       const unsigned long long k = atomicAdd(n_out, 1ull);
-      if (k < out_cap) { out_keys[k] = keys[i]; out_vals[k] = cnt[i]; }
+      if (k < out_cap) { out[k].key = keys[i]; out[k].delta = cnt[i]; }
     }
   }
 }
 
 __global__ void table_rehash_kernel(const unsigned long long *__restrict__ keys, const long long *__restrict__ cnt, uint64_t cap,
-                                    PairTable dst, TrainResult *res) {
+                                    PairTable dst, TrainState *st) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x)
-    if (keys[i] != kEmptyKey && cnt[i] != 0) table_add(dst, keys[i], cnt[i], res);
+    if (keys[i] != kEmptyKey && cnt[i] != 0)
+      atomicAdd(reinterpret_cast<unsigned long long *>(&dst.cnt[table_slot(dst, keys[i], st)]), (unsigned long long)cnt[i]);
+}
+
+// ---- sharded training: the exchange of one step's deltas ----------------------------------------------------------------
+// the slots this rank's apply touched -> one record block.  block[0] is the header: key = records that follow (or were
+// wanted), delta != 0 when they did not fit.
+__global__ void pack_records_kernel(TrainCtx C, DeltaRec *__restrict__ block, uint64_t block_cap) {
+  const unsigned long long n = C.st->n_touched;
+  const bool over = n > C.touched_cap || n + 1 > block_cap;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { block[0].key = n; block[0].delta = over ? 1 : 0; }
+  if (over) return;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t h = C.touched[i];
+    block[i + 1].key = C.T.keys[h];
+    block[i + 1].delta = C.pend[h];
+  }
+}
+
+// Every rank's block into this replica -- unless a block overflowed somewhere: then nothing is added on any rank, the halt
+// flag stops the following steps, and the host grows the blocks and repeats the exchange of this step.
+__global__ void add_blocks_kernel(const DeltaRec *__restrict__ blocks, uint32_t world, uint64_t block_cap, TrainCtx C, unsigned int *halt) {
+  __shared__ int bad;
+  if (threadIdx.x == 0) {
+    int b = *halt != 0;
+    for (uint32_t r = 0; r < world; r++)
+      if (blocks[(uint64_t)r * block_cap].delta != 0) b = 1;
+    bad = b;
+  }
+  __syncthreads();
+  if (bad) return;
+  for (uint32_t r = 0; r < world; r++) {
+    const DeltaRec *blk = blocks + (uint64_t)r * block_cap;
+    const uint64_t n = blk[0].key;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+      if (blk[i + 1].delta != 0) count_add(C, table_slot(C.T, blk[i + 1].key, C.st), blk[i + 1].delta);
+  }
+}
+
+// after add_blocks_kernel: pend[] of the touched slots back to zero and the list emptied -- or the halt raised
+__global__ void finish_exchange_kernel(const DeltaRec *__restrict__ blocks, uint32_t world, uint64_t block_cap, TrainCtx C, unsigned int *halt) {
+  __shared__ int bad;
+  if (threadIdx.x == 0) {
+    int b = *halt != 0;
+    for (uint32_t r = 0; r < world; r++)
+      if (blocks[(uint64_t)r * block_cap].delta != 0) b = 1;
+    bad = b;
+  }
+  __syncthreads();
+  if (bad) {
+    if (threadIdx.x == 0) *halt = 1u;
+    return;
+  }
+  const unsigned long long n = C.st->n_touched;
+  for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) C.pend[C.touched[i]] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) C.st->n_touched = 0;
+}
+
+// recovery after an overflow: the touched list is rebuilt from pend[] itself (the list may have dropped slots)
+__global__ void rebuild_touched_kernel(TrainCtx C, uint64_t cap) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x)
+    if (C.pend[i] != 0) {
+      const unsigned long long k = atomicAdd(&C.st->n_touched, 1ull);
+      if (k < C.touched_cap) C.touched[k] = (uint32_t)i;
+    }
+}
+
+// sharded tie-break: this rank's (first position, pair) for the all-gather
+__global__ __launch_bounds__(64) void tie_send_kernel(TrainCtx C, const ArgPart *__restrict__ parts, uint32_t n_parts,
+                                                      const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
+                                                      unsigned long long *__restrict__ line) {
+  unsigned long long mx, tied, key;
+  arg_collect(parts, n_parts, mx, tied, key);
+  if (threadIdx.x != 0) return;
+  unsigned long long pos = kEmptyKey, k = kEmptyKey;
+  if (mx && tied >= 2 && !cand_dry(C, mx)) {
+    pos = C.st->best_pos;
+    if (pos != kEmptyKey) k = pair_at(sym, woff, pos);
+  }
+  line[0] = pos;
+  line[1] = k;
+}
+
+// ... and the decision from every rank's line: ranks are ordered by their sentence ranges, so the first rank that holds a
+// tied pair holds the earliest occurrence
+__global__ __launch_bounds__(64) void decide_sharded_kernel(TrainCtx C, const ArgPart *__restrict__ parts, uint32_t n_parts,
+                                                            const unsigned long long *__restrict__ lines, uint32_t world, uint32_t rank,
+                                                            StepCmd *cmd, StepLog *log, uint32_t log_i, uint32_t merged,
+                                                            const unsigned int *__restrict__ halt) {
+  unsigned long long mx, tied, key;
+  arg_collect(parts, n_parts, mx, tied, key);
+  if (threadIdx.x != 0) return;
+  TrainState *st = C.st;
+  const bool halted = *halt != 0;
+  const bool dry = cand_dry(C, mx);
+  if (!dry && !halted && mx && tied >= 2) {
+    key = kEmptyKey;
+    for (uint32_t r = 0; r < world; r++)
+      if (lines[2 * r] != kEmptyKey) { key = lines[2 * r + 1]; break; }
+    const unsigned long long mine = lines[2 * rank];
+    if (mine != kEmptyKey) { st->plateau = mx; st->cursor_w = (uint32_t)(mine >> 32); }
+    else if (st->plateau != mx) { st->plateau = mx; st->cursor_w = 0; }
+  } else if (!dry && !halted && st->plateau != mx) {
+    st->plateau = mx; st->cursor_w = 0;
+  }
+  st->best_pos = kEmptyKey;
+  st->max_count = dry ? 0 : mx;
+  st->n_tied = (dry || !mx) ? 0 : tied;
+  st->best_key = key;
+  if (dry) st->flags |= kFlagReplan;
+  const bool ok = !dry && !halted && mx > 0 && key != kEmptyKey;
+  cmd->l = (uint32_t)(key >> 32);
+  cmd->r = (uint32_t)key;
+  cmd->m = merged;
+  cmd->valid = ok ? 1u : 0u;
+  open_step(C, merged, ok);
+  log[log_i].l = cmd->l;
+  log[log_i].r = cmd->r;
+  log[log_i].count = mx;
+  log[log_i].flag = ok ? 0ull : (halted ? 4ull : (dry ? 3ull : 2ull));
+  log[log_i].n_syms = st->n_syms;
+  log[log_i].n_tied = tied;
+  log[log_i].n_cand = st->n_cand;
 }
 
 }  // namespace swt
 
 using namespace swt;
-
-struct swt_bpe_trainer {
-  uint64_t n_words = 0, n_syms0 = 0;
-  uint32_t n_base = 0;
-  std::vector<uint32_t> base_syms;
-  uint32_t *d_sym = nullptr;
-  uint64_t *d_woff = nullptr;
-  uint32_t *d_wlen = nullptr;
-  uint32_t *d_freq = nullptr;
-  PairTable T{nullptr, nullptr, 0};
-  TrainResult *d_res = nullptr;
-  ArgPart *d_parts = nullptr;     // per-workgroup argmax partials + the ticket behind them
-  StepCmd *d_cmd = nullptr;       // device-driven steps
-  StepLog *d_steplog = nullptr;
-  unsigned int *d_halt = nullptr;  // ticket of the tie-break scan
-  uint64_t n_applied = 0;         // merges applied so far (bounds the number of distinct symbols)
-  TrainResult h_res{};
-  uint64_t pos_base = 0;
-  bool hist_ready = false;
-  long long *d_sfreq = nullptr;  // WordPiece mode: symbol frequencies, dense by symbol id (kWpSymCap entries)
-  // delta log (sharded training)
-  bool logging = false;
-  unsigned long long *d_log_keys = nullptr;
-  long long *d_log_vals = nullptr;
-  uint64_t log_cap = 0;
-  DevBuf tmp;
-};
 
 static unsigned grid_for(uint64_t n, int threads, unsigned cap = 1u << 20) {
   uint64_t g = (n + threads - 1) / threads;
@@ -489,12 +1157,43 @@ static unsigned grid_for(uint64_t n, int threads, unsigned cap = 1u << 20) {
   return (unsigned)g;
 }
 
-static int table_alloc(PairTable &T, uint32_t bits) {
+// ---- host side ---------------------------------------------------------------------------------------------------------
+
+TrainCtx swt_bpe_trainer::ctx() const {
+  TrainCtx C{};
+  C.T = T;
+  C.K = K;
+  C.st = d_st;
+  C.sfreq = d_sfreq;
+  C.theta = theta;
+  C.cand = d_cand;
+  C.cand_cap = cand_cap;
+  C.ccnt = d_ccnt;
+  C.ckey = d_ckey;
+  C.cidx = cand_valid && theta ? d_cidx : nullptr;
+  C.idx_tag = d_idx_tag;
+  C.idx_word = d_idx_word;
+  C.idx_cap = idx_cap;
+  C.seg_start = d_seg_start;
+  C.seg_of = d_seg_of;
+  C.seg_cap = seg_cap;
+  C.id_base = id_base;
+  C.wstamp = d_wstamp;
+  C.wkey = d_wkey;
+  C.step = step_no;
+  C.pend = sharded ? d_pend : nullptr;
+  C.tstamp = d_tstamp;
+  C.touched = d_touched;
+  C.touched_cap = touched_cap;
+  return C;
+}
+
+static int table_alloc(PairTable &T, uint32_t bits, hipStream_t st) {
   const size_t cap = (size_t)1 << bits;
   T.bits = bits;
   SWT_HIP(hipMalloc((void **)&T.keys, cap * 8));
   SWT_HIP(hipMalloc((void **)&T.cnt, cap * 8));
-  hipLaunchKernelGGL(table_clear_kernel, dim3(grid_for(cap, 256, 4096)), dim3(256), 0, 0, T.keys, T.cnt, (uint64_t)cap);
+  hipLaunchKernelGGL(table_clear_kernel, dim3(grid_for(cap, 256, 4096)), dim3(256), 0, st, T.keys, T.cnt, (uint64_t)cap);
   return SWT_OK;
 }
 
@@ -505,22 +1204,96 @@ static void table_free(PairTable &T) {
   T.cnt = nullptr;
 }
 
-static int sync_result(swt_bpe_trainer *t) {
-  SWT_HIP(hipMemcpy(&t->h_res, t->d_res, sizeof(TrainResult), hipMemcpyDeviceToHost));
+int swt_bpe_trainer::sync_state() {
+  SWT_HIP(hipMemcpyAsync(&h_st, d_st, sizeof(TrainState), hipMemcpyDeviceToHost, stream));
+  SWT_HIP(hipStreamSynchronize(stream));
   return SWT_OK;
 }
 
-// Rebuild the table at `bits` from its live entries (drops zero-count keys).
+// per-slot arrays of the sharded mode follow the table's size (called between exchanges: pend[] is all zero then)
+static int sharded_arrays(swt_bpe_trainer *t) {
+  if (!t->sharded) return SWT_OK;
+  const size_t cap = (size_t)1 << t->T.bits;
+  if (t->d_pend) (void)hipFree(t->d_pend);
+  if (t->d_tstamp) (void)hipFree(t->d_tstamp);
+  t->d_pend = nullptr; t->d_tstamp = nullptr;
+  SWT_HIP(hipMalloc((void **)&t->d_pend, cap * 8));
+  SWT_HIP(hipMalloc((void **)&t->d_tstamp, cap * 4));
+  SWT_HIP(hipMemsetAsync(t->d_pend, 0, cap * 8, t->stream));
+  SWT_HIP(hipMemsetAsync(t->d_tstamp, 0, cap * 4, t->stream));
+  return SWT_OK;
+}
+
+// Rebuild the table at `bits` from its live entries (drops zero-count keys).  Slots move: the candidate list is void.
 static int table_resize(swt_bpe_trainer *t, uint32_t bits) {
+  if (bits > 31) return fail(SWT_ERR_UNSUPPORTED, "pair table would exceed 2^31 slots");
   PairTable nt{nullptr, nullptr, 0};
-  int rc = table_alloc(nt, bits);
+  int rc = table_alloc(nt, bits, t->stream);
   if (rc) return rc;
-  SWT_HIP(hipMemset(&t->d_res->n_used, 0, 8));
+  SWT_HIP(hipMemsetAsync(&t->d_st->n_used, 0, 8, t->stream));
   const uint64_t cap = 1ull << t->T.bits;
-  hipLaunchKernelGGL(table_rehash_kernel, dim3(grid_for(cap, 256, 4096)), dim3(256), 0, 0, t->T.keys, t->T.cnt, cap, nt, t->d_res);
-  SWT_HIP(hipDeviceSynchronize());
+  hipLaunchKernelGGL(table_rehash_kernel, dim3(grid_for(cap, 256, 4096)), dim3(256), 0, t->stream, t->T.keys, t->T.cnt, cap, nt, t->d_st);
+  SWT_HIP(hipStreamSynchronize(t->stream));
   table_free(t->T);
   t->T = nt;
+  t->cand_valid = false;
+  return sharded_arrays(t);
+}
+
+// theta from the histogram of the counts, then the list of the slots that pass it
+int swt_bpe_trainer::replan() {
+  if (d_sfreq) { theta = 0; cand_valid = true; return SWT_OK; }  // WordPiece: full-table argmax
+  int rc;
+  if (!d_cand) {
+    cand_cap = kCandCap;
+    SWT_HIP(hipMalloc((void **)&d_cand, (size_t)cand_cap * 4));
+    SWT_HIP(hipMalloc((void **)&d_ccnt, (size_t)cand_cap * 8));
+    SWT_HIP(hipMalloc((void **)&d_ckey, (size_t)cand_cap * 8));
+    SWT_HIP(hipMalloc((void **)&d_buckets, 512 * 8));
+  }
+  if (!d_cidx || cidx_bits != T.bits) {  // one place per table slot
+    if (d_cidx) (void)hipFree(d_cidx);
+    d_cidx = nullptr;
+    SWT_HIP(hipMalloc((void **)&d_cidx, ((size_t)1 << T.bits) * 4));
+    cidx_bits = T.bits;
+  }
+  SWT_HIP(hipMemsetAsync(d_cidx, 0xFF, ((size_t)1 << T.bits) * 4, stream));
+  const uint64_t cap = 1ull << T.bits;
+  SWT_HIP(hipMemsetAsync(d_buckets, 0, 512 * 8, stream));
+  hipLaunchKernelGGL(cand_hist_kernel, dim3(grid_for(cap, 256 * 8, 1024)), dim3(256), 0, stream, T.cnt, cap, d_buckets);
+  unsigned long long hb[512];
+  SWT_HIP(hipMemcpyAsync(hb, d_buckets, sizeof hb, hipMemcpyDeviceToHost, stream));
+  if ((rc = sync_state())) return rc;
+  // from the top: whole buckets while at most kCandTarget pairs pass (the highest non-empty bucket always passes)
+  unsigned long long above = 0;
+  int lowest = 512;  // lowest bucket taken
+  for (int b = 511; b >= 0; b--) {
+    if (!hb[b]) continue;
+    if (above && above + hb[b] > kCandTarget) break;
+    above += hb[b];
+    lowest = b;
+  }
+  unsigned long long th = 1;
+  if (lowest < 512) {
+    const int e = lowest / 8, sub = lowest % 8;  // bucket `lowest` starts at (8 + sub) * 2^(e - 3)
+    th = e >= 3 ? ((unsigned long long)(8 + sub) << (e - 3)) : (((unsigned long long)(8 + sub) + ((1u << (3 - e)) - 1)) >> (3 - e));
+    if (th < 1) th = 1;
+  }
+  bool any_lower = false;
+  for (int b = 0; b < lowest && b < 512; b++) any_lower |= hb[b] != 0;
+  if (!any_lower) th = 1;  // everything passes: the list is the whole table, and an empty list means no pair is left
+  // a plateau wider than the list (say a million pairs of count 1): full-table argmax until the next re-plan
+  theta = above > cand_cap / 2 ? 0 : th;
+  const unsigned int flags = h_st.flags & ~kFlagReplan;
+  SWT_HIP(hipMemsetAsync(&d_st->n_cand, 0, 8, stream));
+  SWT_HIP(hipMemcpyAsync(&d_st->flags, &flags, 4, hipMemcpyHostToDevice, stream));
+  cand_valid = true;  // ctx() hands the mirror out from here on
+  if (theta) hipLaunchKernelGGL(cand_build_kernel, dim3(grid_for(cap, 256, 2048)), dim3(256), 0, stream, ctx(), cap);
+  // everything the build listed is mirrored
+  SWT_HIP(hipMemcpyAsync(&d_st->n_synced, &d_st->n_cand, 8, hipMemcpyDeviceToDevice, stream));
+  SWT_HIP(hipMemcpyAsync(&d_st->n_synced_next, &d_st->n_cand, 8, hipMemcpyDeviceToDevice, stream));
+  SWT_HIP(hipStreamSynchronize(stream));  // `flags` is a stack variable
+  n_replans++;
   return SWT_OK;
 }
 
@@ -528,25 +1301,132 @@ static int build_histogram(swt_bpe_trainer *t) {
   // size for the worst case first (every position a distinct pair), then shrink to what is used
   uint32_t bits = 10;
   while ((1ull << bits) < 2 * t->n_syms0 + 16 && bits < 31) bits++;
-  int rc = table_alloc(t->T, bits);
+  int rc = table_alloc(t->T, bits, t->stream);
   if (rc) return rc;
+  TrainCtx C = t->ctx();
+  C.theta = 0;
+  C.pend = nullptr;
   if (t->n_words)
-    hipLaunchKernelGGL(hist_build_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff,
-                       t->d_wlen, t->d_freq, t->n_words, t->T, t->d_res);
-  SWT_HIP(hipDeviceSynchronize());
-  if ((rc = sync_result(t))) return rc;
+    hipLaunchKernelGGL(hist_build_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, t->stream, t->d_sym, t->d_woff,
+                       t->d_freq, t->n_words, C);
+  if ((rc = t->sync_state())) return rc;
   uint32_t want = 10;
-  while ((1ull << want) < 4 * t->h_res.n_used + 1024) want++;
+  while ((1ull << want) < 4 * t->h_st.n_used + 1024) want++;
   if (want < bits) {
     if ((rc = table_resize(t, want))) return rc;
+    if ((rc = t->sync_state())) return rc;
   }
   t->hist_ready = true;
   return SWT_OK;
 }
 
-__global__ void wlen_kernel(const uint64_t *__restrict__ woff, uint32_t *__restrict__ wlen, uint64_t n_words) {
-  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (w < n_words) wlen[w] = (uint32_t)(woff[w + 1] - woff[w]);
+// k0: the words of every initial pair, grouped by key; the log of the later segments; the word stamps
+static int build_index(swt_bpe_trainer *t) {
+  K0Index &K = t->K;
+  K.bits = t->T.bits;
+  const size_t cap = (size_t)1 << K.bits;
+  SWT_HIP(hipMalloc((void **)&K.keys, cap * 8));
+  SWT_HIP(hipMalloc((void **)&K.start, cap * 4));
+  SWT_HIP(hipMalloc((void **)&K.len, cap * 4));
+  SWT_HIP(hipMalloc((void **)&K.fill, cap * 4));
+  SWT_HIP(hipMalloc((void **)&K.words, (size_t)(t->n_syms0 + 16) * 4));
+  SWT_HIP(hipMemcpyAsync(K.keys, t->T.keys, cap * 8, hipMemcpyDeviceToDevice, t->stream));
+  SWT_HIP(hipMemsetAsync(K.fill, 0, cap * 4, t->stream));
+  SWT_HIP(hipMemsetAsync(K.start, 0, cap * 4, t->stream));
+  SWT_HIP(hipMemsetAsync(K.len, 0, cap * 4, t->stream));
+  unsigned long long *cursor = &t->d_st->scratch;
+  SWT_HIP(hipMemsetAsync(cursor, 0, 8, t->stream));
+  if (t->n_words) {
+    const unsigned g = grid_for(t->n_words, kTrainThreads);
+    hipLaunchKernelGGL(k0_pass_kernel, dim3(g), dim3(kTrainThreads), 0, t->stream, t->d_sym, t->d_woff, t->n_words, K, 0);
+    hipLaunchKernelGGL(k0_alloc_kernel, dim3(grid_for(cap, 256, 2048)), dim3(256), 0, t->stream, K, cursor);
+    hipLaunchKernelGGL(k0_pass_kernel, dim3(g), dim3(kTrainThreads), 0, t->stream, t->d_sym, t->d_woff, t->n_words, K, 1);
+  }
+  // a merge removes one symbol and adds at most two entries
+  t->idx_cap = 2 * t->n_syms0 + 1024;
+  SWT_HIP(hipMalloc((void **)&t->d_idx_tag, (size_t)t->idx_cap * 4));
+  SWT_HIP(hipMalloc((void **)&t->d_idx_word, (size_t)t->idx_cap * 4));
+  SWT_HIP(hipMalloc((void **)&t->d_wstamp, (size_t)(t->n_words + 1) * 4));
+  SWT_HIP(hipMemsetAsync(t->d_wstamp, 0, (size_t)(t->n_words + 1) * 4, t->stream));
+  SWT_HIP(hipMalloc((void **)&t->d_wkey, (size_t)(t->n_words + 1) * 8));
+  return SWT_OK;
+}
+
+// seg_of[] (merged symbol -> the step that created it) and seg_start[] grow with the number of steps
+static int ensure_steps(swt_bpe_trainer *t, uint64_t more_steps, uint32_t max_merged_id) {
+  const uint64_t need_seg = (uint64_t)t->step_no + more_steps + 4;
+  if (need_seg > t->seg_start_cap) {
+    uint64_t cap = t->seg_start_cap ? t->seg_start_cap : 4096;
+    while (cap < need_seg) cap *= 2;
+    unsigned long long *p = nullptr;
+    SWT_HIP(hipMalloc((void **)&p, cap * 8));
+    SWT_HIP(hipMemsetAsync(p, 0, cap * 8, t->stream));
+    if (t->d_seg_start) {
+      SWT_HIP(hipMemcpyAsync(p, t->d_seg_start, t->seg_start_cap * 8, hipMemcpyDeviceToDevice, t->stream));
+      SWT_HIP(hipStreamSynchronize(t->stream));
+      (void)hipFree(t->d_seg_start);
+    }
+    t->d_seg_start = p;
+    t->seg_start_cap = cap;
+  }
+  uint64_t need_ids = 1024;
+  if (max_merged_id >= t->id_base && max_merged_id != 0xFFFFFFFFu) need_ids = (uint64_t)(max_merged_id - t->id_base) + 1;
+  if (need_ids > (1ull << 26)) return fail(SWT_ERR_UNSUPPORTED, "merged symbol id %u is beyond the trainer's range", max_merged_id);
+  if (need_ids > t->seg_cap) {
+    uint64_t cap = t->seg_cap ? t->seg_cap : 65536;
+    while (cap < need_ids) cap *= 2;
+    uint32_t *p = nullptr;
+    SWT_HIP(hipMalloc((void **)&p, cap * 4));
+    SWT_HIP(hipMemsetAsync(p, 0, cap * 4, t->stream));
+    if (t->d_seg_of) {
+      SWT_HIP(hipMemcpyAsync(p, t->d_seg_of, (size_t)t->seg_cap * 4, hipMemcpyDeviceToDevice, t->stream));
+      SWT_HIP(hipStreamSynchronize(t->stream));
+      (void)hipFree(t->d_seg_of);
+    }
+    t->d_seg_of = p;
+    t->seg_cap = (uint32_t)cap;
+  }
+  return SWT_OK;
+}
+
+static int alloc_common(swt_bpe_trainer *t) {
+  SWT_HIP(hipMalloc((void **)&t->d_st, sizeof(TrainState)));
+  SWT_HIP(hipMalloc((void **)&t->d_cmd, sizeof(StepCmd)));
+  SWT_HIP(hipMemsetAsync(t->d_cmd, 0, sizeof(StepCmd), t->stream));
+  SWT_HIP(hipMalloc((void **)&t->d_steplog, kMaxRunSteps * sizeof(StepLog)));
+  SWT_HIP(hipMalloc((void **)&t->d_parts, kArgParts * sizeof(ArgPart)));
+  SWT_HIP(hipMemsetAsync(t->d_parts, 0, kArgParts * sizeof(ArgPart), t->stream));
+  TrainState init{};
+  init.n_syms = t->n_syms0;
+  init.best_pos = kEmptyKey;
+  init.res_pos = kEmptyKey;
+  init.best2[0] = init.best2[1] = kEmptyKey;
+  init.plateau = ~0ull;
+  SWT_HIP(hipMemcpyAsync(t->d_st, &init, sizeof init, hipMemcpyHostToDevice, t->stream));
+  SWT_HIP(hipStreamSynchronize(t->stream));
+  return SWT_OK;
+}
+
+// ids at or above id_base that are already in the stream are initial symbols: they have no birth step, and a merge may not
+// take their id
+static int mark_initial_ids(swt_bpe_trainer *t, const std::vector<uint32_t> &ids) {
+  uint32_t hi = 0;
+  for (uint32_t s : ids) if (s >= t->id_base && s > hi) hi = s;
+  if (!hi) return SWT_OK;
+  int rc = ensure_steps(t, 0, hi);
+  if (rc) return rc;
+  std::vector<uint32_t> seg(t->seg_cap, 0u);
+  for (uint32_t s : ids) if (s >= t->id_base) seg[s - t->id_base] = kSegBase;
+  SWT_HIP(hipMemcpy(t->d_seg_of, seg.data(), (size_t)t->seg_cap * 4, hipMemcpyHostToDevice));
+  return SWT_OK;
+}
+
+static int finish_create(swt_bpe_trainer *t) {
+  int rc;
+  if ((rc = build_histogram(t))) return rc;
+  if ((rc = build_index(t))) return rc;
+  if ((rc = ensure_steps(t, kRunBatch, 0xFFFFFFFFu))) return rc;
+  return t->sync_state();
 }
 
 // take ownership of a unique-word stream that is already on the device (swt_words.hip)
@@ -557,21 +1437,12 @@ static int trainer_adopt(swt_bpe_trainer *t, DeviceWords &dw) {
   t->d_woff = dw.d_woff;
   t->d_freq = dw.d_freq;
   dw.d_sym = nullptr; dw.d_woff = nullptr; dw.d_freq = nullptr;
-  SWT_HIP(hipMalloc((void **)&t->d_wlen, (t->n_words + 1) * 4));
-  SWT_HIP(hipMalloc((void **)&t->d_res, sizeof(TrainResult)));
-  SWT_HIP(hipMemset(t->d_res, 0, sizeof(TrainResult)));
-  SWT_HIP(hipMalloc((void **)&t->d_cmd, sizeof(StepCmd)));
-  SWT_HIP(hipMalloc((void **)&t->d_steplog, kMaxRunSteps * sizeof(StepLog)));
-  SWT_HIP(hipMalloc((void **)&t->d_halt, 8));
-  SWT_HIP(hipMalloc((void **)&t->d_parts, (kArgBlocks + 1) * sizeof(ArgPart)));
-  SWT_HIP(hipMemset(t->d_parts, 0, (kArgBlocks + 1) * sizeof(ArgPart)));
-  if (t->n_words)
-    hipLaunchKernelGGL(wlen_kernel, dim3(grid_for(t->n_words, 256)), dim3(256), 0, 0, t->d_woff, t->d_wlen, t->n_words);
-  unsigned long long ns = t->n_syms0;
-  SWT_HIP(hipMemcpy(&t->d_res->n_syms, &ns, 8, hipMemcpyHostToDevice));
+  if (t->n_words >= 0xFFFFFFFFull || t->n_syms0 >= 0xFFFFFFFFull) return fail(SWT_ERR_UNSUPPORTED, "more than 2^32 - 1 unique words or symbols");
+  int rc = alloc_common(t);
+  if (rc) return rc;
   t->base_syms = dw.base_syms;
   t->n_base = (uint32_t)t->base_syms.size();
-  return build_histogram(t);
+  return SWT_OK;
 }
 
 static int trainer_upload(swt_bpe_trainer *t, const uint32_t *syms, const uint64_t *word_off, const uint32_t *freq, uint64_t n_words) {
@@ -580,48 +1451,90 @@ static int trainer_upload(swt_bpe_trainer *t, const uint32_t *syms, const uint64
   const uint64_t n_syms = word_off[n_words];
   t->n_words = n_words;
   t->n_syms0 = n_syms;
-  std::vector<uint32_t> wlen(n_words + 1);
+  if (n_words >= 0xFFFFFFFFull || n_syms >= 0xFFFFFFFFull) return fail(SWT_ERR_UNSUPPORTED, "more than 2^32 - 1 unique words or symbols");
   for (uint64_t w = 0; w < n_words; w++) {
     if (word_off[w + 1] < word_off[w]) return fail(SWT_ERR_INVALID, "word offsets must be non-decreasing");
     if (word_off[w + 1] - word_off[w] > 0xFFFFFFFFull) return fail(SWT_ERR_UNSUPPORTED, "word too long");
-    wlen[w] = (uint32_t)(word_off[w + 1] - word_off[w]);
   }
+  for (uint64_t i = 0; i < n_syms; i++)
+    if (syms[i] == kHole) return fail(SWT_ERR_INVALID, "symbol id 0xFFFFFFFF is reserved");
   SWT_HIP(hipMalloc((void **)&t->d_sym, (n_syms + 16) * 4));
   SWT_HIP(hipMalloc((void **)&t->d_woff, (n_words + 1) * 8));
-  SWT_HIP(hipMalloc((void **)&t->d_wlen, (n_words + 1) * 4));
   SWT_HIP(hipMalloc((void **)&t->d_freq, (n_words + 1) * 4));
-  SWT_HIP(hipMalloc((void **)&t->d_res, sizeof(TrainResult)));
-  SWT_HIP(hipMemset(t->d_res, 0, sizeof(TrainResult)));
-  SWT_HIP(hipMalloc((void **)&t->d_cmd, sizeof(StepCmd)));
-  SWT_HIP(hipMalloc((void **)&t->d_steplog, kMaxRunSteps * sizeof(StepLog)));
-  SWT_HIP(hipMalloc((void **)&t->d_halt, 8));
-  SWT_HIP(hipMalloc((void **)&t->d_parts, (kArgBlocks + 1) * sizeof(ArgPart)));
-  SWT_HIP(hipMemset(t->d_parts, 0, (kArgBlocks + 1) * sizeof(ArgPart)));
+  if ((rc = alloc_common(t))) return rc;
   if (n_syms) SWT_HIP(hipMemcpy(t->d_sym, syms, n_syms * 4, hipMemcpyHostToDevice));
   SWT_HIP(hipMemcpy(t->d_woff, word_off, (n_words + 1) * 8, hipMemcpyHostToDevice));
-  if (n_words) {
-    SWT_HIP(hipMemcpy(t->d_wlen, wlen.data(), n_words * 4, hipMemcpyHostToDevice));
-    SWT_HIP(hipMemcpy(t->d_freq, freq, n_words * 4, hipMemcpyHostToDevice));
-  }
-  unsigned long long ns = n_syms;
-  SWT_HIP(hipMemcpy(&t->d_res->n_syms, &ns, 8, hipMemcpyHostToDevice));
+  if (n_words) SWT_HIP(hipMemcpy(t->d_freq, freq, n_words * 4, hipMemcpyHostToDevice));
   // distinct code points (the initial vocab, bpe.py:75)
-  {
-    std::vector<uint8_t> seen(kNumCodePoints, 0);
-    std::vector<uint32_t> other;  // ids that are not code points (a caller-supplied stream may already hold merged symbols)
-    for (uint64_t i = 0; i < n_syms; i++) {
-      if (syms[i] < kNumCodePoints) seen[syms[i]] = 1;
-      else other.push_back(syms[i]);
-    }
-    std::vector<uint32_t> b;
-    for (uint32_t c = 0; c < kNumCodePoints; c++) if (seen[c]) b.push_back(c);
-    std::sort(other.begin(), other.end());
-    other.erase(std::unique(other.begin(), other.end()), other.end());
-    b.insert(b.end(), other.begin(), other.end());
-    t->base_syms = b;
-    t->n_base = (uint32_t)b.size();
+  std::vector<uint8_t> seen(kNumCodePoints, 0);
+  std::vector<uint32_t> other;  // ids that are not code points (a caller-supplied stream may already hold merged symbols)
+  for (uint64_t i = 0; i < n_syms; i++) {
+    if (syms[i] < kNumCodePoints) seen[syms[i]] = 1;
+    else other.push_back(syms[i]);
   }
-  return build_histogram(t);
+  std::vector<uint32_t> b;
+  for (uint32_t c = 0; c < kNumCodePoints; c++) if (seen[c]) b.push_back(c);
+  std::sort(other.begin(), other.end());
+  other.erase(std::unique(other.begin(), other.end()), other.end());
+  b.insert(b.end(), other.begin(), other.end());
+  t->base_syms = b;
+  t->n_base = (uint32_t)b.size();
+  if ((rc = mark_initial_ids(t, other))) return rc;
+  return finish_create(t);
+}
+
+// New pairs one merge can create: two per occurrence (occurrences <= the pair's count, counts never grow), and never
+// more than (x, m) / (m, y) over the distinct symbols x, y plus (m, m).
+static uint64_t new_pairs_bound(const swt_bpe_trainer *t, uint64_t count_bound) {
+  if (t->d_sfreq) count_bound = 0;  // WordPiece: max_count holds a score, not a count
+  const uint64_t n_base = t->sharded ? t->n_base_global : t->n_base;
+  const uint64_t by_symbols = 2 * (n_base + t->n_applied + 1) + 1;
+  uint64_t by_count = count_bound ? 2 * count_bound : by_symbols;
+  if (!t->sharded && t->h_st.n_syms && 2 * t->h_st.n_syms < by_count) by_count = 2 * t->h_st.n_syms;
+  return by_symbols < by_count ? by_symbols : by_count;
+}
+
+static int ensure_room(swt_bpe_trainer *t, uint64_t extra) {
+  const uint64_t cap = 1ull << t->T.bits;
+  if (2 * (t->h_st.n_used + extra + 64) <= cap) return SWT_OK;
+  uint32_t bits = t->T.bits;
+  while ((1ull << bits) < 4 * (t->h_st.n_used + extra + 64)) bits++;
+  int rc = table_resize(t, bits);
+  if (rc) return rc;
+  return t->sync_state();
+}
+
+// argmax -> tie scan (the caller enqueues its decide kernel behind them)
+void swt_bpe_trainer::enqueue_argmax() {
+  const TrainCtx C = ctx();
+  if (theta) {
+    n_parts = kCandBlocks;
+    hipLaunchKernelGGL(cand_argmax_kernel, dim3(kCandBlocks), dim3(256), 0, stream, C, d_parts);
+  } else {
+    const uint64_t cap = 1ull << T.bits;
+    n_parts = grid_for(cap, 256 * 8, kArgParts);
+    hipLaunchKernelGGL(argmax_full_kernel, dim3(n_parts), dim3(256), 0, stream, T.keys, T.cnt, cap, d_parts, (const long long *)d_sfreq);
+  }
+  if (n_words)
+    hipLaunchKernelGGL(tie_kernel, dim3(grid_for(n_words, kTrainThreads, kTieBlocks)), dim3(kTrainThreads), 0, stream, d_sym, d_woff,
+                       n_words, C, d_parts, n_parts);
+}
+
+// unsharded BPE: tie scan + apply, each with its own workgroup-level argmax over the (short) candidate list
+void swt_bpe_trainer::enqueue_fast_step(uint32_t log_i, uint32_t merged) {
+  const TrainCtx C = ctx();
+  if (!n_words) return;
+  // every workgroup of the tie launch reads the whole candidate list: few of them for a small corpus, kTieBlocks at most
+  unsigned tie_blocks = grid_for(n_words, kTrainThreads * 16, kTieBlocks);
+  if (tie_blocks < 8) tie_blocks = grid_for(n_words, kTrainThreads, 8);
+  hipLaunchKernelGGL(fast_tie_kernel, dim3(tie_blocks), dim3(kTrainThreads), 0, stream, d_sym, d_woff, n_words, C);
+  hipLaunchKernelGGL(fast_apply_kernel, dim3(kFastApplyBlocks), dim3(kTrainThreads), 0, stream, d_sym, d_woff, d_freq, n_words, C,
+                     d_steplog, log_i, merged);
+}
+
+void swt_bpe_trainer::enqueue_apply() {
+  if (n_words)
+    hipLaunchKernelGGL(apply_kernel, dim3(kApplyBlocks), dim3(kTrainThreads), 0, stream, d_sym, d_woff, d_freq, n_words, ctx(), d_cmd);
 }
 
 extern "C" {
@@ -637,8 +1550,7 @@ int swt_bpe_train_create_words(const uint32_t *syms, const uint64_t *word_off, c
   return SWT_OK;
 }
 
-// bpe.py:70-81 on the device (swt_words.hip): split (utils.py:27), Counter(words) in first-occurrence order, symbolise.
-int swt_bpe_train_create_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, swt_bpe_trainer **out) {
+static int words_from_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, swt_bpe_trainer **out) {
   if (!out || !sent_off || (n_sent && sent_off[n_sent] && !text)) return fail(SWT_ERR_INVALID, "null argument");
   if (sent_off[0] != 0) return fail(SWT_ERR_INVALID, "sent_off[0] must be 0");
   for (uint64_t s = 0; s < n_sent; s++)
@@ -647,13 +1559,12 @@ int swt_bpe_train_create_text(const uint8_t *text, const uint64_t *sent_off, uin
   if (rc) return rc;
   const uint64_t n_bytes = sent_off[n_sent];
   DevBuf d_text, d_off;
+  struct Guard { DevBuf &a, &b; ~Guard() { a.release(); b.release(); } } guard{d_text, d_off};
   if ((rc = d_text.reserve(n_bytes + 64)) || (rc = d_off.reserve((n_sent + 1) * 8))) return rc;
   if (n_bytes) SWT_HIP(hipMemcpy(d_text.p, text, n_bytes, hipMemcpyHostToDevice));
   SWT_HIP(hipMemcpy(d_off.p, sent_off, (n_sent + 1) * 8, hipMemcpyHostToDevice));
   DeviceWords dw;
   rc = device_words_from_text(d_text.as<uint8_t>(), n_bytes, d_off.as<uint64_t>(), n_sent, &dw);
-  d_text.release();
-  d_off.release();
   if (rc) return rc;
   auto *t = new swt_bpe_trainer();
   rc = trainer_adopt(t, dw);
@@ -662,49 +1573,64 @@ int swt_bpe_train_create_text(const uint8_t *text, const uint64_t *sent_off, uin
   return SWT_OK;
 }
 
+// bpe.py:70-81 on the device (swt_words.hip): split (utils.py:27), Counter(words) in first-occurrence order, symbolise.
+int swt_bpe_train_create_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, swt_bpe_trainer **out) {
+  swt_bpe_trainer *t = nullptr;
+  int rc = words_from_text(text, sent_off, n_sent, &t);
+  if (rc) return rc;
+  if ((rc = finish_create(t))) { swt_bpe_train_destroy(t); return rc; }
+  *out = t;
+  return SWT_OK;
+}
+
 // wordpiece.py:44-63 on the device: the same split and Counter, then [word[0]] + ["##" + c ...] and the symbol frequencies.
 // The handle is used with the swt_bpe_train_* calls; `count` outputs carry the winning score's bit pattern.
 int swt_wp_train_create_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, swt_bpe_trainer **out) {
   swt_bpe_trainer *t = nullptr;
-  int rc = swt_bpe_train_create_text(text, sent_off, n_sent, &t);
+  int rc = words_from_text(text, sent_off, n_sent, &t);
   if (rc) return rc;
-  // the pair histogram was built on plain code points: rebuild it on the WordPiece symbols
-  table_free(t->T);
+  auto bail = [&](int code) { swt_bpe_train_destroy(t); return code; };
+  t->id_base = kWpMergedBase;
   if (t->n_words)
-    hipLaunchKernelGGL(wp_symbolise_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff,
-                       t->n_words);
-  SWT_HIP(hipMemset(&t->d_res->n_used, 0, 8));
-  if ((rc = build_histogram(t))) { swt_bpe_train_destroy(t); return rc; }
-  SWT_HIP(hipMalloc((void **)&t->d_sfreq, kWpSymCap * 8));
-  SWT_HIP(hipMemset(t->d_sfreq, 0, kWpSymCap * 8));
-  unsigned int *d_flag = reinterpret_cast<unsigned int *>(t->d_halt);
-  SWT_HIP(hipMemset(d_flag, 0, 8));
+    hipLaunchKernelGGL(wp_symbolise_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, t->stream, t->d_sym,
+                       t->d_woff, t->n_words);
+  if ((rc = finish_create(t))) return bail(rc);  // the histogram build counts plain pairs: the frequencies come after it
+  if (hipMalloc((void **)&t->d_sfreq, kWpSymCap * 8) != hipSuccess) return bail(fail(SWT_ERR_HIP, "hipMalloc of the symbol frequencies failed"));
+  if (hipMemsetAsync(t->d_sfreq, 0, kWpSymCap * 8, t->stream) != hipSuccess) return bail(fail(SWT_ERR_HIP, "hipMemset failed"));
+  DevBuf live, flag;
+  struct Guard { DevBuf &a, &b; ~Guard() { a.release(); b.release(); } } guard{live, flag};
+  const uint32_t live_cap = 2 * kWpCont;
+  if ((rc = live.reserve((size_t)live_cap * 4)) || (rc = flag.reserve(8))) return bail(rc);
+  unsigned int *d_flag = flag.as<unsigned int>();
+  if (hipMemsetAsync(d_flag, 0, 8, t->stream) != hipSuccess) return bail(fail(SWT_ERR_HIP, "hipMemset failed"));
   if (t->n_words)
-    hipLaunchKernelGGL(sym_hist_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff, t->d_wlen,
+    hipLaunchKernelGGL(sym_hist_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, t->stream, t->d_sym, t->d_woff,
                        t->d_freq, t->n_words, t->d_sfreq, kWpSymCap, d_flag);
   // the initial vocabulary (wordpiece.py:62-63) = the symbols that occur
-  DevBuf live;
-  const uint32_t live_cap = 2 * kWpCont;
-  if ((rc = live.reserve((size_t)live_cap * 4))) { swt_bpe_train_destroy(t); return rc; }
-  hipLaunchKernelGGL(wp_live_symbols_kernel, dim3(1024), dim3(256), 0, 0, (const long long *)t->d_sfreq, (uint64_t)kWpMergedBase,
+  hipLaunchKernelGGL(wp_live_symbols_kernel, dim3(1024), dim3(256), 0, t->stream, (const long long *)t->d_sfreq, (uint64_t)kWpMergedBase,
                      live.as<uint32_t>(), live_cap, d_flag + 1);
   unsigned int h[2] = {0, 0};
-  SWT_HIP(hipMemcpy(h, d_flag, 8, hipMemcpyDeviceToHost));
-  if (h[0]) { swt_bpe_train_destroy(t); return fail(SWT_ERR_UNSUPPORTED, "symbol id out of range for a WordPiece trainer"); }
+  if (hipMemcpyAsync(h, d_flag, 8, hipMemcpyDeviceToHost, t->stream) != hipSuccess || hipStreamSynchronize(t->stream) != hipSuccess)
+    return bail(fail(SWT_ERR_HIP, "reading the symbol census failed"));
+  if (h[0]) return bail(fail(SWT_ERR_UNSUPPORTED, "symbol id out of range for a WordPiece trainer"));
   t->base_syms.resize(h[1]);
-  if (h[1]) SWT_HIP(hipMemcpy(t->base_syms.data(), live.p, (size_t)h[1] * 4, hipMemcpyDeviceToHost));
+  if (h[1] && hipMemcpy(t->base_syms.data(), live.p, (size_t)h[1] * 4, hipMemcpyDeviceToHost) != hipSuccess)
+    return bail(fail(SWT_ERR_HIP, "reading the initial symbols failed"));
   std::sort(t->base_syms.begin(), t->base_syms.end());
   t->n_base = h[1];
-  SWT_HIP(hipMemset(d_flag, 0, 8));
-  live.release();
   *out = t;
   return SWT_OK;
 }
 
 void swt_bpe_train_destroy(swt_bpe_trainer *t) {
   if (!t) return;
-  for (void *p : {(void *)t->d_sym, (void *)t->d_woff, (void *)t->d_wlen, (void *)t->d_freq, (void *)t->d_res, (void *)t->d_parts, (void *)t->d_cmd, (void *)t->d_steplog, (void *)t->d_halt,
-                  (void *)t->d_log_keys, (void *)t->d_log_vals, (void *)t->d_sfreq})
+  (void)hipStreamSynchronize(t->stream);
+  for (void *p : {(void *)t->d_sym, (void *)t->d_woff, (void *)t->d_freq, (void *)t->d_st, (void *)t->d_parts, (void *)t->d_cmd,
+                  (void *)t->d_steplog, (void *)t->d_sfreq, (void *)t->d_cand, (void *)t->d_ccnt, (void *)t->d_ckey, (void *)t->d_cidx, (void *)t->d_buckets, (void *)t->d_idx_tag,
+                  (void *)t->d_idx_word, (void *)t->d_wstamp, (void *)t->d_wkey, (void *)t->d_seg_start, (void *)t->d_seg_of, (void *)t->d_pend,
+                  (void *)t->d_tstamp, (void *)t->d_touched, (void *)t->d_block, (void *)t->d_blocks_all, (void *)t->d_tie_line,
+                  (void *)t->d_tie_all, (void *)t->d_halt, (void *)t->K.keys, (void *)t->K.start, (void *)t->K.len, (void *)t->K.fill,
+                  (void *)t->K.words})
     if (p) (void)hipFree(p);
   table_free(t->T);
   t->tmp.release();
@@ -719,12 +1645,33 @@ int swt_bpe_train_set_pos_base(swt_bpe_trainer *t, uint64_t pos_base) {
 
 int swt_bpe_train_info(const swt_bpe_trainer *t, uint64_t *n_words, uint64_t *n_symbols, uint32_t *n_base_symbols, uint64_t *n_pairs) {
   if (!t) return fail(SWT_ERR_INVALID, "null trainer");
-  TrainResult r;
-  SWT_HIP(hipMemcpy(&r, t->d_res, sizeof r, hipMemcpyDeviceToHost));
+  TrainState r;
+  SWT_HIP(hipMemcpy(&r, t->d_st, sizeof r, hipMemcpyDeviceToHost));
   if (n_words) *n_words = t->n_words;
   if (n_symbols) *n_symbols = r.n_syms;
   if (n_base_symbols) *n_base_symbols = t->n_base;
   if (n_pairs) *n_pairs = r.n_used;
+  return SWT_OK;
+}
+
+int swt_bpe_train_stats(const swt_bpe_trainer *t, uint64_t *out, uint32_t n) {
+  if (!t || !out) return fail(SWT_ERR_INVALID, "null argument");
+  TrainState r;
+  SWT_HIP(hipMemcpy(&r, t->d_st, sizeof r, hipMemcpyDeviceToHost));
+  const uint64_t v[8] = {t->n_replans, t->theta, r.n_cand, r.idx_cursor, (uint64_t)(1ull << t->T.bits), r.flags, t->step_no, r.n_used};
+  for (uint32_t i = 0; i < n && i < 8; i++) out[i] = v[i];
+  return SWT_OK;
+}
+
+int swt_bpe_train_trace(const swt_bpe_trainer *t, uint64_t *rows, uint64_t cap_rows, uint64_t *n_rows) {
+  if (!t || !n_rows) return fail(SWT_ERR_INVALID, "null argument");
+  *n_rows = t->trace.size();
+  for (uint64_t i = 0; rows && i < t->trace.size() && i < cap_rows; i++) {
+    rows[4 * i] = t->trace[i].count;
+    rows[4 * i + 1] = t->trace[i].n_tied;
+    rows[4 * i + 2] = t->trace[i].n_cand;
+    rows[4 * i + 3] = t->trace[i].n_syms;
+  }
   return SWT_OK;
 }
 
@@ -740,29 +1687,27 @@ int swt_bpe_train_best(swt_bpe_trainer *t, uint32_t *left, uint32_t *right, uint
   if (!t || !left || !right || !count) return fail(SWT_ERR_INVALID, "null argument");
   int rc = ensure_device();
   if (rc) return rc;
-  const uint64_t cap = 1ull << t->T.bits;
-  const unsigned g = grid_for(cap, 256 * 8, kArgBlocks);  // 8 counts per thread: 4 double loads
-  unsigned int *ticket = reinterpret_cast<unsigned int *>(t->d_parts + kArgBlocks);
-  hipLaunchKernelGGL(argmax_kernel, dim3(g), dim3(256), 0, 0, t->T.keys, t->T.cnt, cap, t->d_parts, ticket, t->d_res,
-                     (const long long *)t->d_sfreq);
-  if ((rc = sync_result(t))) return rc;
-  if (t->h_res.n_tied >= 2 && t->n_words) {
-    // bpe.py:102: only a tied maximum needs the scan for the earliest (word, position)
-    hipLaunchKernelGGL(first_pos_kernel, dim3(grid_for(t->n_words, kTrainThreads, 1024)), dim3(kTrainThreads), 0, 0, t->d_sym,
-                       t->d_woff, t->d_wlen, t->n_words, t->T, t->d_res, (StepCmd *)nullptr, (StepLog *)nullptr, 0u, 0u,
-                       (unsigned int *)nullptr, t->d_sfreq);
-    hipLaunchKernelGGL(winner_kernel, dim3(1), dim3(1), 0, 0, t->d_sym, t->d_res);
-    if ((rc = sync_result(t))) return rc;
+  for (int attempt = 0;; attempt++) {
+    if (!t->cand_valid && (rc = t->replan())) return rc;
+    t->enqueue_argmax();
+    hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(64), 0, t->stream, t->d_sym, t->d_woff, t->ctx(), t->d_parts, t->n_parts,
+                       (StepCmd *)nullptr, (StepLog *)nullptr, 0u, 0u);
+    if ((rc = t->sync_state())) return rc;
+    if (!(t->h_st.flags & kFlagReplan)) break;
+    if (attempt > 64) return fail(SWT_ERR_STATE, "the candidate list cannot be rebuilt");
+    t->cand_valid = false;  // the list ran dry or overflowed: new theta, again
   }
-  const TrainResult &r = t->h_res;
+  const TrainState &r = t->h_st;
   *count = r.max_count;
   if (n_tied) *n_tied = r.n_tied;
   if (r.max_count == 0) { *left = *right = 0; if (first_pos) *first_pos = kEmptyKey; return SWT_OK; }
-  unsigned long long key = r.best_key;
+  const unsigned long long key = r.best_key;
   unsigned long long pos = kEmptyKey;
-  if (r.n_tied >= 2) {
-    if (r.best_pos != kEmptyKey) { key = r.win_key; pos = t->pos_base + r.best_pos; }
-    else key = kEmptyKey;  // none of the tied pairs occurs in this shard
+  if (r.n_tied >= 2 && r.res_pos != kEmptyKey) {
+    // the caller compares positions across shards: stream address of the pair's left symbol, after pos_base
+    uint64_t wo = 0;
+    SWT_HIP(hipMemcpy(&wo, t->d_woff + (r.res_pos >> 32), 8, hipMemcpyDeviceToHost));
+    pos = t->pos_base + wo + (uint32_t)r.res_pos;
   }
   *left = (uint32_t)(key >> 32);
   *right = (uint32_t)key;
@@ -770,108 +1715,92 @@ int swt_bpe_train_best(swt_bpe_trainer *t, uint32_t *left, uint32_t *right, uint
   return SWT_OK;
 }
 
-// New pairs one merge can create: two per occurrence (occurrences <= the pair's count, counts never grow), and never
-// more than (x, m) / (m, y) over the distinct symbols x, y plus (m, m).
-static uint64_t new_pairs_bound(const swt_bpe_trainer *t, uint64_t count_bound) {
-  if (t->d_sfreq) count_bound = 0;  // WordPiece: max_count holds a score, not a count
-  const uint64_t by_symbols = 2 * (t->n_base + t->n_applied + 1) + 1;
-  uint64_t by_count = count_bound ? 2 * count_bound : by_symbols;
-  if (t->h_res.n_syms && 2 * t->h_res.n_syms < by_count) by_count = 2 * t->h_res.n_syms;
-  return by_symbols < by_count ? by_symbols : by_count;
-}
-
-static int ensure_room(swt_bpe_trainer *t, uint64_t extra) {
-  const uint64_t cap = 1ull << t->T.bits;
-  if (2 * (t->h_res.n_used + extra + 64) <= cap) return SWT_OK;
-  uint32_t bits = t->T.bits;
-  while ((1ull << bits) < 4 * (t->h_res.n_used + extra + 64)) bits++;
-  if (bits > 32) return fail(SWT_ERR_UNSUPPORTED, "pair table would exceed 2^32 slots");
-  int rc = table_resize(t, bits);
-  if (rc) return rc;
-  return sync_result(t);
-}
-
 int swt_bpe_train_apply(swt_bpe_trainer *t, uint32_t left, uint32_t right, uint32_t merged) {
   if (!t) return fail(SWT_ERR_INVALID, "null trainer");
   int rc = ensure_device();
   if (rc) return rc;
+  if (t->sharded) return fail(SWT_ERR_STATE, "a sharded trainer is stepped by swt_bpe_train_run_sharded");
+  if (merged == kHole) return fail(SWT_ERR_INVALID, "symbol id 0xFFFFFFFF is reserved");
+  if (t->d_sfreq && (left >= kWpSymCap || right >= kWpSymCap || merged >= kWpSymCap))
+    return fail(SWT_ERR_UNSUPPORTED, "WordPiece symbol id beyond %llu", (unsigned long long)kWpSymCap);
   // keep the load factor below 1/2 whatever this merge creates
-  const uint64_t occ = new_pairs_bound(t, t->h_res.max_count);
+  const uint64_t occ = new_pairs_bound(t, t->h_st.max_count);
   if ((rc = ensure_room(t, occ))) return rc;
-  if (t->logging) SWT_HIP(hipMemsetAsync(&t->d_res->n_log, 0, 8, 0));
-  if (t->d_sfreq) {
-    if (left >= kWpSymCap || right >= kWpSymCap || merged >= kWpSymCap)
-      return fail(SWT_ERR_UNSUPPORTED, "WordPiece symbol id beyond %llu", (unsigned long long)kWpSymCap);
-    hipLaunchKernelGGL(wp_move_freq_kernel, dim3(1), dim3(1), 0, 0, t->T, left, right, merged, t->d_sfreq);
-  }
-  prof_begin(0);
-  if (t->n_words)
-    hipLaunchKernelGGL(apply_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff,
-                       t->d_wlen, t->d_freq, t->n_words, left, right, merged, t->T, t->d_res,
-                       t->logging ? t->d_log_keys : nullptr, t->logging ? t->d_log_vals : nullptr, t->log_cap,
-                       (const StepCmd *)nullptr, t->d_sfreq);
-  prof_end(0);
+  if ((rc = ensure_steps(t, 2, merged))) return rc;
+  if (!t->cand_valid && (rc = t->replan())) return rc;
+  t->step_no++;
+  hipLaunchKernelGGL(set_cmd_kernel, dim3(1), dim3(1), 0, t->stream, t->ctx(), t->d_cmd, left, right, merged);
+  t->enqueue_apply();
   SWT_HIP(hipGetLastError());
-  // n_used may have grown; the next best() refreshes h_res.  Be conservative until then.
-  t->h_res.n_used += occ;
+  // n_used may have grown; the next best() refreshes h_st.  Be conservative until then.
+  t->h_st.n_used += occ;
   t->n_applied++;
   return SWT_OK;
 }
 
-// Up to max_steps iterations of {argmax, tie-break, apply} enqueued back to back: the pair of step i stays on the device
-// (decide_kernel -> apply_kernel), only the log comes back.  Step i merges into symbol first_merged + i.
+// Up to max_steps iterations of {argmax, tie-break, decide, apply} enqueued back to back: the pair of step i stays on the
+// device (decide_kernel -> apply_kernel), only the log comes back.  Step i merges into symbol first_merged + i.
 int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_merged, uint32_t *left, uint32_t *right,
                       uint64_t *count, uint32_t *n_done) {
   if (!t || !left || !right || !count || !n_done) return fail(SWT_ERR_INVALID, "null argument");
-  if (t->logging) return fail(SWT_ERR_STATE, "swt_bpe_train_run is for unsharded training (deltas are exchanged per step)");
+  if (t->sharded) return fail(SWT_ERR_STATE, "swt_bpe_train_run is for unsharded training (see swt_bpe_train_run_sharded)");
   if (t->d_sfreq && (uint64_t)first_merged + max_steps > kWpSymCap)
     return fail(SWT_ERR_UNSUPPORTED, "WordPiece symbol id beyond %llu", (unsigned long long)kWpSymCap);
+  if ((uint64_t)first_merged + max_steps >= 0xFFFFFFFFull) return fail(SWT_ERR_UNSUPPORTED, "merged symbol ids would reach the reserved id");
   int rc = ensure_device();
   if (rc) return rc;
   *n_done = 0;
   std::vector<StepLog> hlog(kMaxRunSteps);
   uint32_t done = 0;
-  unsigned int *ticket = reinterpret_cast<unsigned int *>(t->d_parts + kArgBlocks);
-  unsigned int *ticket2 = reinterpret_cast<unsigned int *>(t->d_halt);
   bool exhausted = false;
+  int dry_runs = 0;
   while (done < max_steps && !exhausted) {
     uint32_t k = max_steps - done;
     if (k > kRunBatch) k = kRunBatch;
     // room for the whole batch (the symbol count grows by one per step, counts never grow)
     const uint64_t by_sym = 2 * (t->n_base + t->n_applied + k + 1) + 1;
-    uint64_t per = new_pairs_bound(t, t->h_res.max_count);
-    if (t->h_res.max_count == 0 || by_sym < per) per = by_sym;
+    uint64_t per = new_pairs_bound(t, t->h_st.max_count);
+    if (t->h_st.max_count == 0 || by_sym < per) per = by_sym;
     if ((rc = ensure_room(t, per * k))) return rc;
-    const uint64_t cap = 1ull << t->T.bits;
-    const unsigned g = grid_for(cap, 256 * 8, kArgBlocks);  // 8 counts per thread: 4 double loads
-    const unsigned gw = grid_for(t->n_words ? t->n_words : 1, kTrainThreads * 8, 256);
-    SWT_HIP(hipMemsetAsync(t->d_halt, 0, 8, 0));
-    prof_begin(0);  // one bracket around the whole batch of merge steps: bench.py divides by the merges done
+    if ((rc = ensure_steps(t, k, first_merged + done + k))) return rc;
+    if ((!t->cand_valid || (!t->theta && !t->d_sfreq) || t->h_st.n_cand > kCandHigh) && (rc = t->replan())) return rc;
+    prof_begin(t->stream);  // one bracket around the whole batch of merge steps: bench.py divides by the merges done
+    const bool fast = t->theta && !t->d_sfreq && t->n_words;
     for (uint32_t i = 0; i < k; i++) {
-      hipLaunchKernelGGL(argmax_kernel, dim3(g), dim3(256), 0, 0, t->T.keys, t->T.cnt, cap, t->d_parts, ticket, t->d_res,
-                         (const long long *)t->d_sfreq);
-      hipLaunchKernelGGL(first_pos_kernel, dim3(gw), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff, t->d_wlen, t->n_words, t->T,
-                         t->d_res, t->d_cmd, t->d_steplog, i, first_merged + done + i, ticket2, t->d_sfreq);
-      if (t->n_words)
-        hipLaunchKernelGGL(apply_kernel, dim3(grid_for(t->n_words, kTrainThreads)), dim3(kTrainThreads), 0, 0, t->d_sym, t->d_woff,
-                           t->d_wlen, t->d_freq, t->n_words, 0u, 0u, 0u, t->T, t->d_res, (unsigned long long *)nullptr,
-                           (long long *)nullptr, (uint64_t)0, (const StepCmd *)t->d_cmd, t->d_sfreq);
+      t->step_no++;
+      if (fast) {
+        t->enqueue_fast_step(i, first_merged + done + i);
+        continue;
+      }
+      t->enqueue_argmax();
+      hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(64), 0, t->stream, t->d_sym, t->d_woff, t->ctx(), t->d_parts, t->n_parts, t->d_cmd,
+                         t->d_steplog, i, first_merged + done + i);
+      t->enqueue_apply();
     }
-    prof_end(0);
+    prof_end(t->stream);
     SWT_HIP(hipGetLastError());
-    SWT_HIP(hipMemcpy(hlog.data(), t->d_steplog, k * sizeof(StepLog), hipMemcpyDeviceToHost));
-    if ((rc = sync_result(t))) return rc;
+    SWT_HIP(hipMemcpyAsync(hlog.data(), t->d_steplog, k * sizeof(StepLog), hipMemcpyDeviceToHost, t->stream));
+    if ((rc = t->sync_state())) return rc;
     uint32_t good = 0;
     while (good < k && hlog[good].flag == 0) {
       left[done] = hlog[good].l;
       right[done] = hlog[good].r;
       count[done] = hlog[good].count;
+      t->trace.push_back(hlog[good]);
       done++;
       good++;
     }
     t->n_applied += good;
-    if (good && !t->d_sfreq) t->h_res.max_count = hlog[good - 1].count;  // counts never grow: bound for the next batch
-    if (good < k) exhausted = true;  // bpe.py:98-99: no pair left (later steps of the batch were no-ops)
+    if (good && !t->d_sfreq) t->h_st.max_count = hlog[good - 1].count;  // counts never grow: bound for the next batch
+    if (good < k) {
+      if (hlog[good].flag == 3) {  // the candidate list ran dry: later steps of the batch were no-ops; new theta, go on
+        t->cand_valid = false;
+        if (!good && ++dry_runs > 64) return fail(SWT_ERR_STATE, "the candidate list cannot be rebuilt");
+      } else {
+        exhausted = true;  // bpe.py:98-99: no pair left
+      }
+    }
+    if (good) dry_runs = 0;
   }
   *n_done = done;
   return SWT_OK;
@@ -879,17 +1808,18 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
 
 int swt_bpe_train_export(swt_bpe_trainer *t, uint32_t *syms, uint64_t syms_cap, uint64_t *word_off, uint32_t *freq) {
   if (!t || !word_off) return fail(SWT_ERR_INVALID, "null argument");
-  std::vector<uint32_t> wlen(t->n_words + 1), all(t->n_syms0 + 1);
+  SWT_HIP(hipStreamSynchronize(t->stream));
+  std::vector<uint32_t> all(t->n_syms0 + 1);
   std::vector<uint64_t> woff(t->n_words + 1);
-  if (t->n_words) SWT_HIP(hipMemcpy(wlen.data(), t->d_wlen, t->n_words * 4, hipMemcpyDeviceToHost));
   SWT_HIP(hipMemcpy(woff.data(), t->d_woff, (t->n_words + 1) * 8, hipMemcpyDeviceToHost));
   if (t->n_syms0) SWT_HIP(hipMemcpy(all.data(), t->d_sym, t->n_syms0 * 4, hipMemcpyDeviceToHost));
   uint64_t o = 0;
   for (uint64_t w = 0; w < t->n_words; w++) {
     word_off[w] = o;
-    for (uint32_t i = 0; i < wlen[w]; i++) {
+    for (uint64_t i = woff[w]; i < woff[w + 1]; i++) {
+      if (all[i] == kHole) continue;
       if (o >= syms_cap) return fail(SWT_ERR_CAPACITY, "syms buffer too small");
-      syms[o++] = all[woff[w] + i];
+      syms[o++] = all[i];
     }
   }
   word_off[t->n_words] = o;
@@ -900,69 +1830,125 @@ int swt_bpe_train_export(swt_bpe_trainer *t, uint32_t *syms, uint64_t syms_cap, 
 int swt_bpe_train_histogram(swt_bpe_trainer *t, uint64_t *keys, uint64_t *counts, uint64_t cap, uint64_t *n) {
   if (!t || !n) return fail(SWT_ERR_INVALID, "null argument");
   int rc;
-  if ((rc = t->tmp.reserve(cap * 16 + 16))) return rc;
+  if ((rc = t->tmp.reserve(cap * 16 + 32))) return rc;
   unsigned long long *d_n = t->tmp.as<unsigned long long>();
-  unsigned long long *d_k = d_n + 1;
-  long long *d_v = reinterpret_cast<long long *>(d_k + cap);
-  SWT_HIP(hipMemset(d_n, 0, 8));
+  DeltaRec *d_r = reinterpret_cast<DeltaRec *>(d_n + 2);
+  SWT_HIP(hipMemsetAsync(d_n, 0, 8, t->stream));
   const uint64_t tcap = 1ull << t->T.bits;
-  hipLaunchKernelGGL(table_export_kernel, dim3(grid_for(tcap, 256, 4096)), dim3(256), 0, 0, t->T.keys, t->T.cnt, tcap, d_k, d_v, cap, d_n);
+  hipLaunchKernelGGL(table_export_kernel, dim3(grid_for(tcap, 256, 4096)), dim3(256), 0, t->stream, t->T.keys, t->T.cnt, tcap, d_r, cap, d_n);
   unsigned long long got = 0;
-  SWT_HIP(hipMemcpy(&got, d_n, 8, hipMemcpyDeviceToHost));
+  SWT_HIP(hipMemcpyAsync(&got, d_n, 8, hipMemcpyDeviceToHost, t->stream));
+  SWT_HIP(hipStreamSynchronize(t->stream));
   *n = got;
   if (got > cap) return fail(SWT_ERR_CAPACITY, "histogram holds %llu live pairs", got);
   if (got) {
-    SWT_HIP(hipMemcpy(keys, d_k, got * 8, hipMemcpyDeviceToHost));
-    SWT_HIP(hipMemcpy(counts, d_v, got * 8, hipMemcpyDeviceToHost));
+    std::vector<DeltaRec> h(got);
+    SWT_HIP(hipMemcpy(h.data(), d_r, got * sizeof(DeltaRec), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < got; i++) { keys[i] = h[i].key; counts[i] = (uint64_t)h[i].delta; }
   }
-  return SWT_OK;
-}
-
-// ---- sharded training -----------------------------------------------------------------------------
-
-int swt_bpe_train_take_deltas(swt_bpe_trainer *t, uint64_t *d_keys, int64_t *d_vals, uint64_t cap, uint64_t *n, void *stream) {
-  if (!t || !n) return fail(SWT_ERR_INVALID, "null argument");
-  hipStream_t st = (hipStream_t)stream;
-  if (!t->logging) {
-    // first call: switch logging on and hand out the whole local histogram as the initial "delta"
-    t->log_cap = 4 * t->n_syms0 + 1024;
-    SWT_HIP(hipMalloc((void **)&t->d_log_keys, t->log_cap * 8));
-    SWT_HIP(hipMalloc((void **)&t->d_log_vals, t->log_cap * 8));
-    t->logging = true;
-    SWT_HIP(hipMemsetAsync(&t->d_res->n_log, 0, 8, st));
-    const uint64_t tcap = 1ull << t->T.bits;
-    hipLaunchKernelGGL(table_export_kernel, dim3(grid_for(tcap, 256, 4096)), dim3(256), 0, st, t->T.keys, t->T.cnt, tcap,
-                       t->d_log_keys, t->d_log_vals, t->log_cap, &t->d_res->n_log);
-  }
-  unsigned long long got = 0;
-  SWT_HIP(hipMemcpyAsync(&got, &t->d_res->n_log, 8, hipMemcpyDeviceToHost, st));
-  SWT_HIP(hipStreamSynchronize(st));
-  *n = got;
-  if (got > t->log_cap) return fail(SWT_ERR_CAPACITY, "delta log overflow (%llu entries)", got);
-  if (got > cap) return fail(SWT_ERR_CAPACITY, "delta buffer too small: need %llu entries", got);
-  if (got) {
-    SWT_HIP(hipMemcpyAsync(d_keys, t->d_log_keys, got * 8, hipMemcpyDeviceToDevice, st));
-    SWT_HIP(hipMemcpyAsync(d_vals, t->d_log_vals, got * 8, hipMemcpyDeviceToDevice, st));
-  }
-  return SWT_OK;
-}
-
-int swt_bpe_train_add_remote(swt_bpe_trainer *t, const uint64_t *d_keys, const int64_t *d_vals, uint64_t n, void *stream) {
-  if (!t || (n && (!d_keys || !d_vals))) return fail(SWT_ERR_INVALID, "null argument");
-  if (!n) return SWT_OK;
-  int rc = sync_result(t);
-  if (rc) return rc;
-  const uint64_t cap = 1ull << t->T.bits;
-  if (2 * (t->h_res.n_used + n + 64) > cap) {
-    uint32_t bits = t->T.bits;
-    while ((1ull << bits) < 4 * (t->h_res.n_used + n + 64)) bits++;
-    if (bits > 32) return fail(SWT_ERR_UNSUPPORTED, "pair table would exceed 2^32 slots");
-    if ((rc = table_resize(t, bits))) return rc;
-  }
-  hipLaunchKernelGGL(add_remote_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const unsigned long long *>(d_keys), reinterpret_cast<const long long *>(d_vals), n, t->T, t->d_res);
-  SWT_HIP(hipGetLastError());
   return SWT_OK;
 }
 
 }  // extern "C"
+
+// ---- sharded training: the pieces swt_dist.hip drives --------------------------------------------------------------------
+
+namespace swt {
+
+int trainer_set_block_cap(swt_bpe_trainer *t, uint64_t block_cap) {
+  if (block_cap < 64) block_cap = 64;
+  if (block_cap <= t->block_cap) return SWT_OK;
+  SWT_HIP(hipStreamSynchronize(t->stream));
+  for (void *p : {(void *)t->d_touched, (void *)t->d_block, (void *)t->d_blocks_all}) if (p) (void)hipFree(p);
+  t->d_touched = nullptr; t->d_block = nullptr; t->d_blocks_all = nullptr;
+  t->touched_cap = block_cap - 1;
+  t->block_cap = block_cap;
+  SWT_HIP(hipMalloc((void **)&t->d_touched, (size_t)t->touched_cap * 4));
+  SWT_HIP(hipMalloc((void **)&t->d_block, (size_t)block_cap * sizeof(DeltaRec)));
+  SWT_HIP(hipMalloc((void **)&t->d_blocks_all, (size_t)block_cap * sizeof(DeltaRec) * t->world));
+  // whatever was pending is listed again from pend[] itself
+  SWT_HIP(hipMemsetAsync(&t->d_st->n_touched, 0, 8, t->stream));
+  const uint64_t cap = 1ull << t->T.bits;
+  hipLaunchKernelGGL(rebuild_touched_kernel, dim3(grid_for(cap, 256, 2048)), dim3(256), 0, t->stream, t->ctx(), cap);
+  SWT_HIP(hipGetLastError());
+  return SWT_OK;
+}
+
+int trainer_enter_sharded(swt_bpe_trainer *t, uint32_t world, uint64_t block_cap) {
+  if (t->d_sfreq) return fail(SWT_ERR_UNSUPPORTED, "sharded training is built for BPE");
+  if (t->sharded) return fail(SWT_ERR_STATE, "the trainer is already sharded");
+  t->sharded = true;
+  t->world = world;
+  int rc = sharded_arrays(t);
+  if (rc) return rc;
+  SWT_HIP(hipMalloc((void **)&t->d_halt, 8));
+  SWT_HIP(hipMemsetAsync(t->d_halt, 0, 8, t->stream));
+  SWT_HIP(hipMalloc((void **)&t->d_tie_line, 16));
+  SWT_HIP(hipMalloc((void **)&t->d_tie_all, (size_t)world * 16));
+  return trainer_set_block_cap(t, block_cap);
+}
+
+// the local histogram as one record list (the one-off reduction at start)
+int trainer_export_records(swt_bpe_trainer *t, DeltaRec *d_out, uint64_t cap, uint64_t *n) {
+  unsigned long long *d_n = &t->d_st->scratch;
+  SWT_HIP(hipMemsetAsync(d_n, 0, 8, t->stream));
+  const uint64_t tcap = 1ull << t->T.bits;
+  hipLaunchKernelGGL(table_export_kernel, dim3(grid_for(tcap, 256, 4096)), dim3(256), 0, t->stream, t->T.keys, t->T.cnt, tcap, d_out, cap, d_n);
+  unsigned long long got = 0;
+  SWT_HIP(hipMemcpyAsync(&got, d_n, 8, hipMemcpyDeviceToHost, t->stream));
+  SWT_HIP(hipStreamSynchronize(t->stream));
+  *n = got;
+  return SWT_OK;
+}
+
+int trainer_add_records(swt_bpe_trainer *t, const DeltaRec *d_recs, uint64_t n) {
+  if (!n) return SWT_OK;
+  int rc = t->sync_state();
+  if (rc) return rc;
+  if ((rc = ensure_room(t, n))) return rc;
+  TrainCtx C = t->ctx();
+  C.pend = nullptr;
+  C.theta = 0;  // the candidate list is built after the replicas are whole
+  t->cand_valid = false;
+  hipLaunchKernelGGL(add_records_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, t->stream, d_recs, n, C);
+  SWT_HIP(hipGetLastError());
+  return t->sync_state();
+}
+
+int trainer_prepare_batch(swt_bpe_trainer *t, uint32_t k, uint32_t max_merged) {
+  int rc = t->sync_state();
+  if (rc) return rc;
+  // every rank's new pairs land in every replica: the bound is over the whole corpus
+  const uint64_t by_sym = 2 * (t->n_base_global + t->n_applied + k + 1) + 1;
+  uint64_t per = t->h_st.max_count ? 2 * t->h_st.max_count : by_sym;
+  if (by_sym < per) per = by_sym;
+  if ((rc = ensure_room(t, per * k))) return rc;
+  if ((rc = ensure_steps(t, k, max_merged))) return rc;
+  if ((!t->cand_valid || !t->theta) && (rc = t->replan())) return rc;
+  return SWT_OK;
+}
+
+void trainer_enqueue_tie_send(swt_bpe_trainer *t) {
+  t->enqueue_argmax();
+  hipLaunchKernelGGL(tie_send_kernel, dim3(1), dim3(64), 0, t->stream, t->ctx(), t->d_parts, t->n_parts, t->d_sym, t->d_woff, t->d_tie_line);
+}
+
+void trainer_enqueue_pack(swt_bpe_trainer *t) {
+  hipLaunchKernelGGL(pack_records_kernel, dim3(kPackBlocks), dim3(256), 0, t->stream, t->ctx(), t->d_block, t->block_cap);
+}
+
+void trainer_enqueue_decide_apply(swt_bpe_trainer *t, uint32_t rank, uint32_t log_i, uint32_t merged) {
+  hipLaunchKernelGGL(decide_sharded_kernel, dim3(1), dim3(64), 0, t->stream, t->ctx(), t->d_parts, t->n_parts, t->d_tie_all, t->world, rank,
+                     t->d_cmd, t->d_steplog, log_i, merged, t->d_halt);
+  t->enqueue_apply();
+  trainer_enqueue_pack(t);
+}
+
+void trainer_enqueue_add_blocks(swt_bpe_trainer *t) {
+  TrainCtx C = t->ctx();
+  C.pend = nullptr;  // the blocks go into the counts themselves
+  hipLaunchKernelGGL(add_blocks_kernel, dim3(kPackBlocks), dim3(256), 0, t->stream, t->d_blocks_all, t->world, t->block_cap, C, t->d_halt);
+  hipLaunchKernelGGL(finish_exchange_kernel, dim3(1), dim3(256), 0, t->stream, t->d_blocks_all, t->world, t->block_cap, t->ctx(), t->d_halt);
+}
+
+}  // namespace swt

@@ -28,7 +28,13 @@ int fail(int code, const char *fmt, ...);
 int ensure_device();  // SWT_OK when a device is selected (selects 0 on first use)
 int device_cus();
 
-int debug_knob(int which);
+// Ablation switches of the encode kernels (skip a phase: results are WRONG while set).  They exist only in a library built
+// with -DSWT_ABLATION (tools/gpu_ablate*.py); the product build folds them to zero.
+#ifdef SWT_ABLATION
+int ablation_knob(int which);
+#else
+constexpr int ablation_knob(int) { return 0; }
+#endif
 
 // ---- dominant-kernel timing (bench.py roofline) ---------------------------------------------------
 // level 1 = the dominant kernel of a path, 2 = all kernels of a call, 3.. = diagnostics (swt_profile_enable selects one)

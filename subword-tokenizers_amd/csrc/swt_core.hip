@@ -93,11 +93,14 @@ void DevBuf::release() {
   cap = 0;
 }
 
+#ifdef SWT_ABLATION
 static int g_knobs[8] = {0};
-int debug_knob(int which) { return (which >= 0 && which < 8) ? g_knobs[which] : 0; }
+int ablation_knob(int which) { return (which >= 0 && which < 8) ? g_knobs[which] : 0; }
+#endif
 
-static int g_prof_on = 0;  // 0 off, else the level that is being timed
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pending, g_prof_pool;
+// timing state of the calling thread (a handle is used by one host thread at a time: nothing here is shared)
+static thread_local int g_prof_on = 0;  // 0 off, else the level that is being timed
+static thread_local std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pending, g_prof_pool;
 
 void prof_begin(hipStream_t st, int level) {
   if (g_prof_on != level) return;
@@ -181,11 +184,13 @@ int swt_device_info(int *n_cu, char *name, size_t name_cap) {
   return SWT_OK;
 }
 
-int swt_debug_knob(int which, int value) {
+#ifdef SWT_ABLATION
+int swt_ablation_knob(int which, int value) {  // not declared in include/swt.h: ablation builds only
   if (which < 0 || which >= 8) return swt::fail(SWT_ERR_INVALID, "no such knob");
   swt::g_knobs[which] = value;
   return SWT_OK;
 }
+#endif
 
 int swt_profile_enable(int on) {
   swt::g_prof_on = on;

@@ -33,6 +33,8 @@ enum DedupMode {
 struct DedupEngine {
   DevBuf slot, rec, drec, uslot, utext, uoff, misc, newlist, tile_new, new_local, new_blk, tile_words;
   uint32_t bits = 0, epoch = 0;
+  int opt_mode = 0;            // SWT_OPT_DEDUP of the owning handle: 0 by batch size, 1 never, 2 always
+  uint32_t opt_table_bits = 0; // SWT_OPT_DEDUP_TABLE_BITS: log2 of the word table's slots (0: sized from the batch)
   void release();
   unsigned long long *rec_ptr() const { return rec.as<unsigned long long>(); }    // per table slot: count:32 | unique index:32
   unsigned long long *drec_ptr() const { return drec.as<unsigned long long>(); }  // per unique word: count:32 | place:32

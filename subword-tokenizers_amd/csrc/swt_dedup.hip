@@ -680,8 +680,8 @@ int dedup_front(DedupEngine &E, TileWorkspace &ws, const uint8_t *d_text, uint64
   // (see DedupTab); never cleared (epoch).  rec[] = the table's slots, then the own slots of the words that overflowed.
   uint32_t bits = 16;
   while ((1ull << bits) < n_bytes / 32 && bits < 24) bits++;
-  if (debug_knob(4) > 0) {  // tests: a table of 2^knob slots, so that words overflow it
-    bits = (uint32_t)debug_knob(4);
+  if (E.opt_table_bits) {  // SWT_OPT_DEDUP_TABLE_BITS (tests: a table so small that words overflow it)
+    bits = E.opt_table_bits;
     if (bits != E.bits) E.bits = 0;
   }
   if (bits > E.bits) {
@@ -714,7 +714,7 @@ int dedup_front(DedupEngine &E, TileWorkspace &ws, const uint8_t *d_text, uint64
   D.slot = E.slot.as<unsigned long long>();
   D.rec = E.rec.as<unsigned long long>();
   D.n_bytes = n_bytes;
-  D.diag = (debug_knob(2) & 4) ? 1u : 0u;
+  D.diag = (ablation_knob(2) & 4) ? 1u : 0u;
   D.bits = E.bits;
   D.epoch = E.epoch;
   D.ovf_shift = ovf_shift;
@@ -729,10 +729,10 @@ int dedup_front(DedupEngine &E, TileWorkspace &ws, const uint8_t *d_text, uint64
   prof_begin(st, 3);
   if (mode == kDedupWp)
     hipLaunchKernelGGL(wordref_kernel<kDedupWp>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off, plan1, d_cls, D, wref,
-                       ws.sent_local.as<uint32_t>(), E.tile_words.as<uint32_t>(), (uint32_t)debug_knob(2));
+                       ws.sent_local.as<uint32_t>(), E.tile_words.as<uint32_t>(), (uint32_t)ablation_knob(2));
   else
     hipLaunchKernelGGL(wordref_kernel<kDedupBpe>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off, plan1, d_cls, D, wref,
-                       ws.sent_local.as<uint32_t>(), E.tile_words.as<uint32_t>(), (uint32_t)debug_knob(2));
+                       ws.sent_local.as<uint32_t>(), E.tile_words.as<uint32_t>(), (uint32_t)ablation_knob(2));
   prof_end(st, 3);
   launch_scan_u64(n_tiles, D.tile_new, new_local, new_blk, reinterpret_cast<uint64_t *>(d_misc), st);
   if (mode == kDedupWp)

@@ -1,0 +1,185 @@
+// swt_train.h -- the trainer's device state and the pieces swt_dist.hip (sharded training) drives.
+#pragma once
+
+#include <vector>
+
+#include "swt_common.h"
+
+namespace swt {
+
+constexpr uint32_t kMaxRunSteps = 512;
+constexpr uint32_t kRunBatch = 256;     // merges enqueued per host round trip
+constexpr uint32_t kArgParts = 256;     // workgroup partials of an argmax launch (combined by every consumer)
+constexpr uint32_t kCandBlocks = 32;    // cand_argmax_kernel
+constexpr uint32_t kCandTarget = 1024;  // pairs the candidate threshold theta lets through at a re-plan: every workgroup of the
+                                        // fast path scans the whole list itself, so it is kept short
+constexpr uint32_t kCandHigh = 2048;    // re-plan at a batch boundary once pushes have grown the list beyond this
+constexpr uint32_t kCandCap = 8192;     // room for the pairs that cross theta afterwards
+constexpr uint32_t kTieSet = 256;       // tied pairs a workgroup keeps in its LDS set (more: membership by table probe)
+constexpr uint32_t kTieBlocks = 128;
+constexpr uint32_t kApplyBlocks = 512;
+constexpr uint32_t kFastApplyBlocks = 128;
+constexpr uint32_t kPackBlocks = 16;
+constexpr uint32_t kSegBase = 0xFFFFFFFFu;  // seg_of[]: the id names a symbol of the initial stream
+
+constexpr uint32_t kFlagIndexBroken = 1u;  // a merged id was reused (or the index log overflowed): applies scan every word
+constexpr uint32_t kFlagBrokenPending = 4u; // fast path: kFlagIndexBroken from the next step on
+constexpr uint32_t kFlagReplan = 2u;       // the candidate list ran dry or overflowed: steps are no-ops until the host re-plans
+
+struct TrainState {
+  unsigned long long max_count;  // result of the last decide: the maximum (count, or WordPiece score bits)
+  unsigned long long n_tied;     //   pairs holding it
+  unsigned long long best_pos;   // tie scan: word << 32 | offset (kEmptyKey: none found); reset by decide
+  unsigned long long best_key;   //   the winning pair
+  unsigned long long n_used;     // distinct keys in the table
+  unsigned long long res_pos;    //   position of the tie winner in this shard (kEmptyKey: not tied / not here)
+  unsigned long long n_syms;     // live symbols
+  unsigned long long win_key;
+  unsigned long long n_cand;     // candidate list length
+  unsigned long long idx_cursor; // entries in the index log
+  unsigned long long plateau;    // count level the tie cursor holds for
+  unsigned long long n_touched;  // sharded: slots with pending deltas
+  unsigned long long scratch;
+  unsigned long long best2[2];   // fast path: tie scan result of the step, by step parity (the other one is reset meanwhile)
+  unsigned long long n_synced;   // candidates [0, n_synced) have their count and key mirrored in ccnt[] / ckey[]
+  unsigned long long n_synced_next;
+  unsigned int cursor_w;         // the tie scan may start at this word
+  unsigned int flags;
+};
+
+struct StepCmd {
+  uint32_t l, r, m, valid;
+};
+
+struct StepLog {
+  uint32_t l, r;
+  unsigned long long count;
+  unsigned long long flag;    // 0 merged, 2 no pair left, 3 candidate list dry (re-plan), 4 exchange block overflow (sharded)
+  unsigned long long n_syms;  // live symbols before this merge
+  unsigned long long n_tied;  // pairs that held the maximum
+  unsigned long long n_cand;  // candidate list length
+};
+
+struct ArgPart {
+  unsigned long long mx, cnt, key;
+};
+
+struct DeltaRec {
+  unsigned long long key;
+  long long delta;
+};
+
+struct PairTable {
+  unsigned long long *keys;
+  long long *cnt;
+  uint32_t bits;
+};
+
+// the words of every pair of the initial stream, grouped by key (static)
+struct K0Index {
+  unsigned long long *keys;
+  uint32_t *start, *len, *fill;
+  uint32_t *words;
+  uint32_t bits;
+};
+
+// everything a training kernel needs, by value
+struct TrainCtx {
+  PairTable T;
+  K0Index K;
+  TrainState *st;
+  long long *sfreq;        // WordPiece: symbol frequencies
+  unsigned long long theta;
+  uint32_t *cand;
+  uint64_t cand_cap;
+  long long *ccnt;           // compact mirror of the candidates' counts (cidx[slot] = place in the list), so that an argmax
+  unsigned long long *ckey;  // reads the list as a coalesced stream instead of a gather from the pair table
+  uint32_t *cidx;
+  uint32_t *idx_tag, *idx_word;
+  uint64_t idx_cap;
+  unsigned long long *seg_start;
+  uint32_t *seg_of;
+  uint32_t seg_cap, id_base;
+  uint32_t *wstamp;
+  unsigned long long *wkey;  // fast path: the tied pair a tie scan found in word w
+  uint32_t step;
+  long long *pend;         // sharded: per-slot pending deltas (nullptr: deltas go straight into cnt)
+  uint32_t *tstamp, *touched;
+  uint64_t touched_cap;
+};
+
+}  // namespace swt
+
+struct swt_bpe_trainer {
+  uint64_t n_words = 0, n_syms0 = 0;
+  uint32_t n_base = 0;
+  uint64_t n_base_global = 0;  // sharded: distinct initial symbols over all ranks
+  std::vector<uint32_t> base_syms;
+  hipStream_t stream = 0;
+  uint32_t *d_sym = nullptr;
+  uint64_t *d_woff = nullptr;
+  uint32_t *d_freq = nullptr;
+  swt::PairTable T{nullptr, nullptr, 0};
+  swt::K0Index K{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  swt::TrainState *d_st = nullptr;
+  swt::ArgPart *d_parts = nullptr;
+  uint32_t n_parts = 0;
+  swt::StepCmd *d_cmd = nullptr;
+  swt::StepLog *d_steplog = nullptr;
+  uint64_t n_applied = 0;  // merges applied so far (bounds the number of distinct symbols)
+  uint32_t step_no = 0;    // steps enqueued so far (index segments, word stamps)
+  swt::TrainState h_st{};
+  uint64_t pos_base = 0;
+  bool hist_ready = false;
+  long long *d_sfreq = nullptr;  // WordPiece mode: symbol frequencies, dense by symbol id
+  uint32_t id_base = SWT_SYM_BASE;
+  // candidates
+  unsigned long long theta = 0;
+  uint32_t *d_cand = nullptr;
+  uint64_t cand_cap = 0;
+  long long *d_ccnt = nullptr;
+  unsigned long long *d_ckey = nullptr;
+  uint32_t *d_cidx = nullptr;
+  uint32_t cidx_bits = 0;
+  unsigned long long *d_buckets = nullptr;
+  bool cand_valid = false;
+  uint64_t n_replans = 0;
+  // index
+  uint32_t *d_idx_tag = nullptr, *d_idx_word = nullptr, *d_wstamp = nullptr;
+  unsigned long long *d_wkey = nullptr;
+  uint64_t idx_cap = 0;
+  unsigned long long *d_seg_start = nullptr;
+  uint64_t seg_start_cap = 0;
+  uint32_t *d_seg_of = nullptr;
+  uint32_t seg_cap = 0;
+  // sharded
+  bool sharded = false;
+  uint32_t world = 1;
+  long long *d_pend = nullptr;
+  uint32_t *d_tstamp = nullptr, *d_touched = nullptr;
+  uint64_t touched_cap = 0, block_cap = 0;
+  swt::DeltaRec *d_block = nullptr, *d_blocks_all = nullptr;
+  unsigned long long *d_tie_line = nullptr, *d_tie_all = nullptr;
+  unsigned int *d_halt = nullptr;
+  swt::DevBuf tmp;
+  std::vector<swt::StepLog> trace;  // every merge so far (swt_bpe_train_trace)
+
+  swt::TrainCtx ctx() const;
+  int sync_state();
+  int replan();
+  void enqueue_argmax();
+  void enqueue_apply();
+  void enqueue_fast_step(uint32_t log_i, uint32_t merged);
+};
+
+namespace swt {
+int trainer_enter_sharded(swt_bpe_trainer *t, uint32_t world, uint64_t block_cap);
+int trainer_set_block_cap(swt_bpe_trainer *t, uint64_t block_cap);
+int trainer_export_records(swt_bpe_trainer *t, DeltaRec *d_out, uint64_t cap, uint64_t *n);
+int trainer_add_records(swt_bpe_trainer *t, const DeltaRec *d_recs, uint64_t n);
+int trainer_prepare_batch(swt_bpe_trainer *t, uint32_t k, uint32_t max_merged);
+void trainer_enqueue_tie_send(swt_bpe_trainer *t);
+void trainer_enqueue_decide_apply(swt_bpe_trainer *t, uint32_t rank, uint32_t log_i, uint32_t merged);
+void trainer_enqueue_pack(swt_bpe_trainer *t);
+void trainer_enqueue_add_blocks(swt_bpe_trainer *t);
+}  // namespace swt

@@ -626,6 +626,21 @@ int swt_wp_trie_create(const uint32_t *vocab_cps, const uint64_t *vocab_off, uin
   return SWT_OK;
 }
 
+int swt_wp_trie_set_option(swt_wp_trie *t, int option, int value) {
+  if (!t) return fail(SWT_ERR_INVALID, "null trie");
+  switch (option) {
+    case SWT_OPT_DEDUP:
+      if (value < 0 || value > 2) return fail(SWT_ERR_INVALID, "SWT_OPT_DEDUP takes 0, 1 or 2");
+      t->dd.opt_mode = value;
+      return SWT_OK;
+    case SWT_OPT_DEDUP_TABLE_BITS:
+      if (value != 0 && (value < 4 || value > 24)) return fail(SWT_ERR_INVALID, "SWT_OPT_DEDUP_TABLE_BITS takes 0 or 4..24");
+      t->dd.opt_table_bits = (uint32_t)value;
+      return SWT_OK;
+  }
+  return fail(SWT_ERR_INVALID, "no such option");
+}
+
 void swt_wp_trie_destroy(swt_wp_trie *t) {
   if (!t) return;
   if (t->d_edges) (void)hipFree(t->d_edges);
@@ -710,7 +725,7 @@ int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, c
   T.corner_nonterm = t->H.corner_nonterm ? 1u : 0u;
   T.empty_status = t->H.child(t->H.root, ' ') >= 0 ? SWT_WP_INDEXERROR : SWT_WP_OK;
   T.corner_id = t->H.corner.size() == 1 ? t->H.corner[0] : t->H.n_vocab + 2;
-  if (n_bytes <= kWpDirectBytes && n_sent <= kWpDirectSents && !(debug_knob(1) & 2)) {
+  if (n_bytes <= kWpDirectBytes && n_sent <= kWpDirectSents && t->dd.opt_mode != 2) {
     // a sentence or a few: one workgroup, one launch, the caller's arrays written by the kernel (DirectOut, swt_tile.h)
     hipLaunchKernelGGL(wp_encode_kernel, dim3(1), dim3(64), 0, st, d_text, n_bytes, d_sent_off, (const uint64_t *)nullptr, d_cls, T,
                        d_out_ids, t->ws.sent_local.as<uint32_t>(), t->ws.tile_tok.as<uint32_t>(), d_status,
@@ -719,8 +734,8 @@ int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, c
     return SWT_OK;
   }
   // debug knob 1: bit 0 = never dedup, bit 1 = dedup whatever the batch size (tests)
-  if (t->dedup_ok && T.empty_status == SWT_WP_OK && n_bytes <= kDedupMaxBytes && !(debug_knob(1) & 1) &&
-      (n_bytes >= kDedupMinBytesWp || (debug_knob(1) & 2))) {
+  if (t->dedup_ok && T.empty_status == SWT_WP_OK && n_bytes <= kDedupMaxBytes && t->dd.opt_mode != 1 &&
+      (n_bytes >= kDedupMinBytesWp || t->dd.opt_mode == 2)) {
     // Word-level dedup (swt_dedup.h): the chunks between whitespace are encoded once per call.  The encode over the unique
     // chunks is this same kernel with every chunk as a "sentence"; its launch size is fixed and the tile size follows on
     // the device (the number of unique chunks never reaches the host).

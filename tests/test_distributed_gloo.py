@@ -47,6 +47,8 @@ def test_sharded_training_protocol_world2(case, oracle, corpora, tmp_path, swt):
     assert res[0]["vocab"] == res[1]["vocab"] == ref.vocab_size
     assert res[0]["max"] == res[1]["max"] == 2.0
     assert res[0]["sum"] == res[1]["sum"] == float(len(corpus))
+    if case == "pan":
+        assert res[0]["grown"] >= 1 and res[0]["grown"] == res[1]["grown"]  # the block-overflow path (grow, repeat the exchange) ran
 
 
 def test_shard_ranges_cover_everything():

@@ -217,9 +217,10 @@ def test_config4_statuses_in_a_large_batch(wp30k, oracle, synth):
     ids, ooff, st = wp30k.encode_ids_batch(sents)
     orc = oracle.OracleWP(wp30k._tokens)
     for i in bad:
-        oi, oo, os_ = orc.tokenize_batch_ids(sents[i - 2:i + 3])
-        assert np.array_equal(st[i - 2:i + 3], os_) and os_[2] != 0
-        assert np.array_equal(ids[int(ooff[i - 2]):int(ooff[i + 3])], oi)
+        hi = min(i + 3, len(sents))
+        oi, oo, os_ = orc.tokenize_batch_ids(sents[i - 2:hi])
+        assert np.array_equal(st[i - 2:hi], os_) and os_[2] != 0
+        assert np.array_equal(ids[int(ooff[i - 2]):int(ooff[hi])], oi)
     assert int(st.astype(bool).sum()) == len(bad)
 
 

@@ -1,5 +1,6 @@
 """Parity of the HIP path (through the C ABI of libswt_hip.so) against the CPU oracle and the committed golden
 vectors.  Needs a real MI355X: run with `-m gpu`.  Bit-exact everywhere: this is integer/index work."""
+import contextlib
 import os
 
 import numpy as np
@@ -38,6 +39,21 @@ def wp(swt, dev, ref_dir):
 @pytest.fixture(scope="module")
 def wp_orc(oracle, wp):
     return oracle.OracleWP(wp._tokens)
+
+
+@contextlib.contextmanager
+def dedup(dev, mode, *toks, bits=0):
+    """SWT_OPT_DEDUP (and the word table's size) on the handles of these tokenizers, restored afterwards"""
+    handles = [getattr(t, "_table", None) or t._trie for t in toks]
+    try:
+        for h in handles:
+            h.set_option(dev.OPT_DEDUP, mode)
+            h.set_option(dev.OPT_DEDUP_TABLE_BITS, bits)
+        yield
+    finally:
+        for h in handles:
+            h.set_option(dev.OPT_DEDUP, dev.DEDUP_AUTO)
+            h.set_option(dev.OPT_DEDUP_TABLE_BITS, 0)
 
 
 def same_bpe(tok, orc, texts):
@@ -126,15 +142,12 @@ def test_bpe_dedup_path_equals_direct_path(bpe, bpe_orc, dev, corpora):
         ["a" * 4095, "b" * 4096, "c" * 4097, "d" * 2047, "e" * 2048, "f" * 2049, "g" * 1023, "h" * 1024, "i" * 1025],
         ["wyraz"] * 3000, corpora["pan"][:400], ["\U0001F600 emoji \U0001F600\U0001F601 x", "中文 字", "İstanbul", "a\x00b"],
     ]
-    try:
-        dev.debug_knob(1, 2)  # dedup whatever the size
+    with dedup(dev, dev.DEDUP_ALWAYS, bpe):  # dedup whatever the size
         for texts in cases:
             same_bpe(bpe, bpe_orc, texts)
         ids_d, off_d = bpe.encode_ids_batch(corpora["t5k"])
-        dev.debug_knob(1, 1)  # never dedup
+    with dedup(dev, dev.DEDUP_NEVER, bpe):
         ids_n, off_n = bpe.encode_ids_batch(corpora["t5k"])
-    finally:
-        dev.debug_knob(1, 0)
     assert np.array_equal(ids_d, ids_n) and np.array_equal(off_d, off_n)
     # calling again reuses the table under a new epoch
     for _ in range(3):
@@ -151,8 +164,7 @@ def test_bpe_dedup_growing_batches_and_epoch_wrap(swt, oracle, dev, bpe, corpora
     tok._build_table()
     orc = oracle.OracleBPE(merges)
     pan, t5k = corpora["pan"], corpora["t5k"]
-    try:
-        dev.debug_knob(1, 2)
+    with dedup(dev, dev.DEDUP_ALWAYS, tok):
         for texts in (pan[:3], pan[:200], t5k[:3000], pan[:50], t5k, ["a b c"]):
             same_bpe(tok, orc, texts)
         small = pan[:40]
@@ -160,22 +172,15 @@ def test_bpe_dedup_growing_batches_and_epoch_wrap(swt, oracle, dev, bpe, corpora
         for i in range(300):
             ids, off = tok.encode_ids_batch(small)
             assert np.array_equal(ids, want[0]) and np.array_equal(off, want[1]), i
-    finally:
-        dev.debug_knob(1, 0)
 
 
 def test_dedup_table_overflow_is_harmless(swt, dev, bpe, bpe_orc, wp, wp_orc, corpora):
     """the word table is small on purpose; a word that finds no slot is encoded on its own -- same ids whatever the load"""
     texts = corpora["t5k"][:2500] + ["x" * 300 + " " + "x" * 300, "hello! ok", "a ## b"]
-    try:
-        dev.debug_knob(1, 2)
-        for bits in (4, 8, 12):
-            dev.debug_knob(4, bits)
+    for bits in (4, 8, 12):
+        with dedup(dev, dev.DEDUP_ALWAYS, bpe, wp, bits=bits):
             same_bpe(bpe, bpe_orc, texts)
             same_wp(wp, wp_orc, texts)
-    finally:
-        dev.debug_knob(4, 0)
-        dev.debug_knob(1, 0)
     same_bpe(bpe, bpe_orc, texts)
     same_wp(wp, wp_orc, texts)
 
@@ -230,13 +235,10 @@ def test_random_tables_and_texts_both_paths(swt, oracle, dev):
         for _ in range(rng.randint(1, 60)):
             words = ["".join(rng.choice(alpha) for _ in range(rng.randint(1, 12))) for _ in range(rng.randint(0, 30))]
             texts.append(rng.choice(["", " ", "  "]).join([""] + words) if rng.random() < 0.2 else " ".join(words))
-        try:
-            for knob in (1, 2):
-                dev.debug_knob(1, knob)
+        for mode in (dev.DEDUP_NEVER, dev.DEDUP_ALWAYS):
+            with dedup(dev, mode, bpe, wp):
                 same_bpe(bpe, borc, texts)
                 same_wp(wp, worc, texts)
-        finally:
-            dev.debug_knob(1, 0)
 
 
 def test_device_lowercase_equals_str_lower(swt, dev, bpe, bpe_orc, corpora):
@@ -433,16 +435,13 @@ def test_wp_dedup_path_equals_direct_path(swt, wp, wp_orc, dev, golden, corpora,
     tut.load_resources(os.path.join(ref_dir, "resources/tests/FastWordPiece"))
     from oracle import oracle as O
     tut_orc = O.OracleWP(tut._tokens)
-    try:
-        dev.debug_knob(1, 2)  # dedup whatever the size
+    with dedup(dev, dev.DEDUP_ALWAYS, wp, tut):  # dedup whatever the size
         for texts in cases:
             same_wp(wp, wp_orc, texts)
             same_wp(tut, tut_orc, texts)
         got_d = wp.encode_ids_batch(corpora["t5k"])
-        dev.debug_knob(1, 1)  # never dedup
+    with dedup(dev, dev.DEDUP_NEVER, wp):
         got_n = wp.encode_ids_batch(corpora["t5k"])
-    finally:
-        dev.debug_knob(1, 0)
     for a, b in zip(got_d, got_n):
         assert np.array_equal(a, b)
     for _ in range(3):  # the table is reused under a new epoch
@@ -696,16 +695,53 @@ def test_wp_train_state_matches_oracle(swt, oracle, dev, corpora):
     assert fw.tokenize("Ala ma kota") == fw.tokenize("ala ma kota")
 
 
-def test_sharded_training_two_handles(swt, oracle, dev, corpora):
-    """two shards on one GPU: local histograms exchanged once, delta lists after every merge, tie-break by
-    the smallest (pos_base + position) -- must reproduce the single-shard merges exactly"""
-    torch = pytest.importorskip("torch")
-    from subword_tokenizers_amd.distributed import LocalGroup, ShardedBpeTrainer
+def test_sharded_training_loopback_runner(swt, oracle, dev, corpora):
+    """csrc/swt_dist.hip through the loop-back communicator: 2, 3 and 5 shards as trainers of this process on one GPU -- local
+    histograms reduced once, per merge one record-block gather + one tie-line gather, tie-break by the first rank holding a
+    tied pair -- must reproduce the single-shard merges exactly; the tiny-alphabet corpus makes almost every step a tie"""
+    from subword_tokenizers_amd.distributed import train_sharded_loopback
 
     sents = corpora["pan"][:400]
-    ref = swt.NaiveBPE()
-    ref.train(list(sents), 400)
-    group = LocalGroup(2)
-    shards = [ShardedBpeTrainer.from_corpus(sents, rank=r, world=2, group=group) for r in range(2)]
-    merges = LocalGroup.run_lockstep(shards, max_vocab=400)
-    assert merges == ref.merges_list
+    ref = oracle.OracleBPETrainer(sents)
+    ref.run(400)
+    want = [tuple(p) for p in ref.merges_list]
+    for world in (2, 3, 5):
+        merges, stats = train_sharded_loopback(sents, 400, world)
+        assert merges == want, world
+        assert all(not (st["flags"] & 1) for st in stats)  # the inverted index stayed in use on every shard
+    ties = ["ab ba ab", "ba ab cc", "cc ab ba", "abab baba", "cab bac", "ccc aaa bbb", "abc cba", "bb aa"]
+    ref = oracle.OracleBPETrainer(ties)
+    ref.run(20)
+    for world in (2, 4):
+        merges, _ = train_sharded_loopback(ties, 20, world)
+        assert merges == [tuple(p) for p in ref.merges_list], world
+    # more shards than sentences: empty shards take part in every collective
+    merges, _ = train_sharded_loopback(ties[:2], 12, 4)
+    ref = oracle.OracleBPETrainer(ties[:2])
+    ref.run(12)
+    assert merges == [tuple(p) for p in ref.merges_list]
+
+
+def test_sharded_training_block_overflow_recovers(swt, oracle, dev, corpora, monkeypatch):
+    """a merge whose deltas do not fit the record block halts the batch on every shard; the runner grows the blocks and repeats
+    that exchange -- t5k's first merges touch hundreds of pairs; the block starts at 64 records here (4,096 by default)"""
+    from subword_tokenizers_amd import _native as N
+
+    monkeypatch.setenv("SWT_DIST_BLOCK_RECORDS", "64")
+    from subword_tokenizers_amd.distributed import HipShardEngine, ShardedBpeTrainer
+
+    sents = corpora["t5k"][:3000]
+    ref = oracle.OracleBPETrainer(sents)
+    target = ref.vocab_size + 300
+    ref.run(target)
+    comm = N.Dist.loopback(2)
+    trainers = []
+    for r in range(2):
+        text, off = N.pack_and_lower(ShardedBpeTrainer.shard(sents, r, 2))
+        trainers.append(N.BpeTrainer.from_text(text, off))
+    tr = ShardedBpeTrainer(HipShardEngine(trainers, comm), 0, 2)
+    merges = tr.train(target)
+    assert [tuple(m) for m in merges] == [tuple(p) for p in ref.merges_list]
+    assert trainers[0].stats()["steps"] > 300  # halted steps were spent: the overflow path ran
+    tr.engine.close()
+    comm.close()

@@ -17,7 +17,7 @@ for n_sent in [int(a) for a in sys.argv[1:]] or [10000, 85000, 340000, 850000]:
     d_out = torch.empty(nb + 64, dtype=torch.int32, device="cuda"); d_oo = torch.empty(ns + 1, dtype=torch.int64, device="cuda")
     d_n = torch.zeros(1, dtype=torch.int64, device="cuda")
     for flags, name in ((0, "dedup"), (N.BPE_NO_DEDUP, "direct")):
-        N.debug_knob(1, 2 if name == "dedup" else 0)  # the dedup pipeline whatever the size, against the direct path
+        bpe._table.set_option(N.OPT_DEDUP, N.DEDUP_ALWAYS if name == "dedup" else N.DEDUP_AUTO)  # the dedup pipeline whatever the size, against the direct path
         for _ in range(3):
             bpe._table.encode_dev(d_text.data_ptr(), nb, d_off.data_ptr(), ns, d_out.data_ptr(), d_oo.data_ptr(), d_n.data_ptr(), flags, 0)
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -26,5 +26,5 @@ for n_sent in [int(a) for a in sys.argv[1:]] or [10000, 85000, 340000, 850000]:
             bpe._table.encode_dev(d_text.data_ptr(), nb, d_off.data_ptr(), ns, d_out.data_ptr(), d_oo.data_ptr(), d_n.data_ptr(), flags, 0)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
         print("%8d sentences %7.2f MB  %-6s %9.1f us/call %9.1f MB/s  tokens %d" % (ns, nb / 1e6, name, dt * 1e6, nb / dt / 1e6, int(d_n.item())), flush=True)
-    N.debug_knob(1, 0)
+    bpe._table.set_option(N.OPT_DEDUP, N.DEDUP_AUTO)
     del d_text, d_off, d_out, d_oo

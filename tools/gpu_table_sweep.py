@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-call time of the FastWP dedup path (V30k, 1 M sentences) against the size of the word table (knob 4; diagnostics)."""
+"""Per-call time of the FastWP dedup path (V30k, 1 M sentences) against the size of the word table (SWT_OPT_DEDUP_TABLE_BITS; diagnostics)."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,13 +18,12 @@ def call():
     wp._trie.encode_dev(d_text.data_ptr(), nb, d_off.data_ptr(), n_sent, d_out.data_ptr(), d_oo.data_ptr(), d_st.data_ptr(), d_n.data_ptr(), 0)
 ref = None
 for bits in [int(a) for a in sys.argv[1:]] or [0, 22, 21, 20, 19, 18, 17]:
-    N.debug_knob(4, bits)
+    wp._trie.set_option(N.OPT_DEDUP_TABLE_BITS, bits)
     for _ in range(3): call()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): call()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
     ids = d_out[: int(d_n.item())].cpu().numpy().copy()
     if ref is None: ref = ids
-    N.debug_knob(2, 4); call(); torch.cuda.synchronize(); N.debug_knob(2, 0)
     print("table bits %2d  %8.1f us/call  %8.1f MB/s  same=%s" % (bits, dt * 1e6, nb / dt / 1e6, np.array_equal(ref, ids)), flush=True)
-N.debug_knob(4, 0)
+wp._trie.set_option(N.OPT_DEDUP_TABLE_BITS, 0)

@@ -14,12 +14,12 @@ for n_sent in [int(a) for a in sys.argv[1:]] or [5000, 10000, 20000, 40000, 8000
     d_text = torch.from_numpy(text.copy()).cuda(); d_off = torch.from_numpy(off.view(np.int64).copy()).cuda()
     d_out = torch.empty(nb + 64, dtype=torch.int32, device="cuda"); d_oo = torch.empty(n_sent + 1, dtype=torch.int64, device="cuda")
     d_st = torch.empty(n_sent + 8, dtype=torch.uint8, device="cuda"); d_n = torch.zeros(1, dtype=torch.int64, device="cuda")
-    for knob, name in ((2, "dedup"), (1, "direct")):
-        N.debug_knob(1, knob)
+    for knob, name in ((N.DEDUP_ALWAYS, "dedup"), (N.DEDUP_NEVER, "direct")):
+        wp._trie.set_option(N.OPT_DEDUP, knob)
         call = lambda: wp._trie.encode_dev(d_text.data_ptr(), nb, d_off.data_ptr(), n_sent, d_out.data_ptr(), d_oo.data_ptr(), d_st.data_ptr(), d_n.data_ptr(), 0)
         for _ in range(3): call()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(20): call()
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
         print("%7d sentences %6.2f MB  %-6s %8.1f us/call %9.1f MB/s" % (n_sent, nb / 1e6, name, dt * 1e6, nb / dt / 1e6), flush=True)
-    N.debug_knob(1, 0)
+    wp._trie.set_option(N.OPT_DEDUP, N.DEDUP_AUTO)
