@@ -164,6 +164,17 @@ int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, c
                       uint64_t *d_n_tokens, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Token-id histogram on the device: the Counter over token strings of the reference's
+ * zipf_distribution (source/benchmarks.py:240-253), over ids -- a '##' token and the same token without the prefix are
+ * different strings and different ids.  counts has 2 * id_cap entries: counts[id & 0x7FFFFFFF] for ids without SWT_BPE_CONT,
+ * counts[id_cap + (id & 0x7FFFFFFF)] for ids with it; ids whose low 31 bits reach id_cap are tallied in *out_of_range.
+ * FastWP ids carry no flag: only the first half is used.  The `_dev` form takes device pointers and zeroes the outputs itself.
+ */
+int swt_token_histogram(const uint32_t *ids, uint64_t n, uint32_t id_cap, uint64_t *counts, uint64_t *out_of_range);
+int swt_token_histogram_dev(const uint32_t *d_ids, uint64_t n, uint32_t id_cap, uint64_t *d_counts, uint64_t *d_out_of_range,
+                            void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * BPE training: replaces the merge loop of NaiveBPE.train (source/bpe.py:88-111; FastBPE.train
  * inherits it, source/bpe.py:198-200) and its word dedup (source/bpe.py:73-81).
  *

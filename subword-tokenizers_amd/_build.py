@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "_lib")
 LIB_PATH = os.path.join(LIB_DIR, "libswt_hip.so")
-SOURCES = ["swt_core.hip", "swt_tile.hip", "swt_dedup.hip", "swt_bpe_encode.hip", "swt_wp.hip", "swt_words.hip", "swt_bpe_train.hip", "swt_dist.hip", "swt_lower.hip"]
+SOURCES = ["swt_core.hip", "swt_tile.hip", "swt_dedup.hip", "swt_bpe_encode.hip", "swt_wp.hip", "swt_words.hip", "swt_bpe_train.hip", "swt_dist.hip", "swt_lower.hip", "swt_metrics.hip"]
 HEADERS = ["swt_common.h", "swt_tile.h", "swt_dedup.h", "swt_words.h", "swt_train.h", "unicode_classes.inc", "unicode_lower.inc", os.path.join("..", "..", "include", "swt.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

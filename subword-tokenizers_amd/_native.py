@@ -58,6 +58,8 @@ SIGNATURES = {
     "swt_utf8_lower": (C.c_int, [u8p, u64p, C.c_uint64, u8p]),
     "swt_utf8_prepare": (C.c_int, [u8p, C.c_uint64, u64p, C.c_uint64, u64p, u8p]),
     "swt_utf8_lower_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "swt_token_histogram": (C.c_int, [u32p, C.c_uint64, C.c_uint32, u64p, u64p]),
+    "swt_token_histogram_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "swt_bpe_train_create_text": (C.c_int, [u8p, u64p, C.c_uint64, vpp]),
     "swt_wp_train_create_text": (C.c_int, [u8p, u64p, C.c_uint64, vpp]),
     "swt_bpe_train_create_words": (C.c_int, [u32p, u64p, u32p, C.c_uint64, vpp]),
@@ -224,6 +226,17 @@ def pack_utf32(strings):
         np.cumsum(np.fromiter(map(len, strings), dtype=np.uint64, count=len(strings)), out=off[1:])
     blob = np.frombuffer("".join(strings).encode("utf-32-le", "surrogatepass"), dtype=np.uint32)
     return blob, off
+
+
+def token_histogram(ids, id_cap):
+    """uint32 token ids -> uint64 counts[2 * id_cap] (second half: ids carrying BPE_CONT), counted on the device"""
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    counts = np.zeros(2 * int(id_cap), dtype=np.uint64)
+    oor = C.c_uint64()
+    check(lib().swt_token_histogram(ptr(ids, u32p) if ids.size else None, int(ids.size), int(id_cap), ptr(counts, u64p), C.byref(oor)))
+    if oor.value:
+        raise ValueError("%d token ids are outside [0, %d)" % (oor.value, id_cap))
+    return counts
 
 
 class BpeTable:
