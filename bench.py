@@ -232,7 +232,7 @@ def train_bench(args, torch, dist, rank, world, N, sents, max_vocab, name, repea
         N.profile_read()
         barrier_sync(torch, dist)
         t0 = time.perf_counter()
-        if world == 1:
+        if world == 1 and not os.environ.get("SWT_BENCH_FORCE_SHARDED"):
             tok = tokenizers.FastBPE()
             tok.train(sents, max_vocab)
             merges = list(tok.merges_list)
@@ -242,7 +242,7 @@ def train_bench(args, torch, dist, rank, world, N, sents, max_vocab, name, repea
         else:
             from subword_tokenizers_amd.distributed import train_sharded
 
-            merges, info = train_sharded(sents, max_vocab, rank, world, dist)
+            merges, info = train_sharded(sents, max_vocab, rank, world, dist)  # C++ runner over RCCL (csrc/swt_dist.hip)
         barrier_sync(torch, dist)
         dt = max_over_ranks(torch, dist, time.perf_counter() - t0)
         ms, _n = N.profile_read()

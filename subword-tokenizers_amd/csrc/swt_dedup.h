@@ -23,6 +23,7 @@ namespace swt {
 constexpr uint64_t kDedupMinBytes = 7u << 18;     // FastBPE: 1.75 MiB
 constexpr uint64_t kDedupMinBytesWp = 11u << 18;  // FastWP: 2.75 MiB
 constexpr uint64_t kDedupMaxBytes = 1ull << 30;  // 32-bit fields of the records
+constexpr uint32_t kDedupRetry = 16;             // direct calls between two looks at a text that repeats few of its words
 constexpr uint32_t kRecFailed = 0xFFFFFFFFu;     // count field of rec[]: the word cannot be encoded (FastWP non-termination)
 
 enum DedupMode {
@@ -35,6 +36,12 @@ struct DedupEngine {
   uint32_t bits = 0, epoch = 0;
   int opt_mode = 0;            // SWT_OPT_DEDUP of the owning handle: 0 by batch size, 1 never, 2 always
   uint32_t opt_table_bits = 0; // SWT_OPT_DEDUP_TABLE_BITS: log2 of the word table's slots (0: sized from the batch)
+  // What the last deduplicated call found, copied to pinned memory behind its kernels (never waited for): the owner skips
+  // the dedup while the text repeats too few of its words for it to pay, and looks again every kDedupRetry calls.
+  PinnedBuf seen;              // [0] unique words:32 | their bytes:32 of the last dedup call, [1] that call's text bytes
+  uint32_t skipped = 0;        // calls since the dedup last ran
+  bool pays(uint64_t n_bytes);
+  void note(uint64_t n_bytes, hipStream_t st);
   void release();
   unsigned long long *rec_ptr() const { return rec.as<unsigned long long>(); }    // per table slot: count:32 | unique index:32
   unsigned long long *drec_ptr() const { return drec.as<unsigned long long>(); }  // per unique word: count:32 | place:32

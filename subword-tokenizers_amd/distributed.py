@@ -109,6 +109,8 @@ def rccl_dist(dist, rank: int, world: int, device="cuda") -> "N.Dist":
     (ncclGetUniqueId), torch.distributed broadcasts it."""
     import torch
 
+    if dist is None or world == 1:
+        return N.Dist.rccl(0, 1, N.Dist.unique_id())
     uid = torch.zeros(128, dtype=torch.uint8, device=device)
     if rank == 0:
         uid.copy_(torch.from_numpy(N.Dist.unique_id()))

@@ -745,3 +745,24 @@ def test_sharded_training_block_overflow_recovers(swt, oracle, dev, corpora, mon
     assert trainers[0].stats()["steps"] > 300  # halted steps were spent: the overflow path ran
     tr.engine.close()
     comm.close()
+
+
+def test_sharded_training_over_rccl_world1(swt, oracle, dev, corpora):
+    """the RCCL side of csrc/swt_dist.hip on the one GPU there is: a communicator of ONE rank (ncclGetUniqueId,
+    ncclCommInitRank, the per-merge ncclAllGather pair on the training stream) must train exactly like the unsharded path"""
+    from subword_tokenizers_amd import _native as N
+    from subword_tokenizers_amd.distributed import ShardedBpeTrainer
+
+    sents = corpora["t5k"][:1200]
+    ref = oracle.OracleBPETrainer(sents)
+    target = ref.vocab_size + 250
+    ref.run(target)
+    comm = N.Dist.rccl(0, 1, N.Dist.unique_id())
+    tr = ShardedBpeTrainer.from_corpus(sents, 0, 1, comm)
+    try:
+        merges = tr.train(target)
+        assert [tuple(m) for m in merges] == [tuple(p) for p in ref.merges_list]
+        assert len(tr.vocab) == ref.vocab_size
+    finally:
+        tr.engine.close()
+        comm.close()
