@@ -140,6 +140,12 @@ def encode_corpus_bench(args, torch, dist, rank, N, bpe, sents, merges, name, cp
     barrier_sync(torch, dist)
     elapsed = max_over_ranks(torch, dist, time.perf_counter() - t0)
     kernel_ms, launches = N.profile_read()
+    total_bytes = sum_over_ranks(torch, dist, float(n_bytes))
+    res = {"corpus": name, "mb_s": total_bytes * args.steps / 1e6 / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+           "n_bytes": n_bytes, "n_sent": n_sent, "n_tok": n_tok, "roofline": None, "cpu": None, "detail": None}
+    if args.lean:  # profiling runs (tools/gpu_profile_r02.sh): only the launches of the timed path reach the counters
+        N.profile_enable(False)
+        return res
     # ---- outside the timed region ----
     extra = min(max(args.steps, 1), 20)
     N.profile_enable(2)  # one event pair around ALL kernels of a call
@@ -158,9 +164,6 @@ def encode_corpus_bench(args, torch, dist, rank, N, bpe, sents, merges, name, cp
     N.profile_enable(False)
     step()
     torch.cuda.synchronize()
-    total_bytes = sum_over_ranks(torch, dist, float(n_bytes))
-    res = {"corpus": name, "mb_s": total_bytes * args.steps / 1e6 / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
-           "n_bytes": n_bytes, "n_sent": n_sent, "n_tok": n_tok, "roofline": None, "cpu": None, "detail": None}
     if rank != 0:
         return res
     from oracle import oracle as O
@@ -197,7 +200,7 @@ def encode_corpus_bench(args, torch, dist, rank, N, bpe, sents, merges, name, cp
     res["roofline"] = check_frac({
         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
         "traffic": traffic_from_profile("bpe_encode_" + name) or traffic_from_profile("bpe_encode"),
-        "kernel": "whole call (word-dedup pipeline; the longest kernel beside it)", "kernel_us": round(per_call_s * 1e6, 2),
+        "kernel": "whole call: the word-dedup pipeline, or the direct path while the text repeats too few of its words (the longest kernel beside it)", "kernel_us": round(per_call_s * 1e6, 2),
         "algorithmic_bytes_per_launch": int(algo), "launches_timed": int(calls),
         "dominant_kernel": {"name": "bpe_encode_kernel", "us": round(kernel_ms * 1e3 / max(launches, 1), 2), "launches_timed": int(launches)}})
     # what the dedup feeds on, exactly: the device's own split + Counter (bpe.py:73-77) of this batch
@@ -319,6 +322,7 @@ def bench_headline(args, torch, dist, rank, world, local):
 
 
 def bench_bpe_encode(args, torch, dist, rank, world, local):
+    """configs[1] alone, on ONE of the two stand-ins (--corpus lex | open): the encode half of the default line"""
     from subword_tokenizers_amd import _native as N
     from subword_tokenizers_amd import synth, tokenizers
 
@@ -327,83 +331,19 @@ def bench_bpe_encode(args, torch, dist, rank, world, local):
     bpe = tokenizers.FastBPE()
     bpe.merges_list = list(merges)
     bpe._build_table()
-    sents = synth.sentences(85000, 85000 + rank) if rank else synth.s85k()
-    text, off = N.pack_utf8([s.lower() for s in sents])
-    n_bytes, n_sent = int(text.size), len(sents)
-    d_text, d_off = to_dev(torch, text), to_dev(torch, off.view(np.int64))
-    d_out = torch.empty(n_bytes + 64, dtype=torch.int32, device="cuda")
-    d_out_off = torch.empty(n_sent + 1, dtype=torch.int64, device="cuda")
-    d_ntok = torch.zeros(1, dtype=torch.int64, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        bpe._table.encode_dev(d_text.data_ptr(), n_bytes, d_off.data_ptr(), n_sent, d_out.data_ptr(), d_out_off.data_ptr(),
-                              d_ntok.data_ptr(), 0, stream)
-
-    for _ in range(args.warmup):
-        step()
-    barrier_sync(torch, dist)
-    n_tok = int(d_ntok.item())
-    N.profile_enable(True)
-    N.profile_read()
-    barrier_sync(torch, dist)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier_sync(torch, dist)
-    elapsed = max_over_ranks(torch, dist, time.perf_counter() - t0)
-    kernel_ms, launches = N.profile_read()
-    # outside the timed region: the same step with one event pair around ALL kernels of a call (profile level 2)
-    N.profile_enable(2)
-    for _ in range(min(max(args.steps, 1), 20)):
-        step()
-    torch.cuda.synchronize()
-    call_ms, calls = N.profile_read()
-    N.profile_enable(False)
-    total_bytes = sum_over_ranks(torch, dist, float(n_bytes))
-
-    # parity check of what was just measured (rank 0, the whole batch) -- the oracle is the checker only
-    roof = cpu = None
-    if rank == 0:
-        from oracle import oracle as O
-
-        orc = O.OracleBPE(merges)
-        ids = d_out[:n_tok].cpu().numpy().view(np.uint32)
-        offs = d_out_off.cpu().numpy().view(np.uint64)
-        oids, ooff = orc.tokenize_batch_ids(sents)
-        # time the C call alone (lower() + packing excluded, as on the GPU side)
-        blob, boff = O.pack([s.lower() for s in sents])
-        out = np.zeros(max(blob.size, 1), dtype=np.uint32)
-        oo = np.zeros(n_sent + 1, dtype=np.uint64)
-        t1 = time.perf_counter()
-        O.lib().orc_bpe_tokenize_batch(orc._h, O._p32(blob), O._p64(boff), n_sent, O._p32(out), O._p64(oo))
-        cpu_s = time.perf_counter() - t1
-        if not (np.array_equal(ids, oids) and np.array_equal(offs, ooff)):
-            raise SystemExit("PARITY FAILURE: device ids differ from the oracle on the benchmark batch")
-        # Since the word-level dedup the batch passes through eight short kernels and none of them touches all of the
-        # algorithmic bytes, so the roofline line is that of the whole call: algorithmic bytes of the batch over the
-        # time from the first kernel's start to the last kernel's end (HIP events on the launch stream).  The longest
-        # single kernel (bpe_encode_kernel over the unique words) is reported beside it.
-        algo = n_bytes + 4.0 * n_tok + 8.0 * (n_sent + 1)
-        per_call_s = call_ms / 1e3 / max(calls, 1)
-        achieved = algo / per_call_s / 1e9
-        roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_from_profile("bpe_encode"),
-                "kernel": "dedup pipeline: plan, wordref, scan, ureg, bpe_encode (unique words), refcount, scan, refwrite",
-                "kernel_us": round(per_call_s * 1e6, 2),
-                "algorithmic_bytes_per_launch": int(algo), "launches_timed": int(calls),
-                "dominant_kernel": {"name": "bpe_encode_kernel", "us": round(kernel_ms * 1e3 / max(launches, 1), 2),
-                                    "launches_timed": int(launches)}}
-        cpu = {"value": round(n_bytes / 1e6 / cpu_s, 3), "unit": "MB/s", "cores": 1, "kind": "port",
-               "sample": "the whole S85k batch (%.1f MB), one pass of oracle/swt_oracle.c orc_bpe_tokenize_batch" % (n_bytes / 1e6)}
+    if args.corpus == "lex":
+        name, sents = "S85k-lex", (synth.sentences(85000, 85000 + rank) if rank else synth.s85k())
+    else:
+        name, sents = "S85k-open", (synth.sentences_open(85000, 85000 + rank) if rank else synth.s85k_open())
+    r = encode_corpus_bench(args, torch, dist, rank, N, bpe, sents, merges, name, cpu_leg=True)
     return {
-        "metric": "FastBPE encode throughput (input MB/s, tokens bit-exact)", "value": round(total_bytes * args.steps / 1e6 / elapsed, 1),
-        "unit": "MB/s", "ms_per_step": round(elapsed / args.steps * 1e3, 4), "dtype": "u32",
-        "config": {"workload": "configs[1]: FastBPE encode, S85k stand-in for train-85k (85,000 sentences, %.2f MB/GPU), "
-                               "first 8,000 pretrained merges" % (n_bytes / 1e6),
-                   "sentences_per_gpu": n_sent, "bytes_per_gpu": n_bytes, "tokens_per_gpu": n_tok,
+        "metric": "FastBPE encode throughput (input MB/s, tokens bit-exact)", "value": round(r["mb_s"], 1), "unit": "MB/s",
+        "ms_per_step": round(r["ms_per_step"], 4), "dtype": "u32",
+        "config": {"workload": "configs[1]: FastBPE encode, %s stand-in for train-85k (85,000 sentences, %.2f MB/GPU), first 8,000 pretrained merges"
+                               % (name, r["n_bytes"] / 1e6),
+                   "sentences_per_gpu": r["n_sent"], "bytes_per_gpu": r["n_bytes"], "tokens_per_gpu": r["n_tok"],
                    "parallelism": "corpus-sharded x%d, no collective" % world},
-        "roofline": roof, "cpu_baseline": cpu,
+        "roofline": r["roofline"], "cpu_baseline": r["cpu"], "encode_detail": {name: r["detail"]},
     }
 
 
@@ -746,7 +686,8 @@ def main():
     ap.add_argument("--types", type=int, default=None, help="bpe_train_1g: word types (default 2,000,000)")
     ap.add_argument("--merges", type=int, default=None, help="bpe_train_1g: merges (default 32,000)")
     ap.add_argument("--parity-merges", type=int, default=None, help="bpe_train_1g: merges compared with the oracle (default 200)")
-    ap.add_argument("--corpus", default="open", choices=["open", "lex"], help="bpe_train: S85k-open (default) or S85k-lex")
+    ap.add_argument("--lean", action="store_true", help="bpe_encode: timed steps only (no extra legs, no parity check): for counter passes")
+    ap.add_argument("--corpus", default="open", choices=["open", "lex"], help="bpe_train / bpe_encode: S85k-open (default) or S85k-lex")
     args = ap.parse_args()
     defaults = {"headline": (100, 10), "bpe_encode": (200, 20), "wp_encode": (20, 3), "bpe_train": (2, 1), "wp_train": (2, 1), "bpe_train_1g": (1, 0), "mixed_encode": (10, 2)}[args.workload]
     if args.steps is None:

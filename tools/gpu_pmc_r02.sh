@@ -1,0 +1,33 @@
+# PMC passes of the encode paths with --lean (only the timed launches reach the counters).  FETCH_SIZE and WRITE_SIZE in
+# separate runs (TCC slots), never combined with a trace domain.
+export TMPDIR=/tmp
+cd /tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_r02
+mkdir -p $O
+run_pmc() {  # name, counter, bench args...
+  local name=$1 c=$2; shift; shift
+  timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${name}_$c -- python3 $R/bench.py "$@" > $O/pmc_${name}_$c.json 2> $O/pmc_${name}_$c.err; echo "pmc $name $c exit=$?"
+  f=$(find $O/pmc_${name}_$c -name "*counter_collection.csv" | head -1)
+  python3 - "$f" $c $O $name <<'PY'
+import csv, sys, collections
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "swt::" in r.get("Kernel_Name", "") and r.get("Counter_Name") == sys.argv[2]]
+per = collections.defaultdict(list)
+for r in rows:
+    per[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+out = "%s/%s_%s_per_kernel.csv" % (sys.argv[3], sys.argv[4], sys.argv[2])
+with open(out, "w") as o:
+    o.write("kernel,launches,mean_%s_KiB_per_launch,total_KiB\n" % sys.argv[2])
+    tot = 0.0
+    for k, v in sorted(per.items()):
+        o.write("%s,%d,%.1f,%.1f\n" % (k, len(v), sum(v) / len(v), sum(v)))
+        tot += sum(v)
+    o.write("ALL swt kernels,,,%.1f\n" % tot)
+print(open(out).read())
+PY
+  rm -rf $O/pmc_${name}_$c
+}
+for c in FETCH_SIZE WRITE_SIZE; do
+  run_pmc bpe_encode_lex $c --workload bpe_encode --corpus lex --steps 8 --warmup 2 --lean
+  run_pmc bpe_encode_open $c --workload bpe_encode --corpus open --steps 8 --warmup 2 --lean
+done
