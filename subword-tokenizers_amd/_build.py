@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(LIB_DIR, "libswt_hip.so")
 SOURCES = ["swt_core.hip", "swt_tile.hip", "swt_dedup.hip", "swt_bpe_encode.hip", "swt_wp.hip", "swt_words.hip", "swt_bpe_train.hip", "swt_dist.hip", "swt_lower.hip", "swt_metrics.hip"]
 HEADERS = ["swt_common.h", "swt_tile.h", "swt_dedup.h", "swt_words.h", "swt_train.h", "unicode_classes.inc", "unicode_lower.inc", os.path.join("..", "..", "include", "swt.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# diagnostic builds (tools/ only): SWT_EXTRA_FLAGS="-DSWT_STAMPS" or "-DSWT_ABLATION"; the flags are part of the build stamp
+FLAGS += os.environ.get("SWT_EXTRA_FLAGS", "").split()
 
 
 def _hipcc():

@@ -525,7 +525,38 @@ __global__ void wp_live_symbols_kernel(const long long *__restrict__ sfreq, uint
 // lane), because each one costs a dependent trip to the pair table (~0.2 us: the table lives in the Infinity Cache) and
 // issued one by one they would be the whole cost of a merge.  After the walk the wave reserves its new index entries with
 // one atomic, and every lane flushes its parked deltas four at a time: four independent probes, then four atomics.
+// ---- in-kernel time stamps (diagnostic builds only: SWT_EXTRA_FLAGS=-DSWT_STAMPS, tools/gpu_train_stamps.py) ---------------
+// s_memrealtime is the chip-wide 100 MHz counter: per merge step the first start / last end over all workgroups of the two
+// launches (= what the step costs on the device, without the launch), and the time per phase on one lane's critical path.
+#ifdef SWT_STAMPS
+constexpr uint32_t kSpanSteps = 16384;
+__device__ unsigned long long g_span[4][kSpanSteps];  // tie first start, tie last end, apply first start, apply last end
+__device__ unsigned long long g_phase[3][16];  // [2]: apply launch, every flushing lane of steps 1..64 (the big merges)
+//        // [0] tie launch, workgroup 0; [1] apply launch, per step the first lane done flushing; [.][15] = samples
+__device__ unsigned int g_reported[kSpanSteps];
+struct StampSpan {
+  int k; uint32_t step;
+  __device__ StampSpan(int k_, uint32_t step_) : k(k_), step(step_ & (kSpanSteps - 1)) {
+    if (threadIdx.x == 0) atomicMin(&g_span[2 * k][step], __builtin_amdgcn_s_memrealtime());
+  }
+  __device__ ~StampSpan() {
+    if (threadIdx.x == 0) atomicMax(&g_span[2 * k + 1][step], __builtin_amdgcn_s_memrealtime());
+  }
+};
+__device__ __forceinline__ unsigned long long stamp_now() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // what was requested so far has arrived
+  return __builtin_amdgcn_s_memrealtime();
+}
+#define SWT_SPAN(k, step) StampSpan span_((k), (step))
+#define SWT_STAMP(arr, i) (arr)[(i)] = stamp_now()
+#else
+#define SWT_SPAN(k, step) do { } while (0)
+#define SWT_STAMP(arr, i) do { } while (0)
+#endif
+
 constexpr int kEmitCap = 12;
+constexpr int kStage = 32;      // stream slots of a word staged in LDS before its walk
+constexpr int kFlushBatch = 8;  // parked deltas whose table probes go out together
 constexpr unsigned long long kEmitNew = 1ull << 63;  // symbol ids stay below 2^31, so bit 63 of a pair key is free
 
 // the slot of a key that is very likely in the table already: one plain load; anything else goes the insert-or-find way
@@ -540,19 +571,22 @@ __device__ __forceinline__ void index_entry(const TrainCtx &C, uint64_t at, unsi
 
 // walk one claimed word: rewrite in place, park the deltas.  Returns merges done; n_parked / n_new_parked by reference.
 // Deltas beyond kEmitCap are applied on the spot (a new pair then takes its index entry with an atomic of its own).
+// `stage` holds the word's first kStage stream slots as they were before the walk (one LDS column per lane, loaded in one go:
+// the walk never reads a slot again after writing it, so the copy stays good); slots beyond come from the stream.
 __device__ __forceinline__ uint32_t walk_word(uint32_t *__restrict__ sym, uint64_t b0, uint64_t b1, uint32_t l, uint32_t r, uint32_t m,
-                                              long long f, const TrainCtx &C, uint32_t w, unsigned long long *park, int &n_park,
-                                              int &n_new) {
+                                              long long f, const TrainCtx &C, uint32_t w, const uint32_t *stage,
+                                              unsigned long long *park, int &n_park, int &n_new) {
   uint32_t n_merged = 0;
   uint32_t po = 0, pn = 0;  // previous old / new symbol
   bool po_cov = false, pn_new = false, have = false;
   uint64_t i = b0;
-  while (i < b1 && sym[i] == kHole) i++;
+#define SYM(i_) (((i_) - b0) < (uint64_t)kStage ? stage[((i_) - b0) * kTrainThreads] : sym[(i_)])
+  while (i < b1 && SYM(i) == kHole) i++;
 #define EMIT(a_, b_, new_)                                                           \
   do {                                                                               \
     const unsigned long long key_ = pair_key((a_), (b_));                            \
     if (n_park < kEmitCap) {                                                         \
-      park[n_park++] = key_ | ((new_) ? kEmitNew : 0ull);                            \
+      park[(n_park++) * kTrainThreads] = key_ | ((new_) ? kEmitNew : 0ull);          \
       n_new += (new_) ? 1 : 0;                                                       \
     } else {                                                                         \
       table_add(C, key_, (new_) ? f : -f);                                           \
@@ -560,20 +594,21 @@ __device__ __forceinline__ uint32_t walk_word(uint32_t *__restrict__ sym, uint64
     }                                                                                \
   } while (0)
   while (i < b1) {
-    const uint32_t x = sym[i];
+    const uint32_t x = SYM(i);
     uint64_t j = i + 1;
-    while (j < b1 && sym[j] == kHole) j++;
-    const bool occ = j < b1 && x == l && sym[j] == r;
+    uint32_t y = kHole;
+    while (j < b1 && (y = SYM(j)) == kHole) j++;
+    const bool occ = j < b1 && x == l && y == r;
     if (occ) {
       if (have) EMIT(po, x, false);    // (prev, l): l is consumed
-      EMIT(x, r, false);               // (l, r) itself
       if (have) EMIT(pn, m, true);     // (prev_new, merged)
+      // (l, r) itself: every lane of the launch has this one, the wave sends it once (apply_body)
       po = r; po_cov = true; pn = m; pn_new = true; have = true;
       sym[i] = m;
       sym[j] = kHole;
       n_merged++;
       i = j + 1;
-      while (i < b1 && sym[i] == kHole) i++;
+      while (i < b1 && SYM(i) == kHole) i++;
     } else {
       if (have) {
         if (po_cov) EMIT(po, x, false);  // (r, x): r was consumed
@@ -584,15 +619,22 @@ __device__ __forceinline__ uint32_t walk_word(uint32_t *__restrict__ sym, uint64
     }
   }
 #undef EMIT
+#undef SYM
   return n_merged;
 }
 
 __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff, const uint32_t *__restrict__ freq,
                                            uint64_t n_words, const TrainCtx &C, uint32_t l, uint32_t r, uint32_t m) {
-  __shared__ unsigned long long park_s[kTrainThreads * kEmitCap];
-  unsigned long long *park = park_s + (size_t)threadIdx.x * kEmitCap;
+  __shared__ unsigned long long park_s[kTrainThreads * kEmitCap];  // [delta][lane]: a wave's lanes sit side by side
+  __shared__ uint32_t stage_s[kTrainThreads * kStage];             // [slot][lane]
+  unsigned long long *park = park_s + threadIdx.x;
+  uint32_t *stage = stage_s + threadIdx.x;
   TrainState *st = C.st;
   const int lane = threadIdx.x & 63;
+#ifdef SWT_STAMPS
+  unsigned long long ts[8];
+#endif
+  SWT_STAMP(ts, 0);
   // where the words of (l, r) are listed
   const uint32_t *list = nullptr;  // word ids
   const uint32_t *tags = nullptr;  // log segment: entries of other pairs are skipped by tag
@@ -616,7 +658,7 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
     }
   }
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  unsigned long long removed = 0;
+  unsigned long long removed = 0, self_delta = 0, inserted = 0;
   uint32_t min_w = 0xFFFFFFFFu;
   for (uint64_t e0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; e0 < n_ent; e0 += stride) {
     const uint64_t e = e0 + lane;
@@ -630,14 +672,23 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
       }
     }
     int n_park = 0, n_new = 0;
+    SWT_STAMP(ts, 1);
     if (w != 0xFFFFFFFFu) {
       // the word's bounds and frequency travel beside the claim
       const uint64_t b0 = woff[w], b1 = woff[w + 1];
       const long long f = freq[w];
-      if (atomicMax(&C.wstamp[w], C.step) < C.step) {
-        const uint32_t nm = walk_word(sym, b0, b1, l, r, m, f, C, w, park, n_park, n_new);
+      const uint32_t claimed = atomicMax(&C.wstamp[w], C.step);
+      uint32_t pre[kStage];  // the word's first slots: all loads in flight at once instead of one per step of the walk
+#pragma unroll
+      for (int u = 0; u < kStage; u++) pre[u] = b0 + u < b1 ? sym[b0 + u] : kHole;
+#pragma unroll
+      for (int u = 0; u < kStage; u++) stage[u * kTrainThreads] = pre[u];
+      SWT_STAMP(ts, 2);
+      if (claimed < C.step) {
+        const uint32_t nm = walk_word(sym, b0, b1, l, r, m, f, C, w, stage, park, n_park, n_new);
         if (nm) {
           removed += nm;
+          self_delta += (unsigned long long)nm * (unsigned long long)f;
           min_w = w < min_w ? w : min_w;
           if (C.sfreq && l == r) {  // twin pair: nm merges happened in this word (see wp_move_freq)
             const unsigned long long d = (unsigned long long)nm * (unsigned long long)f;
@@ -649,6 +700,7 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
         w = 0xFFFFFFFFu;  // another lane has this word
       }
     }
+    SWT_STAMP(ts, 3);
     // room in the index log for the wave's new entries: one atomic per wave (lanes without a word take part with zero)
     uint32_t x = (uint32_t)n_new;
     for (int d = 1; d < 64; d <<= 1) {
@@ -659,45 +711,100 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
     unsigned long long base = 0;
     if (lane == 0 && total) base = atomicAdd(&st->idx_cursor, (unsigned long long)total);
     base = __shfl(base, 0);
+    SWT_STAMP(ts, 4);
     if (w != 0xFFFFFFFFu && n_park) {
       const long long f = freq[w];  // L1: loaded a moment ago
       uint64_t at = base + x - (uint32_t)n_new;
-      for (int j0 = 0; j0 < n_park; j0 += 4) {
-        unsigned long long key[4], seen[4];
-        uint32_t h[4];
+      for (int j0 = 0; j0 < n_park; j0 += kFlushBatch) {
+        // three rounds, each with all its memory operations in flight together: probe, add, follow up
+        unsigned long long key[kFlushBatch], seen[kFlushBatch];
+        long long was[kFlushBatch];
+        uint32_t h[kFlushBatch], ci[kFlushBatch];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          key[u] = j0 + u < n_park ? park[j0 + u] : 0ull;
+        for (int u = 0; u < kFlushBatch; u++) {
+          const bool on = j0 + u < n_park;
+          key[u] = on ? park[(j0 + u) * kTrainThreads] : 0ull;
           h[u] = slot_hint(C.T, key[u] & ~kEmitNew);
-          seen[u] = j0 + u < n_park ? C.T.keys[h[u]] : 0ull;
+          seen[u] = on ? C.T.keys[h[u]] : 0ull;
+          ci[u] = on && C.cidx ? C.cidx[h[u]] : 0xFFFFFFFFu;
         }
+        // a pair the merge has just made is usually not in the table: its home slot is taken here, all of them at once
+        unsigned long long got[kFlushBatch];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < kFlushBatch; u++)
+          got[u] = (j0 + u < n_park && seen[u] == kEmptyKey) ? atomicCAS(&C.T.keys[h[u]], kEmptyKey, key[u] & ~kEmitNew) : 1ull;
+#pragma unroll
+        for (int u = 0; u < kFlushBatch; u++) {
           if (j0 + u >= n_park) continue;
           const unsigned long long k = key[u] & ~kEmitNew;
-          const bool is_new = (key[u] & kEmitNew) != 0;
-          const uint32_t slot = seen[u] == k ? h[u] : table_slot(C.T, k, st);
-          if (!C.pend) {
-            count_add(C, slot, is_new ? f : -f);
-          } else {
-            (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&C.pend[slot]), (unsigned long long)(is_new ? f : -f),
-                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (atomicMax(&C.tstamp[slot], C.step) < C.step) {
-              const unsigned long long q = atomicAdd(&st->n_touched, 1ull);
-              if (q < C.touched_cap) C.touched[q] = slot;
-            }
+          if (seen[u] == kEmptyKey) {
+            if (got[u] == kEmptyKey) { inserted++; seen[u] = k; }
+            else seen[u] = got[u];  // another lane was first (with this pair, or with another one)
           }
-          if (is_new) index_entry(C, at++, k, m, w);
+          if (seen[u] != k) {  // not at its home slot
+            h[u] = table_slot(C.T, k, st);
+            ci[u] = C.cidx ? C.cidx[h[u]] : 0xFFFFFFFFu;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kFlushBatch; u++) {
+          was[u] = 0;
+          if (j0 + u >= n_park) continue;
+          const bool is_new = (key[u] & kEmitNew) != 0;
+          const unsigned long long delta = (unsigned long long)(is_new ? f : -f);
+          const uint32_t slot = h[u];
+          if (!C.pend) {  // count_add, with the compact copy's index already here
+            if (ci[u] != 0xFFFFFFFFu)
+              (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&C.ccnt[ci[u]]), delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (is_new && C.theta)
+              was[u] = (long long)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&C.T.cnt[slot]), delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+              (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&C.T.cnt[slot]), delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&C.pend[slot]), delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            was[u] = (long long)atomicMax(&C.tstamp[slot], C.step);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kFlushBatch; u++) {
+          if (j0 + u >= n_park) continue;
+          const bool is_new = (key[u] & kEmitNew) != 0;
+          if (!C.pend) {
+            if (is_new && C.theta && was[u] < (long long)C.theta && was[u] + f >= (long long)C.theta) cand_push(C, h[u]);
+          } else if ((uint32_t)was[u] < C.step) {
+            const unsigned long long q = atomicAdd(&st->n_touched, 1ull);
+            if (q < C.touched_cap) C.touched[q] = h[u];
+          }
+          if (is_new) index_entry(C, at++, key[u] & ~kEmitNew, m, w);
         }
       }
+#ifdef SWT_STAMPS
+      SWT_STAMP(ts, 5);
+      if (e0 < stride && C.step > 512 && atomicAdd(&g_reported[C.step & (kSpanSteps - 1)], 1u) == 0) {  // ts[0] is the kernel's start
+        for (int q = 0; q < 5; q++) atomicAdd(&g_phase[1][q], ts[q + 1] - ts[q]);
+        atomicAdd(&g_phase[1][8], (unsigned long long)n_park);
+        atomicAdd(&g_phase[1][9], (unsigned long long)n_new);
+        atomicAdd(&g_phase[1][15], 1ull);
+      }
+      if (C.step <= 64) {
+        for (int q = 0; q < 5; q++) atomicAdd(&g_phase[2][q], ts[q + 1] - ts[q]);
+        atomicAdd(&g_phase[2][8], (unsigned long long)n_park);
+        atomicAdd(&g_phase[2][9], (unsigned long long)n_new);
+        atomicAdd(&g_phase[2][15], 1ull);
+      }
+#endif
     }
   }
   for (int d = 32; d >= 1; d >>= 1) {
     removed += __shfl_xor(removed, d);
+    self_delta += __shfl_xor(self_delta, d);
+    inserted += __shfl_xor(inserted, d);
     const uint32_t o = __shfl_xor(min_w, d);
     min_w = o < min_w ? o : min_w;
   }
+  if (lane == 0 && inserted) atomicAdd(&st->n_used, inserted);
   if (lane == 0 && removed) {
+    table_add(C, pair_key(l, r), -(long long)self_delta);  // the merged pair's own count: once per wave, not once per word
     atomicAdd(&st->n_syms, (unsigned long long)0 - removed);
     atomicMin(&st->cursor_w, min_w);  // new pairs were born in these words: the tie scan may not start after them
   }
@@ -723,11 +830,21 @@ struct BlockArg {
   unsigned long long mx, tied, key;
 };
 
+#ifndef SWT_TIE_WORDS
+#define SWT_TIE_WORDS 8
+#endif
+constexpr int kTieWords = SWT_TIE_WORDS;      // words a wave scans per trip of the tie scan: 16 lanes per word, 4 words at a time
+constexpr int kTieStage = 8;       // coalesced loads per lane that stage those words (512 stream slots; beyond: the stream)
 constexpr int kTieSetSlots = 1024;  // LDS set of the tied pairs: kTieSet keys at most, load factor 1/4
 constexpr int kCandRegs = 8;        // candidates a lane holds in registers: kTrainThreads * kCandRegs = kCandHigh
 
+// 32-bit mixing: a 64-bit multiply is a dozen quarter-rate instructions, and the scan hashes every live symbol it passes
+__device__ __forceinline__ uint32_t tset_hash(unsigned long long key) {
+  return (((uint32_t)(key >> 32) * 0x9E3779B1u) ^ ((uint32_t)key * 0x85EBCA6Bu)) >> 22;
+}
+
 __device__ __forceinline__ void tset_insert(unsigned long long *tset, unsigned long long key) {
-  uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 54);
+  uint32_t h = tset_hash(key);
   for (;;) {  // a slot may be listed twice: the set takes a key once
     const unsigned long long old = atomicCAS(&tset[h], kEmptyKey, key);
     if (old == kEmptyKey || old == key) break;
@@ -736,7 +853,7 @@ __device__ __forceinline__ void tset_insert(unsigned long long *tset, unsigned l
 }
 
 __device__ __forceinline__ bool tset_has(const unsigned long long *tset, unsigned long long key) {
-  uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 54);
+  uint32_t h = tset_hash(key);
   for (;;) {
     const unsigned long long k = tset[h];
     if (k == key) return true;
@@ -761,24 +878,35 @@ __device__ __forceinline__ BlockArg block_reduce(unsigned long long m, unsigned 
 // pairs) the tied pairs in the LDS set.  The latency of a dependent access to the pair table is what this costs (~0.2 us
 // each: the table lives in the Infinity Cache), so a lane takes its candidates as three rounds of independent loads -- the
 // slots, their counts, the keys of its own maxima -- instead of a chain per candidate.
+// `spec` = cand[threadIdx.x + u * kTrainThreads], requested by the caller together with the state (before n_cand was known:
+// entries past n_cand are stale and unused), which takes the gather of the unmirrored tail from three round trips to two.
 __device__ __forceinline__ BlockArg block_argmax(const TrainCtx &C, unsigned long long n_cand, unsigned long long n_synced,
-                                                 unsigned long long *tset) {
+                                                 unsigned long long *tset, const uint32_t (&spec)[kCandRegs]) {
   if (n_cand <= (unsigned long long)kTrainThreads * kCandRegs) {
     long long v[kCandRegs];
     unsigned long long key[kCandRegs];
-    // the mirrored part of the list is a coalesced stream; the few candidates pushed since the last step are still gathered
+    uint32_t slot[kCandRegs];
+    // the mirrored part of the list is two coalesced streams, counts and keys, requested together; the few candidates
+    // pushed since the last step are gathered from the table in a second round
     long long lm = 0;
 #pragma unroll
     for (int u = 0; u < kCandRegs; u++) {
       const uint64_t i = threadIdx.x + (uint64_t)u * kTrainThreads;
-      v[u] = i < n_synced ? C.ccnt[i] : (i < n_cand ? C.T.cnt[C.cand[i]] : 0);
+      v[u] = 0;
+      key[u] = kEmptyKey;
+      slot[u] = 0xFFFFFFFFu;
+      if (i < n_synced) { v[u] = C.ccnt[i]; key[u] = C.ckey[i]; }
+      else if (i < n_cand) slot[u] = spec[u];
+    }
+#pragma unroll
+    for (int u = 0; u < kCandRegs; u++) {
+      if (slot[u] != 0xFFFFFFFFu) { v[u] = C.T.cnt[slot[u]]; key[u] = C.T.keys[slot[u]]; }
       lm = v[u] > lm ? v[u] : lm;
     }
     unsigned long long m = 0, c = 0, k = kEmptyKey;
 #pragma unroll
     for (int u = 0; u < kCandRegs; u++) {
-      const uint64_t i = threadIdx.x + (uint64_t)u * kTrainThreads;
-      key[u] = (lm > 0 && v[u] == lm) ? (i < n_synced ? C.ckey[i] : C.T.keys[C.cand[i]]) : kEmptyKey;
+      if (!(lm > 0 && v[u] == lm)) key[u] = kEmptyKey;
       if (key[u] != kEmptyKey) arg_combine(m, c, k, (unsigned long long)lm, 1ull, key[u]);
     }
     const BlockArg a = block_reduce(m, c, k);
@@ -818,10 +946,22 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
                                                                  uint64_t n_words, TrainCtx C) {
   __shared__ unsigned long long tset[kTieSetSlots];
   TrainState *st = C.st;
+  SWT_SPAN(0, C.step);
+#ifdef SWT_STAMPS
+  unsigned long long ts[8];
+#endif
+  SWT_STAMP(ts, 0);
   const unsigned int flags = st->flags;
   const unsigned long long n_cand = st->n_cand, n_synced = st->n_synced, plateau = st->plateau, idx_cursor = st->idx_cursor;
   const uint64_t cursor_w = st->cursor_w;
+  uint32_t cand_spec[kCandRegs];  // see block_argmax
+#pragma unroll
+  for (int u = 0; u < kCandRegs; u++) {
+    const uint64_t i = threadIdx.x + (uint64_t)u * kTrainThreads;
+    cand_spec[u] = i < C.cand_cap ? C.cand[i] : 0xFFFFFFFFu;
+  }
   if (flags & kFlagReplan) return;  // a dry batch: fast_apply_kernel logs it
+  SWT_STAMP(ts, 1);
   const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
   if (lead) {
     // the step's index segment begins where the log stands (no apply is in flight); a merged id that was reused in the last
@@ -833,6 +973,30 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
     if (lead) atomicOr(&st->flags, kFlagReplan);
     return;
   }
+  // The tie scan: trips of gridDim.x * 4 * kTieWords words from the plateau cursor.  What bounds this launch is the instruction
+  // stream of its slowest wave, so a word gets SIXTEEN lanes, one stream slot each (a lane per word walked its slots one after
+  // the other, holes included: 6 us of the 14), and a wave takes only kTieWords consecutive words: one contiguous piece of the
+  // stream, fetched with coalesced loads that are all in flight together and parked in LDS.  The first trip is requested NOW
+  // -- from the cursor: the common case late in training -- so that it travels while the argmax waits for the candidate list.
+  __shared__ uint32_t wbuf_s[kTrainThreads / 64][kTieStage * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t *wbuf = wbuf_s[wave];
+  const uint64_t trip_words = (uint64_t)gridDim.x * (kTrainThreads / 64) * kTieWords;
+  const uint64_t wave_off = ((uint64_t)blockIdx.x * (kTrainThreads / 64) + wave) * kTieWords;
+  uint64_t wo = 0, s0 = 0, s1 = 0;  // wo: lanes 0..kTieWords hold the bounds of the wave's words
+  uint32_t pre[kTieStage];
+#define SWT_TIE_FETCH(w_)                                                         \
+  do {                                                                            \
+    const uint64_t wl_ = (w_) + (uint64_t)lane;                                   \
+    wo = woff[wl_ < n_words ? wl_ : n_words];  /* lanes past kTieWords: unused */  \
+    s0 = __shfl(wo, 0);                                                           \
+    s1 = __shfl(wo, kTieWords);                                                   \
+    _Pragma("unroll") for (int k_ = 0; k_ < kTieStage; k_++) {                    \
+      const uint64_t at_ = s0 + (uint64_t)(k_ * 64 + lane);                       \
+      pre[k_] = at_ < s1 ? sym[at_] : kHole;                                      \
+    }                                                                             \
+  } while (0)
+  SWT_TIE_FETCH(cursor_w + wave_off);
   if (blockIdx.x == 0) {
     // the candidates the last merge pushed get their compact copy now (no count moves while this launch runs); every
     // workgroup of THIS launch still gathers them from the table, fast_apply_kernel then moves n_synced up
@@ -844,13 +1008,9 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
     }
     if (lead) st->n_synced_next = n_cand;
   }
-  // the word this lane will scan first if the maximum is tied at the plateau's level (the common case late in training):
-  // its bounds are requested now, so that they travel while the argmax waits for the candidate list
-  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t w_spec = cursor_w + gid;
-  uint64_t sb0 = 0, sb1 = 0;
-  if (w_spec < n_words) { sb0 = woff[w_spec]; sb1 = woff[w_spec + 1]; }
-  const BlockArg a = block_argmax(C, n_cand, n_synced, tset);
+  SWT_STAMP(ts, 2);
+  const BlockArg a = block_argmax(C, n_cand, n_synced, tset, cand_spec);
+  SWT_STAMP(ts, 3);
   const bool dry = a.mx < C.theta && C.theta > 1;
   if (lead) {
     st->max_count = a.mx;
@@ -858,67 +1018,124 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
     st->best_key = a.key;
     if (dry) atomicOr(&st->flags, kFlagReplan);
   }
+#ifdef SWT_STAMPS
+  if (lead && (dry || a.tied < 2 || a.mx == 0)) {  // no tie: the launch ends here
+    for (int q = 0; q < 3; q++) atomicAdd(&g_phase[0][5 + q], ts[q + 1] - ts[q]);
+    atomicAdd(&g_phase[0][14], 1ull);
+  }
+  int n_trips = 0;
+#endif
   if (dry || a.tied < 2 || a.mx == 0) return;
   const unsigned long long mx = a.mx;
   const bool use_set = a.tied <= kTieSet;
   unsigned long long *best = &st->best2[C.step & 1];
   const uint64_t start = plateau == mx ? cursor_w : 0ull;
-  bool first = true;
-  for (uint64_t w = start + gid; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
-    // words only get later: once a hit is in, lanes past it stop (on its first word a lane does not ask: nothing is in yet)
-    if (!first && (w << 32) >= __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-    const bool spec = first && w == w_spec;
-    first = false;
-    const uint64_t b0 = spec ? sb0 : woff[w], b1 = spec ? sb1 : woff[w + 1];
-    uint32_t x = kHole;
-    uint64_t xi = 0;
-    bool found = false;
-    for (uint64_t base = b0; base < b1 && !found; base += 16) {  // sixteen symbols per round of loads
-      uint32_t y16[16];
+  __shared__ unsigned long long blk_seen;
+  __shared__ unsigned int blk_hit;
+  if (threadIdx.x == 0) blk_hit = 0;
+  const int grp = lane >> 4, j = lane & 15;
+  for (uint64_t t0 = start; t0 < n_words; t0 += trip_words) {  // the same trips for every lane of the workgroup
+    const uint64_t w_wave = t0 + wave_off;
+    if (t0 != start) {
+      // words only get later: once a hit before this trip's words is in, the workgroup is done
+      if (threadIdx.x == 0) blk_seen = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (((t0 + (uint64_t)blockIdx.x * (kTrainThreads / 64) * kTieWords) << 32) >= blk_seen) break;
+    }
+#ifdef SWT_STAMPS
+    if (n_trips == 0) { SWT_STAMP(ts, 4); ts[7] = ts[4]; }
+    n_trips++;
+#endif
+    if (t0 != start || start != cursor_w) SWT_TIE_FETCH(w_wave);  // not the trip that is here already
 #pragma unroll
-      for (int u = 0; u < 16; u++) y16[u] = base + u < b1 ? sym[base + u] : kHole;
-      // the pairs of the round, then their set probes as one batch of independent LDS reads
-      unsigned long long key16[16], got16[16];
-      uint32_t h16[16];
-      uint32_t px = x;
-#pragma unroll
-      for (int u = 0; u < 16; u++) {
-        key16[u] = (y16[u] != kHole && px != kHole) ? pair_key(px, y16[u]) : kEmptyKey;
-        if (y16[u] != kHole) px = y16[u];
-        h16[u] = (uint32_t)((key16[u] * 0x9E3779B97F4A7C15ull) >> 54);
-      }
-      if (use_set) {
-#pragma unroll
-        for (int u = 0; u < 16; u++) got16[u] = tset[h16[u]];
-      }
-#pragma unroll
-      for (int u = 0; u < 16; u++) {
-        const uint32_t y = y16[u];
-        if (y == kHole || found) continue;
-        if (x != kHole) {
-          const unsigned long long key = key16[u];
-          bool hit;
-          if (!use_set) hit = (unsigned long long)table_get(C.T, key) == mx;
-          else if (got16[u] == key) hit = true;
-          else if (got16[u] == kEmptyKey) hit = false;
-          else hit = tset_has(tset, key);  // a collision on the first probe: walk on
-          if (hit) {
-            C.wkey[w] = key;
-            atomicMin(best, (unsigned long long)((w << 32) | (xi - b0)));
-            found = true;
+    for (int k = 0; k < kTieStage; k++) wbuf[k * 64 + lane] = pre[k];
+#ifdef SWT_STAMPS
+    if (n_trips == 1) SWT_STAMP(ts, 7);
+#endif
+    __syncthreads();
+    unsigned long long mine = kEmptyKey;
+    for (int r = 0; r < kTieWords / 4; r++) {  // four words at a time, in word order
+      const int wi = r * 4 + grp;
+      const uint64_t w = w_wave + (uint64_t)wi;
+      const uint64_t b0 = __shfl(wo, wi), b1 = __shfl(wo, wi + 1);
+      const uint32_t o0 = (uint32_t)(b0 - s0), len = w < n_words ? (uint32_t)(b1 - b0) : 0u;
+      uint32_t carry = kHole, carry_i = 0;  // the word's last live symbol before this round of sixteen slots
+      bool done = false;                    // this word has its hit
+      for (uint32_t base = 0; __any(base < len && !done); base += 16) {
+        const uint32_t p = base + (uint32_t)j;
+        uint32_t y = kHole;
+        if (p < len && !done) y = o0 + p < (uint32_t)(kTieStage * 64) ? wbuf[o0 + p] : sym[b0 + p];
+        const unsigned long long live = __ballot(y != kHole);
+        const uint32_t gm = (uint32_t)(live >> (grp * 16)) & 0xFFFFu;
+        const uint32_t below = gm & ((1u << j) - 1u);
+        // the live symbol before mine: a lane of my group, or the carry
+        const int src = below ? 31 - __builtin_clz(below) : j;
+        const uint32_t from = __shfl(y, grp * 16 + src);
+        const uint32_t px = below ? from : carry;
+        const uint32_t pxi = below ? base + (uint32_t)src : carry_i;
+        bool hit = false;
+        unsigned long long key = kEmptyKey;
+        if (y != kHole && px != kHole) {
+          key = pair_key(px, y);
+          if (!use_set) {
+            hit = (unsigned long long)table_get(C.T, key) == mx;
+          } else {
+            const unsigned long long got = tset[tset_hash(key)];
+            hit = got == key || (got != kEmptyKey && tset_has(tset, key));  // a collision on the first probe: walk on
           }
         }
-        x = y;
-        xi = base + u;
+        const uint32_t hm = (uint32_t)(__ballot(hit) >> (grp * 16)) & 0xFFFFu;
+        if (hm) {
+          if (hit && (hm & ((1u << j) - 1u)) == 0) {  // the group's first hit
+            C.wkey[w] = key;
+            mine = (unsigned long long)((w << 32) | pxi);
+          }
+          done = true;
+        }
+        // the group's last live symbol of this round is the next round's carry
+        const int top = gm ? 31 - __builtin_clz(gm) : j;
+        const uint32_t last = __shfl(y, grp * 16 + top);
+        if (gm) { carry = last; carry_i = base + (uint32_t)top; }
       }
+      if (__any(done)) break;  // the wave's later words are later
     }
+    // the wave's earliest hit goes out as ONE atomic (same-address device atomics from hundreds of lanes cost microseconds:
+    // tools/micro/atomic_probe.hip)
+    if (__any(mine != kEmptyKey)) {
+      for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(mine, d);
+        mine = o < mine ? o : mine;
+      }
+      if (lane == 0) { atomicMin(best, mine); blk_hit = 1; }
+    }
+#ifdef SWT_STAMPS
+    if (n_trips == 1) SWT_STAMP(ts, 5);
+#endif
+    __syncthreads();
+    if (blk_hit) break;  // later trips only hold later words
   }
+#undef SWT_TIE_FETCH
+#ifdef SWT_STAMPS
+  SWT_STAMP(ts, 6);
+  if (lead) {  // phases: state loads, mirror + prefetch, argmax (+ set), -, first word scanned, the rest of the trips
+    if (n_trips == 0) { ts[4] = ts[3]; ts[5] = ts[3]; ts[7] = ts[3]; }
+    for (int q = 0; q < 3; q++) atomicAdd(&g_phase[0][q], ts[q + 1] - ts[q]);
+    atomicAdd(&g_phase[0][3], ts[5] - ts[3]);
+    atomicAdd(&g_phase[0][4], ts[6] - ts[5]);
+    atomicAdd(&g_phase[0][8], ts[4] - ts[3]);   // argmax done -> scan begins (the lead's stores)
+    atomicAdd(&g_phase[0][9], ts[7] - ts[4]);   // the first word's symbols
+    atomicAdd(&g_phase[0][10], ts[5] - ts[7]);  // its probes, the hit
+    atomicAdd(&g_phase[0][13], (unsigned long long)n_trips);
+    atomicAdd(&g_phase[0][15], 1ull);
+  }
+#endif
 }
 
 __global__ __launch_bounds__(kTrainThreads) void fast_apply_kernel(uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
                                                                    const uint32_t *__restrict__ freq, uint64_t n_words, TrainCtx C,
                                                                    StepLog *__restrict__ log, uint32_t log_i, uint32_t merged) {
   TrainState *st = C.st;
+  SWT_SPAN(1, C.step);
   const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
   if (st->flags & kFlagReplan) {  // dry (this step or an earlier one of the batch): nothing runs until the host re-plans
     if (lead) { log[log_i].l = 0; log[log_i].r = 0; log[log_i].count = 0; log[log_i].flag = 3ull; log[log_i].n_syms = st->n_syms; log[log_i].n_tied = 0; log[log_i].n_cand = st->n_cand; }
@@ -1525,8 +1742,8 @@ void swt_bpe_trainer::enqueue_fast_step(uint32_t log_i, uint32_t merged) {
   const TrainCtx C = ctx();
   if (!n_words) return;
   // every workgroup of the tie launch reads the whole candidate list: few of them for a small corpus, kTieBlocks at most
-  unsigned tie_blocks = grid_for(n_words, kTrainThreads * 16, kTieBlocks);
-  if (tie_blocks < 8) tie_blocks = grid_for(n_words, kTrainThreads, 8);
+  // a trip of the tie scan covers 64 words per workgroup (16 lanes a word, kTieWords words a wave)
+  const unsigned tie_blocks = grid_for(n_words, 64, kTieBlocks);
   hipLaunchKernelGGL(fast_tie_kernel, dim3(tie_blocks), dim3(kTrainThreads), 0, stream, d_sym, d_woff, n_words, C);
   hipLaunchKernelGGL(fast_apply_kernel, dim3(kFastApplyBlocks), dim3(kTrainThreads), 0, stream, d_sym, d_woff, d_freq, n_words, C,
                      d_steplog, log_i, merged);
@@ -1536,6 +1753,23 @@ void swt_bpe_trainer::enqueue_apply() {
   if (n_words)
     hipLaunchKernelGGL(apply_kernel, dim3(kApplyBlocks), dim3(kTrainThreads), 0, stream, d_sym, d_woff, d_freq, n_words, ctx(), d_cmd);
 }
+
+#ifdef SWT_STAMPS
+// diagnostic builds only (not in include/swt.h): read = 0 resets the stamps, 1 copies spans (4 * 16384) then phases (3 * 16)
+extern "C" int swt_debug_stamps(int read, unsigned long long *out) {
+  if (!read) {
+    static unsigned long long init[4][kSpanSteps];
+    for (uint32_t i = 0; i < kSpanSteps; i++) { init[0][i] = ~0ull; init[1][i] = 0; init[2][i] = ~0ull; init[3][i] = 0; }
+    static unsigned long long zero[3][16];
+    static unsigned int zero_r[kSpanSteps];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_span), init, sizeof init) != hipSuccess) return -4;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_reported), zero_r, sizeof zero_r) != hipSuccess) return -4;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase), zero, sizeof zero) == hipSuccess ? 0 : -4;
+  }
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 4 * kSpanSteps) != hipSuccess) return -4;
+  return hipMemcpyFromSymbol(out + 4 * kSpanSteps, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 48) == hipSuccess ? 0 : -4;
+}
+#endif
 
 extern "C" {
 

@@ -16,7 +16,10 @@ constexpr uint32_t kCandTarget = 1024;  // pairs the candidate threshold theta l
 constexpr uint32_t kCandHigh = 2048;    // re-plan at a batch boundary once pushes have grown the list beyond this
 constexpr uint32_t kCandCap = 8192;     // room for the pairs that cross theta afterwards
 constexpr uint32_t kTieSet = 256;       // tied pairs a workgroup keeps in its LDS set (more: membership by table probe)
-constexpr uint32_t kTieBlocks = 128;
+#ifndef SWT_TIE_BLOCKS
+#define SWT_TIE_BLOCKS 128
+#endif
+constexpr uint32_t kTieBlocks = SWT_TIE_BLOCKS;
 constexpr uint32_t kApplyBlocks = 512;
 constexpr uint32_t kFastApplyBlocks = 128;
 constexpr uint32_t kPackBlocks = 16;
