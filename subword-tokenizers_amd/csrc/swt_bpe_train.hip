@@ -555,17 +555,53 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 #endif
 
 constexpr int kEmitCap = 12;
-constexpr int kStage = 32;      // stream slots of a word staged in LDS before its walk
+constexpr int kStage = 24;      // stream slots of a word staged in LDS before its walk
 constexpr int kFlushBatch = 8;  // parked deltas whose table probes go out together
 constexpr unsigned long long kEmitNew = 1ull << 63;  // symbol ids stay below 2^31, so bit 63 of a pair key is free
 
 // the slot of a key that is very likely in the table already: one plain load; anything else goes the insert-or-find way
 __device__ __forceinline__ uint32_t slot_hint(const PairTable &T, unsigned long long key) { return hash_slot(key, T.bits); }
 
-__device__ __forceinline__ void index_entry(const TrainCtx &C, uint64_t at, unsigned long long key, uint32_t m, uint32_t w) {
+// What one apply launch merges: K pairs (l[q], r[q]) -> first_m + q, in this order.  K > 1 only on the fast path, for pairs
+// that cannot affect each other (fast_apply_kernel says when); unused members hold kHole, which no live symbol equals.
+struct BatchPlan {
+  uint32_t K, first_m;
+  uint32_t l[kMaxBatch], r[kMaxBatch];
+  const uint32_t *list[kMaxBatch];  // member q's words: word ids ...
+  const uint32_t *tags[kMaxBatch];  // ... and, in a log segment, the tags that tell its entries from other pairs'
+  uint32_t want[kMaxBatch];
+  unsigned long long ent0[kMaxBatch + 1];  // running sum of the lists' lengths
+};
+
+// where the words of member q are listed: the static index of the initial pairs, or the log segment of the step that made the
+// later-born of its two symbols (every occurrence of a pair is created in that ONE step)
+__device__ __forceinline__ unsigned long long plan_member(const TrainCtx &C, BatchPlan &P, int q) {
+  const uint32_t l = P.l[q], r = P.r[q];
+  const uint32_t sl = seg_of_symbol(C, l), sr = seg_of_symbol(C, r);
+  const uint32_t seg = sl > sr ? sl : sr;
+  unsigned long long n_ent = 0;
+  P.tags[q] = nullptr;
+  P.want[q] = 0;
+  if (seg == 0) {
+    const uint32_t h = k0_find(C.K, pair_key(l, r));
+    if (h != 0xFFFFFFFFu) { P.list[q] = C.K.words + C.K.start[h]; n_ent = C.K.len[h]; }
+    else P.list[q] = C.K.words;
+  } else {
+    const uint64_t s0 = C.seg_start[seg], s1 = C.seg_start[seg + 1];
+    P.list[q] = C.idx_word + s0;
+    P.tags[q] = C.idx_tag + s0;
+    n_ent = s1 - s0;
+    P.want[q] = (sl >= sr) ? ((r << 1) | 1u) : (l << 1);  // the later-born symbol is the segment's m; (m, m') counts as m left
+  }
+  return n_ent;
+}
+
+// the index entry of a new pair: the symbol beside the merged one, and the side the merged one is on.  When both symbols were
+// made in this step the left one counts as "the merged one" -- the same rule plan_member looks entries up by.
+__device__ __forceinline__ void index_entry(const TrainCtx &C, uint64_t at, unsigned long long key, uint32_t first_m, uint32_t K, uint32_t w) {
   if (at >= C.idx_cap) return;
   const uint32_t a = (uint32_t)(key >> 32), b = (uint32_t)key;
-  C.idx_tag[at] = (a == m) ? ((b << 1) | 1u) : (a << 1);  // the symbol beside m, and the side m is on
+  C.idx_tag[at] = (a - first_m < K) ? ((b << 1) | 1u) : (a << 1);
   C.idx_word[at] = w;
 }
 
@@ -573,37 +609,44 @@ __device__ __forceinline__ void index_entry(const TrainCtx &C, uint64_t at, unsi
 // Deltas beyond kEmitCap are applied on the spot (a new pair then takes its index entry with an atomic of its own).
 // `stage` holds the word's first kStage stream slots as they were before the walk (one LDS column per lane, loaded in one go:
 // the walk never reads a slot again after writing it, so the copy stays good); slots beyond come from the stream.
-__device__ __forceinline__ uint32_t walk_word(uint32_t *__restrict__ sym, uint64_t b0, uint64_t b1, uint32_t l, uint32_t r, uint32_t m,
-                                              long long f, const TrainCtx &C, uint32_t w, const uint32_t *stage,
-                                              unsigned long long *park, int &n_park, int &n_new) {
+// L / R are the plan's pairs in registers.  With one pair its own delta is NOT parked: the caller sends it once per wave
+// (every lane of a big merge has it); a batch parks it like any other.
+__device__ __forceinline__ uint32_t walk_word(uint32_t *__restrict__ sym, uint64_t b0, uint64_t b1, const uint32_t (&L)[kMaxBatch],
+                                              const uint32_t (&R)[kMaxBatch], uint32_t K, uint32_t first_m, long long f, const TrainCtx &C,
+                                              uint32_t w, const uint32_t *stage, unsigned long long *park, int &n_park, int &n_new) {
   uint32_t n_merged = 0;
   uint32_t po = 0, pn = 0;  // previous old / new symbol
   bool po_cov = false, pn_new = false, have = false;
   uint64_t i = b0;
 #define SYM(i_) (((i_) - b0) < (uint64_t)kStage ? stage[((i_) - b0) * kTrainThreads] : sym[(i_)])
   while (i < b1 && SYM(i) == kHole) i++;
-#define EMIT(a_, b_, new_)                                                           \
-  do {                                                                               \
-    const unsigned long long key_ = pair_key((a_), (b_));                            \
-    if (n_park < kEmitCap) {                                                         \
-      park[(n_park++) * kTrainThreads] = key_ | ((new_) ? kEmitNew : 0ull);          \
-      n_new += (new_) ? 1 : 0;                                                       \
-    } else {                                                                         \
-      table_add(C, key_, (new_) ? f : -f);                                           \
-      if (new_) index_entry(C, atomicAdd(&C.st->idx_cursor, 1ull), key_, m, w);      \
-    }                                                                                \
+#define EMIT(a_, b_, new_)                                                                   \
+  do {                                                                                       \
+    const unsigned long long key_ = pair_key((a_), (b_));                                    \
+    if (n_park < kEmitCap) {                                                                 \
+      park[(n_park++) * kTrainThreads] = key_ | ((new_) ? kEmitNew : 0ull);                  \
+      n_new += (new_) ? 1 : 0;                                                               \
+    } else {                                                                                 \
+      table_add(C, key_, (new_) ? f : -f);                                                   \
+      if (new_) index_entry(C, atomicAdd(&C.st->idx_cursor, 1ull), key_, first_m, K, w);     \
+    }                                                                                        \
   } while (0)
   while (i < b1) {
     const uint32_t x = SYM(i);
     uint64_t j = i + 1;
     uint32_t y = kHole;
     while (j < b1 && (y = SYM(j)) == kHole) j++;
-    const bool occ = j < b1 && x == l && y == r;
-    if (occ) {
+    int q = -1;  // the plan's pair here (the members share no symbol: at most one)
+    if (j < b1) {
+#pragma unroll
+      for (int u = 0; u < (int)kMaxBatch; u++) q = (x == L[u] && y == R[u]) ? u : q;
+    }
+    if (q >= 0) {
+      const uint32_t m = first_m + (uint32_t)q;
       if (have) EMIT(po, x, false);    // (prev, l): l is consumed
+      if (K > 1) EMIT(x, y, false);    // (l, r) itself
       if (have) EMIT(pn, m, true);     // (prev_new, merged)
-      // (l, r) itself: every lane of the launch has this one, the wave sends it once (apply_body)
-      po = r; po_cov = true; pn = m; pn_new = true; have = true;
+      po = y; po_cov = true; pn = m; pn_new = true; have = true;
       sym[i] = m;
       sym[j] = kHole;
       n_merged++;
@@ -623,8 +666,9 @@ __device__ __forceinline__ uint32_t walk_word(uint32_t *__restrict__ sym, uint64
   return n_merged;
 }
 
+// One apply launch over the plan P (in LDS, complete before the call).
 __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff, const uint32_t *__restrict__ freq,
-                                           uint64_t n_words, const TrainCtx &C, uint32_t l, uint32_t r, uint32_t m) {
+                                           uint64_t n_words, const TrainCtx &C, const BatchPlan &P) {
   __shared__ unsigned long long park_s[kTrainThreads * kEmitCap];  // [delta][lane]: a wave's lanes sit side by side
   __shared__ uint32_t stage_s[kTrainThreads * kStage];             // [slot][lane]
   unsigned long long *park = park_s + threadIdx.x;
@@ -635,28 +679,12 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
   unsigned long long ts[8];
 #endif
   SWT_STAMP(ts, 0);
-  // where the words of (l, r) are listed
-  const uint32_t *list = nullptr;  // word ids
-  const uint32_t *tags = nullptr;  // log segment: entries of other pairs are skipped by tag
-  uint64_t n_ent = 0;
-  uint32_t want_tag = 0;
-  if (st->flags & kFlagIndexBroken) {
-    n_ent = n_words;  // every word (only after a symbol id was reused: never on trained tables)
-  } else {
-    const uint32_t sl = seg_of_symbol(C, l), sr = seg_of_symbol(C, r);
-    const uint32_t seg = sl > sr ? sl : sr;
-    if (seg == 0) {
-      const uint32_t h = k0_find(C.K, pair_key(l, r));
-      if (h != 0xFFFFFFFFu) { list = C.K.words + C.K.start[h]; n_ent = C.K.len[h]; }
-      else list = C.K.words;
-    } else {
-      const uint64_t s0 = C.seg_start[seg], s1 = C.seg_start[seg + 1];
-      list = C.idx_word + s0;
-      tags = C.idx_tag + s0;
-      n_ent = s1 - s0;
-      want_tag = (sl >= sr) ? ((r << 1) | 1u) : (l << 1);  // the later-born symbol is the segment's m; (m, m) counts as m left
-    }
-  }
+  const uint32_t K = P.K, first_m = P.first_m;
+  uint32_t L[kMaxBatch], R[kMaxBatch];
+#pragma unroll
+  for (int u = 0; u < (int)kMaxBatch; u++) { L[u] = P.l[u]; R[u] = P.r[u]; }
+  const bool whole = (st->flags & kFlagIndexBroken) != 0;  // every word (only after a symbol id was reused: never on trained tables)
+  const uint64_t n_ent = whole ? n_words : P.ent0[K];
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   unsigned long long removed = 0, self_delta = 0, inserted = 0;
   uint32_t min_w = 0xFFFFFFFFu;
@@ -664,11 +692,14 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
     const uint64_t e = e0 + lane;
     uint32_t w = 0xFFFFFFFFu;
     if (e < n_ent) {
-      if (!list) {
+      if (whole) {
         w = (uint32_t)e;
       } else {
-        const uint32_t we = list[e];  // both loads go out together
-        if (!tags || tags[e] == want_tag) w = we;
+        uint32_t q = 0;
+        while (q + 1 < K && e >= P.ent0[q + 1]) q++;
+        const uint64_t at = e - P.ent0[q];
+        const uint32_t we = P.list[q][at];  // both loads go out together
+        if (!P.tags[q] || P.tags[q][at] == P.want[q]) w = we;
       }
     }
     int n_park = 0, n_new = 0;
@@ -684,16 +715,16 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
 #pragma unroll
       for (int u = 0; u < kStage; u++) stage[u * kTrainThreads] = pre[u];
       SWT_STAMP(ts, 2);
-      if (claimed < C.step) {
-        const uint32_t nm = walk_word(sym, b0, b1, l, r, m, f, C, w, stage, park, n_park, n_new);
+      if (claimed < C.step) {  // one lane per word and step: it merges every pair of the plan there
+        const uint32_t nm = walk_word(sym, b0, b1, L, R, K, first_m, f, C, w, stage, park, n_park, n_new);
         if (nm) {
           removed += nm;
           self_delta += (unsigned long long)nm * (unsigned long long)f;
           min_w = w < min_w ? w : min_w;
-          if (C.sfreq && l == r) {  // twin pair: nm merges happened in this word (see wp_move_freq)
+          if (C.sfreq && L[0] == R[0]) {  // twin pair: nm merges happened in this word (see wp_move_freq)
             const unsigned long long d = (unsigned long long)nm * (unsigned long long)f;
-            atomicAdd(reinterpret_cast<unsigned long long *>(&C.sfreq[l]), (unsigned long long)0 - 2 * d);
-            atomicAdd(reinterpret_cast<unsigned long long *>(&C.sfreq[m]), d);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&C.sfreq[L[0]]), (unsigned long long)0 - 2 * d);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&C.sfreq[first_m]), d);
           }
         }
       } else {
@@ -775,7 +806,7 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
             const unsigned long long q = atomicAdd(&st->n_touched, 1ull);
             if (q < C.touched_cap) C.touched[q] = h[u];
           }
-          if (is_new) index_entry(C, at++, key[u] & ~kEmitNew, m, w);
+          if (is_new) index_entry(C, at++, key[u] & ~kEmitNew, first_m, K, w);
         }
       }
 #ifdef SWT_STAMPS
@@ -804,28 +835,56 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
   }
   if (lane == 0 && inserted) atomicAdd(&st->n_used, inserted);
   if (lane == 0 && removed) {
-    table_add(C, pair_key(l, r), -(long long)self_delta);  // the merged pair's own count: once per wave, not once per word
+    if (K == 1) table_add(C, pair_key(L[0], R[0]), -(long long)self_delta);  // the pair's own count: once per wave, not once per word
     atomicAdd(&st->n_syms, (unsigned long long)0 - removed);
     atomicMin(&st->cursor_w, min_w);  // new pairs were born in these words: the tie scan may not start after them
   }
 }
 
+// a plan of one pair (every path but the fast one)
+__device__ __forceinline__ void plan_single(const TrainCtx &C, BatchPlan &P, uint32_t l, uint32_t r, uint32_t m) {
+  if (threadIdx.x == 0) {
+    P.K = 1;
+    P.first_m = m;
+    for (int u = 0; u < (int)kMaxBatch; u++) { P.l[u] = kHole; P.r[u] = kHole; }
+    P.l[0] = l;
+    P.r[0] = r;
+    P.ent0[0] = 0;
+    P.ent0[1] = (C.st->flags & kFlagIndexBroken) ? 0ull : plan_member(C, P, 0);
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(kTrainThreads) void apply_kernel(uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
                                                               const uint32_t *__restrict__ freq, uint64_t n_words, TrainCtx C,
                                                               const StepCmd *__restrict__ cmd) {
+  __shared__ BatchPlan P;
   if (!cmd->valid) return;
-  apply_body(sym, woff, freq, n_words, C, cmd->l, cmd->r, cmd->m);
+  plan_single(C, P, cmd->l, cmd->r, cmd->m);
+  apply_body(sym, woff, freq, n_words, C, P);
 }
 
-// ---- the fast path of unsharded BPE: two launches per merge ---------------------------------------------------------------
+// ---- the fast path of unsharded BPE: two launches per STEP, one or more merges per step ---------------------------------
 // The candidate list is short (kCandTarget at a re-plan), so EVERY workgroup of the tie launch finds the maximum over it by
 // itself -- no argmax launch, no partials, no decide launch:
 //   fast_tie_kernel    workgroup argmax (workgroup 0 publishes it); when the maximum is tied, the tied pairs go into an LDS
-//                      set and the words are scanned from the plateau cursor for the earliest one (membership = an LDS probe,
-//                      not a table probe); the finder leaves the pair in wkey[word], the position in best2[step parity]
-//   fast_apply_kernel  reads the published maximum and the winner (best2 / wkey) -- it may not look at the counts itself,
-//                      its own workgroups are already moving them -- then apply_body; workgroup 0 also writes the step's log
-//                      line, the plateau cursor, the merged symbol's birth step, and resets the other best2
+//                      set and the words are scanned from the plateau cursor: every tied pair gets the earliest position seen
+//                      of it (gpos[], by its place in the candidate list; the earliest of all in best2[step parity])
+//   fast_apply_kernel  reads the published maximum and the positions -- it may not look at the counts itself, its own
+//                      workgroups are already moving them -- and decides what the step merges; then apply_body; workgroup 0
+//                      also writes the log lines, the plateau cursor, the merged symbols' birth step, and resets the other best2
+//
+// Several merges in one step.  On a plateau (pairs tied at the maximum c) the reference (bpe.py:102) takes the tied pairs one
+// at a time, each time the one whose first occurrence comes first.  Let P1 < P2 < ... be the tied pairs in the order of their
+// first positions.  After merging P1 the reference picks P2 next PROVIDED
+//   (1) P2 still counts c: a merge only lowers the counts of pairs that share a symbol with it, so it suffices that P2 shares
+//       no symbol with P1 (then all of P2's occurrences, and so its first position and its rank among the others, stand), and
+//   (2) no pair the merge of P1 = (a, b) creates reaches c.  A new pair (x, ab) occurs at most as often as (x, a) did, so it
+//       reaches c only if (x, a) is itself tied at c; likewise (ab, y) needs (b, y) tied, and (ab, ab) needs (b, a) tied.
+//       So: P1 is "dangerous" iff some tied pair has a on its right or b on its left -- decided from the tied set alone.
+// By induction a step may merge the longest prefix P1..PK whose members share no symbol, ending at (and including) the first
+// dangerous one -- what the reference does in K iterations -- as long as the positions are those of a region EVERY workgroup
+// scanned (the scan's first trip: win_end); beyond it only the overall minimum is certain, and the step merges that alone.
 struct BlockArg {
   unsigned long long mx, tied, key;
 };
@@ -833,31 +892,75 @@ struct BlockArg {
 #ifndef SWT_TIE_WORDS
 #define SWT_TIE_WORDS 8
 #endif
-constexpr int kTieWords = SWT_TIE_WORDS;      // words a wave scans per trip of the tie scan: 16 lanes per word, 4 words at a time
-constexpr int kTieStage = 8;       // coalesced loads per lane that stage those words (512 stream slots; beyond: the stream)
-constexpr int kTieSetSlots = 1024;  // LDS set of the tied pairs: kTieSet keys at most, load factor 1/4
-constexpr int kCandRegs = 8;        // candidates a lane holds in registers: kTrainThreads * kCandRegs = kCandHigh
+constexpr int kTieWords = SWT_TIE_WORDS;  // words a wave scans per trip of the tie scan: 16 lanes per word, 4 words at a time
+constexpr int kTieStage = 8;              // coalesced loads per lane that stage those words (512 stream slots; beyond: the stream)
+constexpr int kTieSetSlots = 1024;        // LDS set of the tied pairs: kTieSet keys at most, load factor 1/4
+constexpr int kCandRegs = 8;              // candidates a lane holds in registers: kTrainThreads * kCandRegs = kCandHigh
+
+// the tied pairs of a step, in LDS
+struct TieSets {
+  unsigned long long key[kTieSetSlots];  // the pairs (open addressing)
+  unsigned long long pos[kTieSetSlots];  // earliest position this workgroup saw of each (word << 32 | offset of the left symbol)
+  uint32_t idx[kTieSetSlots];            // its place in the candidate list
+  uint32_t lefts[kTieSetSlots];          // the symbols some tied pair has on its left ...
+  uint32_t rights[kTieSetSlots];         // ... and on its right (for "dangerous", see above)
+};
 
 // 32-bit mixing: a 64-bit multiply is a dozen quarter-rate instructions, and the scan hashes every live symbol it passes
 __device__ __forceinline__ uint32_t tset_hash(unsigned long long key) {
   return (((uint32_t)(key >> 32) * 0x9E3779B1u) ^ ((uint32_t)key * 0x85EBCA6Bu)) >> 22;
 }
 
-__device__ __forceinline__ void tset_insert(unsigned long long *tset, unsigned long long key) {
-  uint32_t h = tset_hash(key);
-  for (;;) {  // a slot may be listed twice: the set takes a key once
-    const unsigned long long old = atomicCAS(&tset[h], kEmptyKey, key);
-    if (old == kEmptyKey || old == key) break;
+__device__ __forceinline__ void symset_insert(uint32_t *set, uint32_t s) {
+  uint32_t h = (s * 0x9E3779B1u) >> 22;
+  for (;;) {
+    const uint32_t old = atomicCAS(&set[h], kHole, s);
+    if (old == kHole || old == s) break;
     h = (h + 1) & (kTieSetSlots - 1);
   }
 }
 
-__device__ __forceinline__ bool tset_has(const unsigned long long *tset, unsigned long long key) {
+__device__ __forceinline__ bool symset_has(const uint32_t *set, uint32_t s) {
+  uint32_t h = (s * 0x9E3779B1u) >> 22;
+  for (;;) {
+    const uint32_t k = set[h];
+    if (k == s) return true;
+    if (k == kHole) return false;
+    h = (h + 1) & (kTieSetSlots - 1);
+  }
+}
+
+__device__ __forceinline__ void tset_clear(TieSets &S) {
+  for (int i = threadIdx.x; i < kTieSetSlots; i += blockDim.x) {
+    S.key[i] = kEmptyKey;
+    S.pos[i] = kEmptyKey;
+    S.lefts[i] = kHole;
+    S.rights[i] = kHole;
+  }
+}
+
+__device__ __forceinline__ void tset_insert(TieSets &S, unsigned long long key, uint32_t cand_i) {
+  uint32_t h = tset_hash(key);
+  for (;;) {  // a slot may be listed twice: the set takes a key once
+    const unsigned long long old = atomicCAS(&S.key[h], kEmptyKey, key);
+    if (old == kEmptyKey) {
+      S.idx[h] = cand_i;
+      symset_insert(S.lefts, (uint32_t)(key >> 32));
+      symset_insert(S.rights, (uint32_t)key);
+      break;
+    }
+    if (old == key) break;
+    h = (h + 1) & (kTieSetSlots - 1);
+  }
+}
+
+// the slot of `key`, -1 when it is not a tied pair
+__device__ __forceinline__ int tset_find(const TieSets &S, unsigned long long key) {
   uint32_t h = tset_hash(key);
   for (;;) {
-    const unsigned long long k = tset[h];
-    if (k == key) return true;
-    if (k == kEmptyKey) return false;
+    const unsigned long long k = S.key[h];
+    if (k == key) return (int)h;
+    if (k == kEmptyKey) return -1;
     h = (h + 1) & (kTieSetSlots - 1);
   }
 }
@@ -874,14 +977,13 @@ __device__ __forceinline__ BlockArg block_reduce(unsigned long long m, unsigned 
   return BlockArg{m, c, k};
 }
 
-// The workgroup's maximum over the candidate list, and (when tset != nullptr and the maximum is tied among at most kTieSet
-// pairs) the tied pairs in the LDS set.  The latency of a dependent access to the pair table is what this costs (~0.2 us
-// each: the table lives in the Infinity Cache), so a lane takes its candidates as three rounds of independent loads -- the
-// slots, their counts, the keys of its own maxima -- instead of a chain per candidate.
+// The workgroup's maximum over the candidate list, and (when the maximum is tied among at most kTieSet pairs) the tied pairs
+// in the LDS sets.  The latency of a dependent access to the pair table is what this costs, so a lane takes its candidates as
+// rounds of independent loads instead of a chain per candidate.
 // `spec` = cand[threadIdx.x + u * kTrainThreads], requested by the caller together with the state (before n_cand was known:
 // entries past n_cand are stale and unused), which takes the gather of the unmirrored tail from three round trips to two.
-__device__ __forceinline__ BlockArg block_argmax(const TrainCtx &C, unsigned long long n_cand, unsigned long long n_synced,
-                                                 unsigned long long *tset, const uint32_t (&spec)[kCandRegs]) {
+__device__ __forceinline__ BlockArg block_argmax(const TrainCtx &C, unsigned long long n_cand, unsigned long long n_synced, TieSets &S,
+                                                 const uint32_t (&spec)[kCandRegs]) {
   if (n_cand <= (unsigned long long)kTrainThreads * kCandRegs) {
     long long v[kCandRegs];
     unsigned long long key[kCandRegs];
@@ -910,13 +1012,13 @@ __device__ __forceinline__ BlockArg block_argmax(const TrainCtx &C, unsigned lon
       if (key[u] != kEmptyKey) arg_combine(m, c, k, (unsigned long long)lm, 1ull, key[u]);
     }
     const BlockArg a = block_reduce(m, c, k);
-    if (tset && a.tied >= 2 && a.tied <= kTieSet && a.mx) {
-      for (int i = threadIdx.x; i < kTieSetSlots; i += blockDim.x) tset[i] = kEmptyKey;
+    if (a.tied >= 2 && a.tied <= kTieSet && a.mx) {
+      tset_clear(S);
       __syncthreads();
       if ((unsigned long long)lm == a.mx) {
 #pragma unroll
         for (int u = 0; u < kCandRegs; u++)
-          if (key[u] != kEmptyKey) tset_insert(tset, key[u]);
+          if (key[u] != kEmptyKey) tset_insert(S, key[u], (uint32_t)(threadIdx.x + u * kTrainThreads));
       }
       __syncthreads();
     }
@@ -930,29 +1032,34 @@ __device__ __forceinline__ BlockArg block_argmax(const TrainCtx &C, unsigned lon
     if (v > 0 && (unsigned long long)v >= m) arg_combine(m, c, k, (unsigned long long)v, 1ull, C.T.keys[slot]);
   }
   const BlockArg a = block_reduce(m, c, k);
-  if (tset && a.tied >= 2 && a.tied <= kTieSet && a.mx) {
-    for (int i = threadIdx.x; i < kTieSetSlots; i += blockDim.x) tset[i] = kEmptyKey;
+  if (a.tied >= 2 && a.tied <= kTieSet && a.mx) {
+    tset_clear(S);
     __syncthreads();
     for (uint64_t i = threadIdx.x; i < n_cand; i += blockDim.x) {
       const uint32_t slot = C.cand[i];
-      if ((unsigned long long)C.T.cnt[slot] == a.mx) tset_insert(tset, C.T.keys[slot]);
+      if ((unsigned long long)C.T.cnt[slot] == a.mx) tset_insert(S, C.T.keys[slot], (uint32_t)i);
     }
     __syncthreads();
   }
   return a;
 }
 
+// `limit`: merges this host round trip may log (st->run_done counts them); a step past it is a no-op
 __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
-                                                                 uint64_t n_words, TrainCtx C) {
-  __shared__ unsigned long long tset[kTieSetSlots];
+                                                                 uint64_t n_words, TrainCtx C, uint32_t limit) {
+  __shared__ TieSets S;
   TrainState *st = C.st;
   SWT_SPAN(0, C.step);
 #ifdef SWT_STAMPS
   unsigned long long ts[8];
 #endif
   SWT_STAMP(ts, 0);
-  const unsigned int flags = st->flags;
+  const unsigned par = C.step & 1u;
+  // what this launch itself may change (workgroup 0 raises flags / halt) is read once per workgroup: its lanes must agree
+  __shared__ unsigned long long hdr[3];
+  if (threadIdx.x == 0) { hdr[0] = st->flags; hdr[1] = st->run_done[par]; hdr[2] = st->halt; }
   const unsigned long long n_cand = st->n_cand, n_synced = st->n_synced, plateau = st->plateau, idx_cursor = st->idx_cursor;
+  const unsigned long long n_old = st->n_list[par ^ 1u], n_syms_now = st->n_syms;
   const uint64_t cursor_w = st->cursor_w;
   uint32_t cand_spec[kCandRegs];  // see block_argmax
 #pragma unroll
@@ -960,17 +1067,22 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
     const uint64_t i = threadIdx.x + (uint64_t)u * kTrainThreads;
     cand_spec[u] = i < C.cand_cap ? C.cand[i] : 0xFFFFFFFFu;
   }
-  if (flags & kFlagReplan) return;  // a dry batch: fast_apply_kernel logs it
-  SWT_STAMP(ts, 1);
+  __syncthreads();
+  const unsigned int flags = (unsigned int)hdr[0];
   const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+  // the step's index segment begins where the log stands (no apply is in flight).  A step that does nothing says so too: its
+  // number is taken, and the segment before it ends where this one begins
+  if (lead) C.seg_start[C.step] = idx_cursor;
+  if ((flags & kFlagReplan) || hdr[2] || hdr[1] >= limit) return;  // nothing runs until the host has looked (fast_apply_kernel: too)
+  SWT_STAMP(ts, 1);
   if (lead) {
-    // the step's index segment begins where the log stands (no apply is in flight); a merged id that was reused in the last
-    // step voids the index from this step on
-    C.seg_start[C.step] = idx_cursor;
+    // a merged id that was reused in the last step voids the index from this step on
     if (idx_cursor > C.idx_cap || (flags & kFlagBrokenPending)) atomicOr(&st->flags, kFlagIndexBroken);
+    st->n_list[par] = 0;
+    st->step_syms = n_syms_now;
   }
   if (n_cand > C.cand_cap) {  // the list lost a candidate
-    if (lead) atomicOr(&st->flags, kFlagReplan);
+    if (lead) { atomicOr(&st->flags, kFlagReplan); st->halt = 3; }
     return;
   }
   // The tie scan: trips of gridDim.x * 4 * kTieWords words from the plateau cursor.  What bounds this launch is the instruction
@@ -1007,16 +1119,24 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
       C.cidx[slot] = (uint32_t)i;
     }
     if (lead) st->n_synced_next = n_cand;
+    // the positions the step before the last left in the other half of gpos[] have been read: that half is the next step's
+    for (uint64_t i = threadIdx.x; i < n_old; i += blockDim.x)
+      C.gpos[(size_t)(par ^ 1u) * C.cand_cap + (C.tied_idx[(par ^ 1u) * kTieSet + i] & 0x7FFFFFFFu)] = kEmptyKey;
   }
   SWT_STAMP(ts, 2);
-  const BlockArg a = block_argmax(C, n_cand, n_synced, tset, cand_spec);
+  const BlockArg a = block_argmax(C, n_cand, n_synced, S, cand_spec);
   SWT_STAMP(ts, 3);
   const bool dry = a.mx < C.theta && C.theta > 1;
+  const unsigned long long mx = a.mx;
+  const bool use_set = a.tied <= kTieSet;
+  const uint64_t start = plateau == mx ? cursor_w : 0ull;
   if (lead) {
     st->max_count = a.mx;
     st->n_tied = a.mx ? a.tied : 0;
     st->best_key = a.key;
-    if (dry) atomicOr(&st->flags, kFlagReplan);
+    const uint64_t we = start + trip_words;
+    st->win_end = (we < n_words ? we : n_words) << 32;
+    if (dry) { atomicOr(&st->flags, kFlagReplan); st->halt = 3; }
   }
 #ifdef SWT_STAMPS
   if (lead && (dry || a.tied < 2 || a.mx == 0)) {  // no tie: the launch ends here
@@ -1026,10 +1146,24 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
   int n_trips = 0;
 #endif
   if (dry || a.tied < 2 || a.mx == 0) return;
-  const unsigned long long mx = a.mx;
-  const bool use_set = a.tied <= kTieSet;
-  unsigned long long *best = &st->best2[C.step & 1];
-  const uint64_t start = plateau == mx ? cursor_w : 0ull;
+  if (blockIdx.x == 0 && use_set) {
+    // the tied pairs as a list, for fast_apply_kernel: place in the candidate list | dangerous << 31, and the key
+    __shared__ unsigned int n_listed;
+    if (threadIdx.x == 0) n_listed = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < kTieSetSlots; i += blockDim.x) {
+      const unsigned long long key = S.key[i];
+      if (key == kEmptyKey) continue;
+      const uint32_t qa = (uint32_t)(key >> 32), qb = (uint32_t)key;
+      const bool danger = symset_has(S.rights, qa) || symset_has(S.lefts, qb);  // a twin pair is its own witness
+      const unsigned int k = atomicAdd(&n_listed, 1u);
+      C.tied_idx[par * kTieSet + k] = S.idx[i] | (danger ? 0x80000000u : 0u);
+      C.tied_key[par * kTieSet + k] = key;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) st->n_list[par] = n_listed;
+  }
+  unsigned long long *best = &st->best2[par];
   __shared__ unsigned long long blk_seen;
   __shared__ unsigned int blk_hit;
   if (threadIdx.x == 0) blk_hit = 0;
@@ -1053,14 +1187,14 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
     if (n_trips == 1) SWT_STAMP(ts, 7);
 #endif
     __syncthreads();
-    unsigned long long mine = kEmptyKey;
+    unsigned long long mine = kEmptyKey;  // this lane's earliest hit of the trip
     for (int r = 0; r < kTieWords / 4; r++) {  // four words at a time, in word order
       const int wi = r * 4 + grp;
       const uint64_t w = w_wave + (uint64_t)wi;
       const uint64_t b0 = __shfl(wo, wi), b1 = __shfl(wo, wi + 1);
       const uint32_t o0 = (uint32_t)(b0 - s0), len = w < n_words ? (uint32_t)(b1 - b0) : 0u;
       uint32_t carry = kHole, carry_i = 0;  // the word's last live symbol before this round of sixteen slots
-      bool done = false;                    // this word has its hit
+      bool done = false;                    // table-probe mode: this word has its hit
       for (uint32_t base = 0; __any(base < len && !done); base += 16) {
         const uint32_t p = base + (uint32_t)j;
         uint32_t y = kHole;
@@ -1073,31 +1207,41 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
         const uint32_t from = __shfl(y, grp * 16 + src);
         const uint32_t px = below ? from : carry;
         const uint32_t pxi = below ? base + (uint32_t)src : carry_i;
-        bool hit = false;
+        bool hit = false;  // table-probe mode only
         unsigned long long key = kEmptyKey;
+        const unsigned long long at = (unsigned long long)((w << 32) | pxi);
         if (y != kHole && px != kHole) {
           key = pair_key(px, y);
-          if (!use_set) {
-            hit = (unsigned long long)table_get(C.T, key) == mx;
+          if (use_set) {
+            // every tied pair keeps the earliest position seen of it (here: by this workgroup)
+            const uint32_t h = tset_hash(key);
+            const unsigned long long got = S.key[h];
+            const int slot = got == key ? (int)h : (got == kEmptyKey ? -1 : tset_find(S, key));  // a collision on the first probe: walk on
+            if (slot >= 0) {
+              atomicMin(&S.pos[slot], at);
+              mine = at < mine ? at : mine;
+            }
           } else {
-            const unsigned long long got = tset[tset_hash(key)];
-            hit = got == key || (got != kEmptyKey && tset_has(tset, key));  // a collision on the first probe: walk on
+            hit = (unsigned long long)table_get(C.T, key) == mx;  // a plateau wider than the set: membership by table probe
           }
         }
-        const uint32_t hm = (uint32_t)(__ballot(hit) >> (grp * 16)) & 0xFFFFu;
-        if (hm) {
-          if (hit && (hm & ((1u << j) - 1u)) == 0) {  // the group's first hit
-            C.wkey[w] = key;
-            mine = (unsigned long long)((w << 32) | pxi);
+        if (!use_set) {
+          // ... and only the word's first hit, its pair left in wkey[word]: such a step merges one pair
+          const uint32_t hm = (uint32_t)(__ballot(hit) >> (grp * 16)) & 0xFFFFu;
+          if (hm) {
+            if (hit && (hm & ((1u << j) - 1u)) == 0) {
+              C.wkey[w] = key;
+              mine = at < mine ? at : mine;
+            }
+            done = true;
           }
-          done = true;
         }
         // the group's last live symbol of this round is the next round's carry
         const int top = gm ? 31 - __builtin_clz(gm) : j;
         const uint32_t last = __shfl(y, grp * 16 + top);
         if (gm) { carry = last; carry_i = base + (uint32_t)top; }
       }
-      if (__any(done)) break;  // the wave's later words are later
+      if (!use_set && __any(done)) break;  // the wave's later words are later
     }
     // the wave's earliest hit goes out as ONE atomic (same-address device atomics from hundreds of lanes cost microseconds:
     // tools/micro/atomic_probe.hip)
@@ -1115,6 +1259,13 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
     if (blk_hit) break;  // later trips only hold later words
   }
 #undef SWT_TIE_FETCH
+  if (use_set) {
+    // what this workgroup saw, to the step's positions (one address per tied pair)
+    for (int i = threadIdx.x; i < kTieSetSlots; i += blockDim.x) {
+      const unsigned long long at = S.pos[i];
+      if (at != kEmptyKey) atomicMin(&C.gpos[(size_t)par * C.cand_cap + S.idx[i]], at);
+    }
+  }
 #ifdef SWT_STAMPS
   SWT_STAMP(ts, 6);
   if (lead) {  // phases: state loads, mirror + prefetch, argmax (+ set), -, first word scanned, the rest of the trips
@@ -1131,47 +1282,131 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
 #endif
 }
 
+// `first_merged`: the symbol id of the round trip's first merge; `limit`: merges the round trip may log
 __global__ __launch_bounds__(kTrainThreads) void fast_apply_kernel(uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
                                                                    const uint32_t *__restrict__ freq, uint64_t n_words, TrainCtx C,
-                                                                   StepLog *__restrict__ log, uint32_t log_i, uint32_t merged) {
+                                                                   StepLog *__restrict__ log, uint32_t first_merged, uint32_t limit) {
+  __shared__ BatchPlan P;
+  __shared__ unsigned long long f_pos[kTieSet], f_key[kTieSet], p1_pos;
+  __shared__ uint32_t f_dng[kTieSet], ord[kMaxBatch];
+  __shared__ unsigned int n_found;
   TrainState *st = C.st;
   SWT_SPAN(1, C.step);
   const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
-  if (st->flags & kFlagReplan) {  // dry (this step or an earlier one of the batch): nothing runs until the host re-plans
-    if (lead) { log[log_i].l = 0; log[log_i].r = 0; log[log_i].count = 0; log[log_i].flag = 3ull; log[log_i].n_syms = st->n_syms; log[log_i].n_tied = 0; log[log_i].n_cand = st->n_cand; }
+  const unsigned par = C.step & 1u;
+  // what this launch itself may change (workgroup 0 raises flags / halt) is read once per workgroup: its lanes must agree
+  __shared__ unsigned long long hdr[3];
+  if (threadIdx.x == 0) { hdr[0] = st->flags; hdr[1] = st->run_done[par]; hdr[2] = st->halt; }
+  const unsigned long long mx = st->max_count, tied = st->n_tied, n_list = st->n_list[par], win_end = st->win_end;
+  __syncthreads();
+  const unsigned int flags = (unsigned int)hdr[0];
+  const unsigned long long run_done = hdr[1];
+  if ((flags & kFlagReplan) || hdr[2] || run_done >= limit) {  // nothing runs until the host has looked
+    if (lead) st->run_done[par ^ 1u] = run_done;
     return;
   }
-  const unsigned long long mx = st->max_count, tied = st->n_tied;
-  unsigned long long key = st->best_key, pos = kEmptyKey;
-  if (mx && tied >= 2) {
-    pos = st->best2[C.step & 1];
-    key = pos != kEmptyKey ? C.wkey[pos >> 32] : kEmptyKey;
+  // ---- what this step merges (every workgroup decides for itself, from what the tie launch left) ----
+  if (threadIdx.x == 0) {
+    n_found = 0;
+    p1_pos = kEmptyKey;
+    P.K = 0;
+    P.first_m = first_merged + (uint32_t)run_done;
+    for (int u = 0; u < (int)kMaxBatch; u++) { P.l[u] = kHole; P.r[u] = kHole; }
   }
-  const bool ok = mx > 0 && key != kEmptyKey;
-  const uint32_t l = (uint32_t)(key >> 32), r = (uint32_t)key;
+  __syncthreads();
+  if (mx && tied >= 2 && n_list) {
+    // the tied pairs that were seen, by position
+    if (threadIdx.x < n_list) {
+      const uint32_t info = C.tied_idx[par * kTieSet + threadIdx.x];
+      const unsigned long long key = C.tied_key[par * kTieSet + threadIdx.x];
+      const unsigned long long pos = C.gpos[(size_t)par * C.cand_cap + (info & 0x7FFFFFFFu)];
+      if (pos != kEmptyKey) {
+        const unsigned int k = atomicAdd(&n_found, 1u);
+        f_pos[k] = pos;
+        f_key[k] = key;
+        f_dng[k] = info >> 31;
+      }
+    }
+    __syncthreads();
+    const unsigned int nf = n_found;
+    if (threadIdx.x < nf) {
+      const unsigned long long mine = f_pos[threadIdx.x];
+      unsigned int rank = 0;
+      for (unsigned int u = 0; u < nf; u++) rank += f_pos[u] < mine ? 1u : 0u;  // positions are distinct
+      if (rank < kMaxBatch) ord[rank] = threadIdx.x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && nf) {
+      // the longest prefix whose members share no symbol, up to and including the first dangerous one (see above)
+      const unsigned long long room = (unsigned long long)limit - run_done;
+      uint32_t K = 0;
+      for (unsigned int rk = 0; rk < nf && rk < kMaxBatch; rk++) {
+        const unsigned int e = ord[rk];
+        const uint32_t a = (uint32_t)(f_key[e] >> 32), b = (uint32_t)f_key[e];
+        if (K) {
+          if (f_pos[e] >= win_end) break;  // not every workgroup scanned that far
+          bool clash = false;
+          for (uint32_t q = 0; q < K; q++) clash |= a == P.l[q] || a == P.r[q] || b == P.l[q] || b == P.r[q];
+          if (clash) break;
+        } else {
+          p1_pos = f_pos[e];
+        }
+        P.l[K] = a;
+        P.r[K] = b;
+        K++;
+        if (f_dng[e] || K >= room) break;
+      }
+      P.K = K;
+    }
+  } else if (threadIdx.x == 0 && mx) {
+    unsigned long long key = st->best_key;
+    if (tied >= 2) {  // a plateau wider than the tie set: the scan left the earliest pair in wkey[]
+      const unsigned long long pos = st->best2[par];
+      key = pos != kEmptyKey ? C.wkey[pos >> 32] : kEmptyKey;
+      p1_pos = pos;
+    }
+    if (key != kEmptyKey) { P.l[0] = (uint32_t)(key >> 32); P.r[0] = (uint32_t)key; P.K = 1; }
+  }
+  __syncthreads();
+  const uint32_t K = P.K;
+  if (K == 0) {  // bpe.py:98-99: no pair left
+    if (lead) { st->halt = 2; st->run_done[par ^ 1u] = run_done; }
+    return;
+  }
+  if (threadIdx.x < K && !(flags & kFlagIndexBroken)) P.ent0[threadIdx.x + 1] = plan_member(C, P, (int)threadIdx.x);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    P.ent0[0] = 0;
+    for (uint32_t q = 0; q < K; q++) P.ent0[q + 1] = (flags & kFlagIndexBroken) ? 0ull : P.ent0[q] + P.ent0[q + 1];
+  }
   if (lead) {
+    const unsigned long long pos = p1_pos;
     st->res_pos = pos;
-    st->win_key = key;
-    st->best2[(C.step + 1) & 1] = kEmptyKey;  // the next step's scan starts from a clean minimum
-    st->n_synced = st->n_synced_next;          // the tie launch mirrored the candidates up to there
+    st->win_key = pair_key(P.l[0], P.r[0]);
+    st->best2[par ^ 1u] = kEmptyKey;    // the next step's scan starts from a clean minimum
+    st->n_synced = st->n_synced_next;  // the tie launch mirrored the candidates up to there
     // the plateau cursor: a plain store beside the other workgroups' atomicMin of the words they touch -- both orders leave a
-    // valid lower bound (the winner's first word is the first word this merge touches)
+    // valid lower bound (the first member's first word is the first word this step touches)
     if (tied >= 2 && pos != kEmptyKey) { st->plateau = mx; st->cursor_w = (uint32_t)(pos >> 32); }
     else if (st->plateau != mx) { st->plateau = mx; st->cursor_w = 0; }
-    if (ok) {
+    const unsigned long long n_syms = st->step_syms, n_cand = st->n_cand;
+    for (uint32_t q = 0; q < K; q++) {
+      const uint32_t merged = P.first_m + q;
       if (merged >= C.id_base && merged - C.id_base < C.seg_cap && C.seg_of[merged - C.id_base] == 0) C.seg_of[merged - C.id_base] = C.step;
       else atomicOr(&st->flags, kFlagBrokenPending);  // the next step's tie launch turns it into kFlagIndexBroken
+      StepLog &row = log[run_done + q];
+      row.l = P.l[q];
+      row.r = P.r[q];
+      row.count = mx;
+      row.flag = 0ull;
+      row.n_syms = n_syms;  // of the step: the members after the first saw a few symbols less
+      row.n_tied = tied;
+      row.n_cand = n_cand;
     }
-    log[log_i].l = l;
-    log[log_i].r = r;
-    log[log_i].count = mx;
-    log[log_i].flag = ok ? 0ull : 2ull;
-    log[log_i].n_syms = st->n_syms;
-    log[log_i].n_tied = tied;
-    log[log_i].n_cand = st->n_cand;
+    st->run_done[par ^ 1u] = run_done + K;
   }
-  if (!ok) return;
-  apply_body(sym, woff, freq, n_words, C, l, r, merged);
+  __syncthreads();
+  apply_body(sym, woff, freq, n_words, C, P);
 }
 
 // ---- candidates --------------------------------------------------------------------------------------------------------
@@ -1397,6 +1632,9 @@ TrainCtx swt_bpe_trainer::ctx() const {
   C.id_base = id_base;
   C.wstamp = d_wstamp;
   C.wkey = d_wkey;
+  C.tied_idx = d_tied_idx;
+  C.tied_key = d_tied_key;
+  C.gpos = d_gpos;
   C.step = step_no;
   C.pend = sharded ? d_pend : nullptr;
   C.tstamp = d_tstamp;
@@ -1467,6 +1705,9 @@ int swt_bpe_trainer::replan() {
     SWT_HIP(hipMalloc((void **)&d_ccnt, (size_t)cand_cap * 8));
     SWT_HIP(hipMalloc((void **)&d_ckey, (size_t)cand_cap * 8));
     SWT_HIP(hipMalloc((void **)&d_buckets, 512 * 8));
+    SWT_HIP(hipMalloc((void **)&d_tied_idx, 2 * kTieSet * 4));
+    SWT_HIP(hipMalloc((void **)&d_tied_key, 2 * kTieSet * 8));
+    SWT_HIP(hipMalloc((void **)&d_gpos, 2 * (size_t)cand_cap * 8));
   }
   if (!d_cidx || cidx_bits != T.bits) {  // one place per table slot
     if (d_cidx) (void)hipFree(d_cidx);
@@ -1738,15 +1979,15 @@ void swt_bpe_trainer::enqueue_argmax() {
 }
 
 // unsharded BPE: tie scan + apply, each with its own workgroup-level argmax over the (short) candidate list
-void swt_bpe_trainer::enqueue_fast_step(uint32_t log_i, uint32_t merged) {
+void swt_bpe_trainer::enqueue_fast_step(uint32_t first_merged, uint32_t limit) {
   const TrainCtx C = ctx();
   if (!n_words) return;
   // every workgroup of the tie launch reads the whole candidate list: few of them for a small corpus, kTieBlocks at most
   // a trip of the tie scan covers 64 words per workgroup (16 lanes a word, kTieWords words a wave)
   const unsigned tie_blocks = grid_for(n_words, 64, kTieBlocks);
-  hipLaunchKernelGGL(fast_tie_kernel, dim3(tie_blocks), dim3(kTrainThreads), 0, stream, d_sym, d_woff, n_words, C);
+  hipLaunchKernelGGL(fast_tie_kernel, dim3(tie_blocks), dim3(kTrainThreads), 0, stream, d_sym, d_woff, n_words, C, limit);
   hipLaunchKernelGGL(fast_apply_kernel, dim3(kFastApplyBlocks), dim3(kTrainThreads), 0, stream, d_sym, d_woff, d_freq, n_words, C,
-                     d_steplog, log_i, merged);
+                     d_steplog, first_merged, limit);
 }
 
 void swt_bpe_trainer::enqueue_apply() {
@@ -1861,7 +2102,7 @@ void swt_bpe_train_destroy(swt_bpe_trainer *t) {
   (void)hipStreamSynchronize(t->stream);
   for (void *p : {(void *)t->d_sym, (void *)t->d_woff, (void *)t->d_freq, (void *)t->d_st, (void *)t->d_parts, (void *)t->d_cmd,
                   (void *)t->d_steplog, (void *)t->d_sfreq, (void *)t->d_cand, (void *)t->d_ccnt, (void *)t->d_ckey, (void *)t->d_cidx, (void *)t->d_buckets, (void *)t->d_idx_tag,
-                  (void *)t->d_idx_word, (void *)t->d_wstamp, (void *)t->d_wkey, (void *)t->d_seg_start, (void *)t->d_seg_of, (void *)t->d_pend,
+                  (void *)t->d_idx_word, (void *)t->d_wstamp, (void *)t->d_wkey, (void *)t->d_tied_idx, (void *)t->d_tied_key, (void *)t->d_gpos, (void *)t->d_seg_start, (void *)t->d_seg_of, (void *)t->d_pend,
                   (void *)t->d_tstamp, (void *)t->d_touched, (void *)t->d_block, (void *)t->d_blocks_all, (void *)t->d_tie_line,
                   (void *)t->d_tie_all, (void *)t->d_halt, (void *)t->K.keys, (void *)t->K.start, (void *)t->K.len, (void *)t->K.fill,
                   (void *)t->K.words})
@@ -1988,22 +2229,46 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
   uint32_t done = 0;
   bool exhausted = false;
   int dry_runs = 0;
+  double per_step = 1.0;  // merges a step of the fast path has carried lately: sizes the next round trip
   while (done < max_steps && !exhausted) {
-    uint32_t k = max_steps - done;
-    if (k > kRunBatch) k = kRunBatch;
-    // room for the whole batch (the symbol count grows by one per step, counts never grow)
-    const uint64_t by_sym = 2 * (t->n_base + t->n_applied + k + 1) + 1;
+    const uint32_t remaining = max_steps - done;
+    // One round trip: `steps` launch sequences that may log up to `cap` merges.  A step of the fast path carries one merge or
+    // several (fast_apply_kernel); every other path carries exactly one.
+    const bool maybe_fast = !t->d_sfreq && t->n_words;
+    uint32_t steps = remaining < kRunBatch ? remaining : kRunBatch;
+    uint32_t cap = steps;
+    if (maybe_fast) {
+      const double want = (double)remaining / per_step * 1.05 + 1.0;
+      if (want < (double)steps) steps = (uint32_t)want;
+      if (steps < 8) steps = remaining < 8 ? remaining : 8;
+      double c = (double)steps * per_step * 1.5 + 8.0;
+      if (c > (double)remaining) c = (double)remaining;
+      if (c > (double)kMaxRunSteps) c = (double)kMaxRunSteps;
+      cap = (uint32_t)c;
+      if (cap < steps) cap = steps;
+    }
+    // room for everything the round trip may create (the symbol count grows by one per merge, counts never grow)
+    const uint64_t by_sym = 2 * (t->n_base + t->n_applied + cap + 1) + 1;
     uint64_t per = new_pairs_bound(t, t->h_st.max_count);
     if (t->h_st.max_count == 0 || by_sym < per) per = by_sym;
-    if ((rc = ensure_room(t, per * k))) return rc;
-    if ((rc = ensure_steps(t, k, first_merged + done + k))) return rc;
+    if ((rc = ensure_room(t, per * cap))) return rc;
+    if ((rc = ensure_steps(t, steps, first_merged + done + cap))) return rc;
     if ((!t->cand_valid || (!t->theta && !t->d_sfreq) || t->h_st.n_cand > kCandHigh) && (rc = t->replan())) return rc;
+    const bool fast = t->theta && maybe_fast;
+    if (!fast) {
+      if (steps > remaining) steps = remaining;
+      cap = steps;
+    } else {
+      // the step counters of the fast path start from zero, and no position of an earlier round trip is left
+      SWT_HIP(hipMemsetAsync(&t->d_st->run_done[0], 0, 7 * 8, t->stream));
+      SWT_HIP(hipMemsetAsync(&t->d_st->best2[0], 0xFF, 2 * 8, t->stream));  // steps that did nothing may have left either parity behind
+      SWT_HIP(hipMemsetAsync(t->d_gpos, 0xFF, 2 * (size_t)t->cand_cap * 8, t->stream));
+    }
     prof_begin(t->stream);  // one bracket around the whole batch of merge steps: bench.py divides by the merges done
-    const bool fast = t->theta && !t->d_sfreq && t->n_words;
-    for (uint32_t i = 0; i < k; i++) {
+    for (uint32_t i = 0; i < steps; i++) {
       t->step_no++;
       if (fast) {
-        t->enqueue_fast_step(i, first_merged + done + i);
+        t->enqueue_fast_step(first_merged + done, cap);
         continue;
       }
       t->enqueue_argmax();
@@ -2013,26 +2278,40 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
     }
     prof_end(t->stream);
     SWT_HIP(hipGetLastError());
-    SWT_HIP(hipMemcpyAsync(hlog.data(), t->d_steplog, k * sizeof(StepLog), hipMemcpyDeviceToHost, t->stream));
+    SWT_HIP(hipMemcpyAsync(hlog.data(), t->d_steplog, cap * sizeof(StepLog), hipMemcpyDeviceToHost, t->stream));
     if ((rc = t->sync_state())) return rc;
     uint32_t good = 0;
-    while (good < k && hlog[good].flag == 0) {
-      left[done] = hlog[good].l;
-      right[done] = hlog[good].r;
-      count[done] = hlog[good].count;
-      t->trace.push_back(hlog[good]);
+    unsigned long long stop = 0;  // why the device stopped before `cap`: 0 (it did not), 2 no pair left, 3 re-plan
+    if (fast) {
+      const unsigned long long logged = t->h_st.run_done[(t->step_no + 1) & 1u];
+      if (logged > cap) return fail(SWT_ERR_STATE, "the step log overran its round trip");
+      good = (uint32_t)logged;
+      stop = t->h_st.halt;
+      for (uint32_t i = 0; i < good; i++)
+        if (hlog[i].flag != 0) return fail(SWT_ERR_STATE, "the step log has a hole");
+    } else {
+      while (good < cap && hlog[good].flag == 0) good++;
+      if (good < cap) stop = hlog[good].flag;
+    }
+    for (uint32_t i = 0; i < good; i++) {
+      left[done] = hlog[i].l;
+      right[done] = hlog[i].r;
+      count[done] = hlog[i].count;
+      t->trace.push_back(hlog[i]);
       done++;
-      good++;
     }
     t->n_applied += good;
     if (good && !t->d_sfreq) t->h_st.max_count = hlog[good - 1].count;  // counts never grow: bound for the next batch
-    if (good < k) {
-      if (hlog[good].flag == 3) {  // the candidate list ran dry: later steps of the batch were no-ops; new theta, go on
-        t->cand_valid = false;
-        if (!good && ++dry_runs > 64) return fail(SWT_ERR_STATE, "the candidate list cannot be rebuilt");
-      } else {
-        exhausted = true;  // bpe.py:98-99: no pair left
-      }
+    if (stop == 3) {  // the candidate list ran dry: later steps of the batch were no-ops; new theta, go on
+      t->cand_valid = false;
+      if (!good && ++dry_runs > 64) return fail(SWT_ERR_STATE, "the candidate list cannot be rebuilt");
+    } else if (stop) {
+      exhausted = true;  // bpe.py:98-99: no pair left
+    } else if (fast) {
+      // every step ran: what they carried; a round trip that filled its cap could have carried more
+      const double seen = (double)good / (double)steps;
+      per_step = good >= cap ? per_step * 1.5 : (seen < 1.0 ? 1.0 : seen);
+      if (per_step > (double)kMaxBatch) per_step = (double)kMaxBatch;
     }
     if (good) dry_runs = 0;
   }

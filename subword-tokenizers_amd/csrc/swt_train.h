@@ -7,7 +7,8 @@
 
 namespace swt {
 
-constexpr uint32_t kMaxRunSteps = 512;
+constexpr uint32_t kMaxRunSteps = 4096;  // rows of the step log = merges per host round trip
+constexpr uint32_t kMaxBatch = 8;        // merges ONE step of the fast path may carry: tied pairs that cannot affect each other
 constexpr uint32_t kRunBatch = 256;     // merges enqueued per host round trip
 constexpr uint32_t kArgParts = 256;     // workgroup partials of an argmax launch (combined by every consumer)
 constexpr uint32_t kCandBlocks = 32;    // cand_argmax_kernel
@@ -48,6 +49,12 @@ struct TrainState {
   unsigned long long n_synced_next;
   unsigned int cursor_w;         // the tie scan may start at this word
   unsigned int flags;
+  // fast path, reset by the host before every round trip
+  unsigned long long run_done[2];  // merges logged so far in this round trip, by step parity
+  unsigned long long halt;         // 0, 2 (no pair left), 3 (candidate list dry or lost: re-plan)
+  unsigned long long win_end;      // tie positions below this (word << 32) lie in the window EVERY workgroup scanned
+  unsigned long long n_list[2];    // length of tied_idx[] / tied_key[], by step parity
+  unsigned long long step_syms;    // live symbols when the step began (the tie launch notes it: no apply is in flight then)
 };
 
 struct StepCmd {
@@ -105,6 +112,9 @@ struct TrainCtx {
   uint32_t seg_cap, id_base;
   uint32_t *wstamp;
   unsigned long long *wkey;  // fast path: the tied pair a tie scan found in word w
+  uint32_t *tied_idx;        // fast path, [2][kTieSet]: candidate index of every tied pair | danger << 31 (see fast_tie_kernel)
+  unsigned long long *tied_key;  // their keys
+  unsigned long long *gpos;  // fast path, [2][cand_cap]: first position of a tied pair within the scanned words, by candidate index
   uint32_t step;
   long long *pend;         // sharded: per-slot pending deltas (nullptr: deltas go straight into cnt)
   uint32_t *tstamp, *touched;
@@ -150,6 +160,8 @@ struct swt_bpe_trainer {
   // index
   uint32_t *d_idx_tag = nullptr, *d_idx_word = nullptr, *d_wstamp = nullptr;
   unsigned long long *d_wkey = nullptr;
+  uint32_t *d_tied_idx = nullptr;
+  unsigned long long *d_tied_key = nullptr, *d_gpos = nullptr;
   uint64_t idx_cap = 0;
   unsigned long long *d_seg_start = nullptr;
   uint64_t seg_start_cap = 0;
@@ -172,7 +184,7 @@ struct swt_bpe_trainer {
   int replan();
   void enqueue_argmax();
   void enqueue_apply();
-  void enqueue_fast_step(uint32_t log_i, uint32_t merged);
+  void enqueue_fast_step(uint32_t first_merged, uint32_t limit);
 };
 
 namespace swt {

@@ -642,6 +642,46 @@ def test_train_config3_shape_words_with_frequencies(dev, oracle):
     tr.close()
 
 
+def test_train_plateaus_many_merges_per_step(dev, oracle):
+    """The fast path merges SEVERAL tied pairs per step when they cannot affect each other (csrc/swt_bpe_train.hip,
+    fast_apply_kernel); the reference takes them one at a time (bpe.py:88-111).  Small alphabets and flat frequencies make wide
+    plateaus, shared symbols, twins and chains (the new pair of one merge tying with the rest): pairs, counts, their order and
+    the final stream must be the oracle's, also when the merges are asked for in small, odd slices."""
+    rng = np.random.default_rng(20260104)
+    shapes = [(4, 3000, 2, 9, 1, 400), (8, 6000, 2, 12, 1, 700), (26, 20000, 1, 10, 1, 900), (6, 5000, 3, 7, 3, 500),
+              (3, 800, 4, 16, 2, 300), (12, 50000, 2, 8, 1, 600)]
+    for alpha, n_words, lo, hi, fmax, n_merges in shapes:
+        lens = rng.integers(lo, hi + 1, size=n_words)
+        off = np.zeros(n_words + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(lens)
+        sym = (97 + rng.integers(0, alpha, size=int(off[-1]))).astype(np.uint32)
+        freq = rng.integers(1, fmax + 1, size=n_words).astype(np.uint32)
+        orc = oracle.OracleBPETrainer.from_words(sym, off, freq)
+        orc.run(10 ** 9, n_merges)
+        ids, cnt = orc.merge_ids()
+        for slices in (None, (1, 2, 7, 64, 5, 300)):
+            tr = dev.BpeTrainer.from_words(sym, off, freq)
+            ls, rs, cs = [], [], []
+            i = 0
+            while len(ls) < len(ids):
+                ask = len(ids) - len(ls) if slices is None else min(slices[i % len(slices)], len(ids) - len(ls))
+                l, r, c = tr.run(ask, dev.SYM_BASE + len(ls))
+                assert len(l) == ask, (alpha, n_words, len(ls), ask, len(l))
+                ls += l.tolist(); rs += r.tolist(); cs += c.tolist()
+                i += 1
+            got = np.stack([np.asarray(ls, dtype=np.uint32), np.asarray(rs, dtype=np.uint32)], axis=1)
+            bad = np.nonzero((got != ids[:, :2]).any(axis=1))[0]
+            assert bad.size == 0, (alpha, n_words, slices, int(bad[0]), got[bad[0]].tolist(), ids[bad[0]].tolist())
+            assert np.array_equal(np.asarray(cs, dtype=np.uint64), cnt)
+            gs, go, gf = tr.export()
+            ws, wo, wf = orc.export()
+            assert np.array_equal(go, wo) and np.array_equal(gs, ws)
+            # the merges of one step log the same live-symbol count (the step's), and every step removes symbols
+            carried = len(ids) / max(1, len(np.unique(tr.step_trace()[:, 3])))
+            tr.close()
+            assert carried > 1.2, "the steps carried %.2f merges each: the plateaus were not batched" % carried
+
+
 def _wp_order_cases(golden, ref_dir):
     import json
     for c in golden("wp_train_order.json"):
