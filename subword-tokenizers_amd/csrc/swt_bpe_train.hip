@@ -534,6 +534,9 @@ __device__ unsigned long long g_span[4][kSpanSteps];  // tie first start, tie la
 __device__ unsigned long long g_phase[3][16];  // [2]: apply launch, every flushing lane of steps 1..64 (the big merges)
 //        // [0] tie launch, workgroup 0; [1] apply launch, per step the first lane done flushing; [.][15] = samples
 __device__ unsigned int g_reported[kSpanSteps];
+__device__ unsigned long long g_pmax[6][kSpanSteps];  // per step: latest apply_body entry (absolute), then the longest of each of its 5 phases over the lanes
+__device__ unsigned int g_kstep[kSpanSteps];  // merges the step carried
+__device__ unsigned long long g_why[32];  // fast_apply_kernel, tied steps: [K] steps that merged K pairs; [16 + reason] why the batch ended
 struct StampSpan {
   int k; uint32_t step;
   __device__ StampSpan(int k_, uint32_t step_) : k(k_), step(step_ & (kSpanSteps - 1)) {
@@ -548,14 +551,17 @@ __device__ __forceinline__ unsigned long long stamp_now() {
   return __builtin_amdgcn_s_memrealtime();
 }
 #define SWT_SPAN(k, step) StampSpan span_((k), (step))
+#define SWT_COUNT(i) do { if (C.step > 1000) atomicAdd(&g_why[(i)], 1ull); } while (0)
 #define SWT_STAMP(arr, i) (arr)[(i)] = stamp_now()
 #else
 #define SWT_SPAN(k, step) do { } while (0)
+#define SWT_COUNT(i) do { } while (0)
 #define SWT_STAMP(arr, i) do { } while (0)
 #endif
 
-constexpr int kEmitCap = 12;
+constexpr int kEmitCap = 10;
 constexpr int kStage = 24;      // stream slots of a word staged in LDS before its walk
+constexpr int kEntryFan = 8;   // index entries a lane looks at per trip of an apply launch
 constexpr int kFlushBatch = 8;  // parked deltas whose table probes go out together
 constexpr unsigned long long kEmitNew = 1ull << 63;  // symbol ids stay below 2^31, so bit 63 of a pair key is free
 
@@ -608,17 +614,31 @@ __device__ __forceinline__ void index_entry(const TrainCtx &C, uint64_t at, unsi
 // walk one claimed word: rewrite in place, park the deltas.  Returns merges done; n_parked / n_new_parked by reference.
 // Deltas beyond kEmitCap are applied on the spot (a new pair then takes its index entry with an atomic of its own).
 // `stage` holds the word's first kStage stream slots as they were before the walk (one LDS column per lane, loaded in one go:
-// the walk never reads a slot again after writing it, so the copy stays good); slots beyond come from the stream.
+// the walk never reads a slot again after writing it, so the copy stays good).
 // L / R are the plan's pairs in registers.  With one pair its own delta is NOT parked: the caller sends it once per wave
 // (every lane of a big merge has it); a batch parks it like any other.
 __device__ __forceinline__ uint32_t walk_word(uint32_t *__restrict__ sym, uint64_t b0, uint64_t b1, const uint32_t (&L)[kMaxBatch],
                                               const uint32_t (&R)[kMaxBatch], uint32_t K, uint32_t first_m, long long f, const TrainCtx &C,
-                                              uint32_t w, const uint32_t *stage, unsigned long long *park, int &n_park, int &n_new) {
+                                              uint32_t w, uint32_t *stage, unsigned long long *park, int &n_park, int &n_new) {
   uint32_t n_merged = 0;
   uint32_t po = 0, pn = 0;  // previous old / new symbol
   bool po_cov = false, pn_new = false, have = false;
   uint64_t i = b0;
-#define SYM(i_) (((i_) - b0) < (uint64_t)kStage ? stage[((i_) - b0) * kTrainThreads] : sym[(i_)])
+  // the staged window [sb, sb + kStage): reads only move forward, and everything at or behind a read position is still as it
+  // was (the walk writes behind itself), so a word longer than the window refills it there -- one round trip per kStage slots
+  uint64_t sb = b0;
+  auto sym_at = [&](uint64_t at) -> uint32_t {
+    if (at - sb >= (uint64_t)kStage) {
+      sb = at;
+      uint32_t pre[kStage];
+#pragma unroll
+      for (int u = 0; u < kStage; u++) pre[u] = sb + u < b1 ? sym[sb + u] : kHole;
+#pragma unroll
+      for (int u = 0; u < kStage; u++) stage[u * kTrainThreads] = pre[u];
+    }
+    return stage[(at - sb) * kTrainThreads];
+  };
+#define SYM(i_) sym_at(i_)
   while (i < b1 && SYM(i) == kHole) i++;
 #define EMIT(a_, b_, new_)                                                                   \
   do {                                                                                       \
@@ -627,6 +647,7 @@ __device__ __forceinline__ uint32_t walk_word(uint32_t *__restrict__ sym, uint64
       park[(n_park++) * kTrainThreads] = key_ | ((new_) ? kEmitNew : 0ull);                  \
       n_new += (new_) ? 1 : 0;                                                               \
     } else {                                                                                 \
+      SWT_COUNT(27);                                                                         \
       table_add(C, key_, (new_) ? f : -f);                                                   \
       if (new_) index_entry(C, atomicAdd(&C.st->idx_cursor, 1ull), key_, first_m, K, w);     \
     }                                                                                        \
@@ -671,10 +692,13 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
                                            uint64_t n_words, const TrainCtx &C, const BatchPlan &P) {
   __shared__ unsigned long long park_s[kTrainThreads * kEmitCap];  // [delta][lane]: a wave's lanes sit side by side
   __shared__ uint32_t stage_s[kTrainThreads * kStage];             // [slot][lane]
+  __shared__ uint32_t queue_s[kTrainThreads / 64][64 * kEntryFan];  // per wave: the words it found in a trip's entries
   unsigned long long *park = park_s + threadIdx.x;
   uint32_t *stage = stage_s + threadIdx.x;
+  uint32_t *queue = queue_s[threadIdx.x >> 6];
   TrainState *st = C.st;
   const int lane = threadIdx.x & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
 #ifdef SWT_STAMPS
   unsigned long long ts[8];
 #endif
@@ -685,23 +709,48 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
   for (int u = 0; u < (int)kMaxBatch; u++) { L[u] = P.l[u]; R[u] = P.r[u]; }
   const bool whole = (st->flags & kFlagIndexBroken) != 0;  // every word (only after a symbol id was reused: never on trained tables)
   const uint64_t n_ent = whole ? n_words : P.ent0[K];
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  // A log segment lists every pair its step made, and a lane keeps the entries of ITS pairs (by tag): of a segment born early
+  // in training that is one in hundreds.  So a lane looks at kEntryFan entries per trip -- all their loads in flight together
+  // -- the wave packs the matches into a queue (ballots), and goes through it 64 at a time (sparse matches: one round; a list
+  // without tags, where everything matches: kEntryFan rounds, the trips it would have made anyway).
+  // (A lane's entries lie a whole grid apart, as the trips did: neighbours in a list stay with neighbouring lanes, so a dense
+  // list still spreads over the launch.)
+  const uint64_t lanes = (uint64_t)gridDim.x * blockDim.x, stride = lanes * kEntryFan;
   unsigned long long removed = 0, self_delta = 0, inserted = 0;
   uint32_t min_w = 0xFFFFFFFFu;
   for (uint64_t e0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; e0 < n_ent; e0 += stride) {
-    const uint64_t e = e0 + lane;
-    uint32_t w = 0xFFFFFFFFu;
-    if (e < n_ent) {
-      if (whole) {
-        w = (uint32_t)e;
-      } else {
-        uint32_t q = 0;
-        while (q + 1 < K && e >= P.ent0[q + 1]) q++;
-        const uint64_t at = e - P.ent0[q];
-        const uint32_t we = P.list[q][at];  // both loads go out together
-        if (!P.tags[q] || P.tags[q][at] == P.want[q]) w = we;
+    int n_q = 0;  // the wave's matches of this trip, packed into its queue in entry order
+    {
+      uint32_t we[kEntryFan], tg[kEntryFan], wt[kEntryFan];
+#pragma unroll
+      for (int u = 0; u < kEntryFan; u++) {
+        const uint64_t e = e0 + (uint64_t)lane + (uint64_t)u * lanes;
+        we[u] = 0xFFFFFFFFu;
+        tg[u] = 0;
+        wt[u] = 0;
+        if (e < n_ent) {
+          if (whole) {
+            we[u] = (uint32_t)e;
+          } else {
+            uint32_t q = 0;
+            while (q + 1 < K && e >= P.ent0[q + 1]) q++;
+            const uint64_t at = e - P.ent0[q];
+            we[u] = P.list[q][at];  // both loads go out together
+            if (P.tags[q]) { tg[u] = P.tags[q][at]; wt[u] = P.want[q]; }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kEntryFan; u++) {
+        const bool match = we[u] != 0xFFFFFFFFu && tg[u] == wt[u];
+        const unsigned long long mm = __ballot(match);
+        if (match) queue[n_q + __popcll(mm & lt)] = we[u];
+        n_q += __popcll(mm);
       }
     }
+   for (int round = 0; round * 64 < n_q; round++) {
+    const int qi = round * 64 + lane;
+    uint32_t w = qi < n_q ? queue[qi] : 0xFFFFFFFFu;
     int n_park = 0, n_new = 0;
     SWT_STAMP(ts, 1);
     if (w != 0xFFFFFFFFu) {
@@ -744,20 +793,36 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
     base = __shfl(base, 0);
     SWT_STAMP(ts, 4);
     if (w != 0xFFFFFFFFu && n_park) {
+      SWT_COUNT(28);
+      if (n_park > kFlushBatch) SWT_COUNT(26);
       const long long f = freq[w];  // L1: loaded a moment ago
       uint64_t at = base + x - (uint32_t)n_new;
       for (int j0 = 0; j0 < n_park; j0 += kFlushBatch) {
         // three rounds, each with all its memory operations in flight together: probe, add, follow up
-        unsigned long long key[kFlushBatch], seen[kFlushBatch];
+        unsigned long long key[kFlushBatch], seen[kFlushBatch], seen2[kFlushBatch];
         long long was[kFlushBatch];
-        uint32_t h[kFlushBatch], ci[kFlushBatch];
+        uint32_t h[kFlushBatch], ci[kFlushBatch], ci2[kFlushBatch];
+        const uint32_t tmask = (uint32_t)((1ull << C.T.bits) - 1ull);
 #pragma unroll
         for (int u = 0; u < kFlushBatch; u++) {
+          // the home slot AND the one behind it (linear probing: most keys that are not at home are there)
           const bool on = j0 + u < n_park;
           key[u] = on ? park[(j0 + u) * kTrainThreads] : 0ull;
           h[u] = slot_hint(C.T, key[u] & ~kEmitNew);
+          const uint32_t h2 = (h[u] + 1) & tmask;
           seen[u] = on ? C.T.keys[h[u]] : 0ull;
+          seen2[u] = on ? C.T.keys[h2] : 0ull;
           ci[u] = on && C.cidx ? C.cidx[h[u]] : 0xFFFFFFFFu;
+          ci2[u] = on && C.cidx ? C.cidx[h2] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < kFlushBatch; u++) {
+          const unsigned long long k = key[u] & ~kEmitNew;
+          if (j0 + u < n_park && seen[u] != k && seen[u] != kEmptyKey && (seen2[u] == k || seen2[u] == kEmptyKey)) {
+            h[u] = (h[u] + 1) & tmask;  // home is taken by another key: this pair is, or goes, one slot on
+            seen[u] = seen2[u];
+            ci[u] = ci2[u];
+          }
         }
         // a pair the merge has just made is usually not in the table: its home slot is taken here, all of them at once
         unsigned long long got[kFlushBatch];
@@ -817,6 +882,10 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
         atomicAdd(&g_phase[1][9], (unsigned long long)n_new);
         atomicAdd(&g_phase[1][15], 1ull);
       }
+      if (e0 < stride) {
+        atomicMax(&g_pmax[0][C.step & (kSpanSteps - 1)], ts[0]);
+        for (int q = 0; q < 5; q++) atomicMax(&g_pmax[1 + q][C.step & (kSpanSteps - 1)], ts[q + 1] - ts[q]);
+      }
       if (C.step <= 64) {
         for (int q = 0; q < 5; q++) atomicAdd(&g_phase[2][q], ts[q + 1] - ts[q]);
         atomicAdd(&g_phase[2][8], (unsigned long long)n_park);
@@ -825,6 +894,7 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
       }
 #endif
     }
+   }
   }
   for (int d = 32; d >= 1; d >>= 1) {
     removed += __shfl_xor(removed, d);
@@ -890,7 +960,7 @@ struct BlockArg {
 };
 
 #ifndef SWT_TIE_WORDS
-#define SWT_TIE_WORDS 8
+#define SWT_TIE_WORDS 16
 #endif
 constexpr int kTieWords = SWT_TIE_WORDS;  // words a wave scans per trip of the tie scan: 16 lanes per word, 4 words at a time
 constexpr int kTieStage = 8;              // coalesced loads per lane that stage those words (512 stream slots; beyond: the stream)
@@ -1336,27 +1406,46 @@ __global__ __launch_bounds__(kTrainThreads) void fast_apply_kernel(uint32_t *__r
       if (rank < kMaxBatch) ord[rank] = threadIdx.x;
     }
     __syncthreads();
-    if (threadIdx.x == 0 && nf) {
-      // the longest prefix whose members share no symbol, up to and including the first dangerous one (see above)
-      const unsigned long long room = (unsigned long long)limit - run_done;
-      uint32_t K = 0;
-      for (unsigned int rk = 0; rk < nf && rk < kMaxBatch; rk++) {
+    if (threadIdx.x < 64 && nf) {
+      // the longest prefix whose members share no symbol, up to and including the first dangerous one (see above): the first
+      // wave holds one candidate per lane, in order, and settles it with shuffles and ballots
+      const unsigned int nsel = nf < kMaxBatch ? nf : kMaxBatch;
+      const unsigned int rk = threadIdx.x;
+      uint32_t a = kHole, b = kHole, dng = 0;
+      unsigned long long pos = kEmptyKey;
+      if (rk < nsel) {
         const unsigned int e = ord[rk];
-        const uint32_t a = (uint32_t)(f_key[e] >> 32), b = (uint32_t)f_key[e];
-        if (K) {
-          if (f_pos[e] >= win_end) break;  // not every workgroup scanned that far
-          bool clash = false;
-          for (uint32_t q = 0; q < K; q++) clash |= a == P.l[q] || a == P.r[q] || b == P.l[q] || b == P.r[q];
-          if (clash) break;
-        } else {
-          p1_pos = f_pos[e];
-        }
-        P.l[K] = a;
-        P.r[K] = b;
-        K++;
-        if (f_dng[e] || K >= room) break;
+        a = (uint32_t)(f_key[e] >> 32);
+        b = (uint32_t)f_key[e];
+        pos = f_pos[e];
+        dng = f_dng[e];
       }
-      P.K = K;
+      bool clash = false;  // with any pair before it (were one of those left out, the prefix would end there anyway)
+#pragma unroll
+      for (int jj = 0; jj < (int)kMaxBatch; jj++) {
+        const uint32_t aj = __shfl(a, jj), bj = __shfl(b, jj);
+        if ((unsigned int)jj < rk && rk < nsel) clash |= a == aj || a == bj || b == aj || b == bj;
+      }
+      const bool far = rk > 0 && rk < nsel && pos >= win_end;  // not every workgroup scanned that far
+      const unsigned long long m_clash = __ballot(clash), m_far = __ballot(far), m_dng = __ballot(dng != 0 && rk < nsel);
+      const unsigned long long room = (unsigned long long)limit - run_done;
+      uint32_t K = nsel;
+      int why = nf > kMaxBatch ? 5 : 0;  // 0: every pair seen is in, 1 beyond the window, 2 shared symbol, 3 dangerous, 4 the round trip's cap, 5 kMaxBatch
+      if (m_far && (uint32_t)__builtin_ctzll(m_far) < K) { K = (uint32_t)__builtin_ctzll(m_far); why = 1; }
+      if (m_clash && (uint32_t)__builtin_ctzll(m_clash) < K) { K = (uint32_t)__builtin_ctzll(m_clash); why = 2; }
+      if (m_dng && (uint32_t)__builtin_ctzll(m_dng) + 1 < K) { K = (uint32_t)__builtin_ctzll(m_dng) + 1; why = 3; }
+      else if (m_dng && (uint32_t)__builtin_ctzll(m_dng) + 1 == K) why = 3;
+      if ((unsigned long long)K > room) { K = (uint32_t)room; why = 4; }
+      if (rk < K) { P.l[rk] = a; P.r[rk] = b; }
+      if (rk == 0) {
+        P.K = K;
+        p1_pos = pos;
+#ifdef SWT_STAMPS
+        if (blockIdx.x == 0) { atomicAdd(&g_why[K], 1ull); atomicAdd(&g_why[16 + why], 1ull); atomicAdd(&g_why[24], (unsigned long long)nf); atomicAdd(&g_why[25], n_list); }
+#else
+        (void)why;
+#endif
+      }
     }
   } else if (threadIdx.x == 0 && mx) {
     unsigned long long key = st->best_key;
@@ -1379,6 +1468,9 @@ __global__ __launch_bounds__(kTrainThreads) void fast_apply_kernel(uint32_t *__r
     P.ent0[0] = 0;
     for (uint32_t q = 0; q < K; q++) P.ent0[q + 1] = (flags & kFlagIndexBroken) ? 0ull : P.ent0[q] + P.ent0[q + 1];
   }
+#ifdef SWT_STAMPS
+  if (lead) g_kstep[C.step & (kSpanSteps - 1)] = K;
+#endif
   if (lead) {
     const unsigned long long pos = p1_pos;
     st->res_pos = pos;
@@ -1389,21 +1481,21 @@ __global__ __launch_bounds__(kTrainThreads) void fast_apply_kernel(uint32_t *__r
     // valid lower bound (the first member's first word is the first word this step touches)
     if (tied >= 2 && pos != kEmptyKey) { st->plateau = mx; st->cursor_w = (uint32_t)(pos >> 32); }
     else if (st->plateau != mx) { st->plateau = mx; st->cursor_w = 0; }
-    const unsigned long long n_syms = st->step_syms, n_cand = st->n_cand;
-    for (uint32_t q = 0; q < K; q++) {
-      const uint32_t merged = P.first_m + q;
-      if (merged >= C.id_base && merged - C.id_base < C.seg_cap && C.seg_of[merged - C.id_base] == 0) C.seg_of[merged - C.id_base] = C.step;
-      else atomicOr(&st->flags, kFlagBrokenPending);  // the next step's tie launch turns it into kFlagIndexBroken
-      StepLog &row = log[run_done + q];
-      row.l = P.l[q];
-      row.r = P.r[q];
-      row.count = mx;
-      row.flag = 0ull;
-      row.n_syms = n_syms;  // of the step: the members after the first saw a few symbols less
-      row.n_tied = tied;
-      row.n_cand = n_cand;
-    }
     st->run_done[par ^ 1u] = run_done + K;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < K) {  // one lane per member: its birth step, its log line
+    const uint32_t q = threadIdx.x, merged = P.first_m + q;
+    const unsigned long long n_syms = st->step_syms, n_cand = st->n_cand;
+    if (merged >= C.id_base && merged - C.id_base < C.seg_cap && C.seg_of[merged - C.id_base] == 0) C.seg_of[merged - C.id_base] = C.step;
+    else atomicOr(&st->flags, kFlagBrokenPending);  // the next step's tie launch turns it into kFlagIndexBroken
+    StepLog &row = log[run_done + q];
+    row.l = P.l[q];
+    row.r = P.r[q];
+    row.count = mx;
+    row.flag = 0ull;
+    row.n_syms = n_syms;  // of the step: the members after the first saw a few symbols less
+    row.n_tied = tied;
+    row.n_cand = n_cand;
   }
   __syncthreads();
   apply_body(sym, woff, freq, n_words, C, P);
@@ -1996,19 +2088,26 @@ void swt_bpe_trainer::enqueue_apply() {
 }
 
 #ifdef SWT_STAMPS
-// diagnostic builds only (not in include/swt.h): read = 0 resets the stamps, 1 copies spans (4 * 16384) then phases (3 * 16)
+// diagnostic builds only (not in include/swt.h): read = 0 resets the stamps, 1 copies spans (4 * 16384) then phases (3 * 16), then g_why (32)
 extern "C" int swt_debug_stamps(int read, unsigned long long *out) {
   if (!read) {
     static unsigned long long init[4][kSpanSteps];
     for (uint32_t i = 0; i < kSpanSteps; i++) { init[0][i] = ~0ull; init[1][i] = 0; init[2][i] = ~0ull; init[3][i] = 0; }
     static unsigned long long zero[3][16];
     static unsigned int zero_r[kSpanSteps];
+    static unsigned long long zero_w[32];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_why), zero_w, sizeof zero_w) != hipSuccess) return -4;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_kstep), zero_r, sizeof zero_r) != hipSuccess) return -4;
+    { void *pm = nullptr; if (hipGetSymbolAddress(&pm, HIP_SYMBOL(g_pmax)) != hipSuccess || hipMemset(pm, 0, sizeof g_pmax) != hipSuccess) return -4; }
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_span), init, sizeof init) != hipSuccess) return -4;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_reported), zero_r, sizeof zero_r) != hipSuccess) return -4;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_phase), zero, sizeof zero) == hipSuccess ? 0 : -4;
   }
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 4 * kSpanSteps) != hipSuccess) return -4;
-  return hipMemcpyFromSymbol(out + 4 * kSpanSteps, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 48) == hipSuccess ? 0 : -4;
+  if (hipMemcpyFromSymbol(out + 4 * kSpanSteps, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 48) != hipSuccess) return -4;
+  if (hipMemcpyFromSymbol(out + 4 * kSpanSteps + 48, HIP_SYMBOL(g_why), sizeof(unsigned long long) * 32) != hipSuccess) return -4;
+  if (hipMemcpyFromSymbol(out + 4 * kSpanSteps + 80, HIP_SYMBOL(g_kstep), sizeof(unsigned int) * kSpanSteps) != hipSuccess) return -4;
+  return hipMemcpyFromSymbol(out + 4 * kSpanSteps + 80 + kSpanSteps / 2, HIP_SYMBOL(g_pmax), sizeof g_pmax) == hipSuccess ? 0 : -4;
 }
 #endif
 

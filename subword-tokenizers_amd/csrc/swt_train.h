@@ -18,7 +18,7 @@ constexpr uint32_t kCandHigh = 2048;    // re-plan at a batch boundary once push
 constexpr uint32_t kCandCap = 8192;     // room for the pairs that cross theta afterwards
 constexpr uint32_t kTieSet = 256;       // tied pairs a workgroup keeps in its LDS set (more: membership by table probe)
 #ifndef SWT_TIE_BLOCKS
-#define SWT_TIE_BLOCKS 128
+#define SWT_TIE_BLOCKS 256
 #endif
 constexpr uint32_t kTieBlocks = SWT_TIE_BLOCKS;
 constexpr uint32_t kApplyBlocks = 512;

@@ -18,10 +18,13 @@ tok = tokenizers.FastBPE()
 t0 = time.time(); tok.train(sents, 8000); wall = time.time() - t0
 tr = tok._trainer.step_trace()
 n = len(tr)
-out = np.zeros(4 * 16384 + 48, dtype=np.uint64)
+out = np.zeros(4 * 16384 + 80 + 8192 + 6 * 16384, dtype=np.uint64)
 assert fn(1, out.ctypes.data) == 0
 span = out[:4 * 16384].reshape(4, 16384).astype(np.float64) / 100.0  # us (100 MHz)
-ph = out[4 * 16384:].reshape(3, 16).astype(np.float64)
+ph = out[4 * 16384:4 * 16384 + 48].reshape(3, 16)
+why = out[4 * 16384 + 48:4 * 16384 + 80].astype(np.int64)
+kstep = out[4 * 16384 + 80:4 * 16384 + 80 + 8192].view(np.uint32)
+pmax = out[4 * 16384 + 80 + 8192:].reshape(6, 16384).astype(np.float64) / 100.0
 print("merges", n, "wall s", round(wall, 3), "us/merge", round(wall / n * 1e6, 2))
 n_steps = int(tok._trainer.stats()["steps"])
 steps = np.arange(1, n_steps + 1) & 16383  # step numbers start at 1; a batch's steps after a re-plan request are no-ops
@@ -59,3 +62,23 @@ for i in range(0, 12):
     print("  merge %d: count %d, %d merges in unique words, apply span %.1f us -> %.1f merges/us" % (i, tr[i, 0], ns[i] - ns[i + 1], app[i], (ns[i] - ns[i + 1]) / app[i]))
 print("tied > 1: %.3f  > 256: %.3f  > 1024: %.3f of the merges; candidates mean %.0f" % (
     (tr[:, 1] > 1).mean(), (tr[:, 1] > 256).mean(), (tr[:, 1] > 1024).mean(), tr[:, 2].mean()))
+
+tot = max(1, int(why[:16].sum()))
+print("tied steps by merges carried:", why[1:9].tolist(), " mean %.2f" % (sum(k * int(why[k]) for k in range(16)) / tot))
+print("why a batch ended: all seen pairs in %d, beyond the window %d, shared symbol %d, dangerous %d, round-trip cap %d, kMaxBatch %d;  pairs seen per step %.1f of %.1f tied" % (
+    tuple(int(x) for x in why[16:22]) + (why[24] / tot, why[25] / tot)))
+
+ks = kstep[steps]
+for k in range(0, 9):
+    sel = seen & (ks == k) & (np.arange(len(steps)) > 1000)
+    if sel.any():
+        print("  steps past 1000 that carried %d merges: %5d  tie span %.1f  apply span %.1f us" % (k, int(sel.sum()), tie[sel].mean(), app[sel].mean()))
+
+print("past step 1000: lanes that flushed %d, with more than 8 deltas %d, deltas that did not fit the park (applied one by one) %d" % (int(why[28]), int(why[26]), int(why[27])))
+
+entry = pmax[0][steps] - span[2][steps]   # kernel start -> the last lane to enter apply_body (of the lanes that flushed)
+for k in range(1, 9):
+    sel = seen & (ks == k) & (np.arange(len(steps)) > 1000) & (pmax[0][steps] > 0)
+    if sel.any():
+        print("  K=%d: slowest lane per phase: prologue %.1f | entries %.1f  bounds+claim+stage %.1f  walk %.1f  reserve %.1f  flush %.1f us" % (
+            (k, entry[sel].mean()) + tuple(pmax[1 + q][steps][sel].mean() for q in range(5))))
