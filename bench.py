@@ -222,6 +222,48 @@ def encode_corpus_bench(args, torch, dist, rank, N, bpe, sents, merges, name, cp
     return res
 
 
+def train_roofline(trace, stats, n0, w0, n_final, n_merges, per_merge_s, launches, rescan, world=1, whole_table=False, traffic=None):
+    """Bytes THIS implementation must move per merge, from the run's own counters:
+      the argmax's input once per step: the candidate list (count + key, 16 B each) -- or the whole pair table for WordPiece,
+        whose score has no monotone bound to list candidates by;
+      the words of the tie scan's window (4 B per stream slot, holes included, + 8 B of bounds per word), on tied steps;
+      the index entries an apply goes through (word id + tag, 8 B);
+      per merged occurrence ~360 B: its word (entry, bounds, frequency, claim stamp, 24 staged slots, 2 slot writes = 140 B)
+        and five histogram deltas (key probe, count read-modify-write, mirror index + mirror count = 44 B each).
+    The reference formulation (a full recount per merge, `rescan` bytes) is what the design avoids moving: the
+    merge time against THOSE bytes is an effective rate (it passes the HBM peak on configs[3]) and is reported as such, never
+    as the fraction."""
+    occurrences = n0 - n_final
+    slot_bytes = 4.0 * n0 / max(w0, 1) + 8.0
+    if trace is not None and len(trace) and stats is not None:
+        step_rows = np.unique(trace[:, 3], return_index=True)[1]  # the merges of one step log the same live-symbol count
+        n_steps = int(step_rows.size)
+        cand_bytes = 16.0 * (float(stats["table_slots"]) * n_steps if whole_table else float(trace[step_rows, 2].sum()))
+        tied_steps = float((trace[step_rows, 1] > 1).sum())
+        # the fast path counts the words its windows covered; the other paths scan from the plateau cursor to the first hit
+        # (bounded here by the whole stream)
+        tie_bytes = slot_bytes * float(stats["tie_words"]) if stats["tie_words"] else (4.0 * n0 + 8.0 * w0) * tied_steps
+        idx_bytes = 8.0 * float(stats["entries_scanned"])
+    else:  # sharded: rank 0's upper bound (every step tied, its whole shard scanned)
+        n_steps = n_merges
+        cand_bytes = 16.0 * 2048 * n_merges
+        tie_bytes = (4.0 * n0 + 8.0 * w0) / world * n_merges
+        idx_bytes = 8.0 * float((stats or {}).get("entries_scanned", 0))
+    algo = (cand_bytes + tie_bytes + idx_bytes + 360.0 * occurrences) / max(n_merges, 1)
+    achieved = algo / per_merge_s / 1e9 if per_merge_s else 0.0
+    return check_frac({
+        "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+        "traffic": traffic, "kernel": "one merge, all of its kernels (the launches of a step, shared by the merges it carries)",
+        "kernel_us": round(per_merge_s * 1e6, 2), "algorithmic_bytes_per_launch": int(algo), "launches_timed": int(launches),
+        "steps": n_steps, "merges_per_step": round(n_merges / max(n_steps, 1), 2),
+        "bytes_model": {"argmax_input": int(cand_bytes / max(n_merges, 1)), "tie_window": int(tie_bytes / max(n_merges, 1)),
+                        "index_entries": int(idx_bytes / max(n_merges, 1)), "occurrences": int(360.0 * occurrences / max(n_merges, 1))},
+        "rescan_formulation": {"bytes_per_merge": int(rescan), "effective_gbs": round(rescan / per_merge_s / 1e9, 1) if per_merge_s else 0.0},
+        "note": "bytes = what the incremental design must move per merge (bench.py train_roofline); the path is bound by dependent "
+                "round trips (~0.7 us each, about a dozen per launch), not by bandwidth.  rescan_formulation = the reference's "
+                "full recount per merge: an effective rate, not traffic"})
+
+
 def train_bench(args, torch, dist, rank, world, N, sents, max_vocab, name, repeats=2, cpu_sample=200):
     """FastBPE.train (bpe.py:50-112) of `sents` to max_vocab: wall seconds per 1,000 merges over the whole call (host lower +
     pack, H2D, device split/Counter/histogram, the merge loop), the merge loop's device time per merge (HIP events around every
@@ -229,7 +271,7 @@ def train_bench(args, torch, dist, rank, world, N, sents, max_vocab, name, repea
     from subword_tokenizers_amd import tokenizers
 
     times, loops = [], []
-    merges, info, trace = [], {}, None
+    merges, info, trace, stats = [], {}, None, None
     for it in range(1 + repeats):  # first pass = warm-up (allocations, code objects)
         N.profile_enable(True)
         N.profile_read()
@@ -240,7 +282,8 @@ def train_bench(args, torch, dist, rank, world, N, sents, max_vocab, name, repea
             tok.train(sents, max_vocab)
             merges = list(tok.merges_list)
             info = tok._trainer.info()
-            trace = tok._trainer.step_trace() if hasattr(tok._trainer, "step_trace") else None
+            trace = tok._trainer.step_trace()
+            stats = tok._trainer.stats()
             tok.reset()
         else:
             from subword_tokenizers_amd.distributed import train_sharded
@@ -266,19 +309,11 @@ def train_bench(args, torch, dist, rank, world, N, sents, max_vocab, name, repea
     if orc.merges_list != merges[:cpu_sample]:
         raise SystemExit("PARITY FAILURE: device merges differ from the oracle on the first %d merges (%s)" % (cpu_sample, name))
     n_final = int(info["n_symbols"])
-    # reference formulation: 12 N_t + 8 W bytes per merge; N_t falls from N_0 to N_final (trapezoid), and the
-    # time is that of the WHOLE merge step (every kernel of it), so the fraction is an effective bandwidth and cannot pass 1
-    algo = 12.0 * (n0 + n_final) / 2.0 + 8.0 * w0
     loop_s = sum(loops) / len(loops)
     per_merge_s = loop_s / n_merges
-    achieved = algo / per_merge_s / 1e9 if per_merge_s else 0.0
     wall = sum(times) / len(times)
-    roof = check_frac({
-        "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-        "traffic": traffic_from_profile("bpe_train"), "kernel": "one merge step, all of its kernels (argmax, tie-break, apply)",
-        "kernel_us": round(per_merge_s * 1e6, 2), "algorithmic_bytes_per_launch": int(algo), "launches_timed": int(n_merges * len(loops)),
-        "note": "algorithmic bytes are the reference's full-rescan formulation (12 N_t + 8 W, N_t averaged over the run); the "
-                "incremental design moves far fewer, so this is an effective rate, not HBM traffic"})
+    roof = train_roofline(trace, stats if stats is not None else info, n0, w0, n_final, n_merges, per_merge_s, n_merges * len(loops),
+                          12.0 * (n0 + n_final) / 2.0 + 8.0 * w0, world=world, traffic=traffic_from_profile("bpe_train"))
     return {"metric": "BPE train seconds per 1k merges", "s_per_1k_merges": round(wall / n_merges * 1000, 5), "train_wall_s": round(wall, 4),
             "merge_loop_s": round(loop_s, 4), "us_per_merge_device": round(per_merge_s * 1e6, 2), "n_merges": len(merges),
             "workload": "FastBPE.train on %s to max_vocab=%d: %d merges, %d unique words, %d -> %d symbols" % (name, max_vocab, len(merges), w0, n0, n_final),
@@ -569,6 +604,7 @@ def bench_bpe_train_words(args, torch, dist, rank, world, local):
         tr = N.BpeTrainer.from_words(sym, off, freq)
         lefts, rights, counts = tr.run(n_merges, N.SYM_BASE)
         info = tr.info()
+        trace, stats = tr.step_trace(), tr.stats()
         tr.close()
         barrier_sync(torch, dist)
         if it >= args.warmup:
@@ -589,9 +625,7 @@ def bench_bpe_train_words(args, torch, dist, rank, world, local):
             and np.array_equal(np.asarray(counts[:sample], dtype=np.uint64), cnt)):
         raise SystemExit("PARITY FAILURE: device merges differ from the oracle on the first %d merges" % sample)
     n_final = int(info["n_symbols"])
-    algo = 12.0 * (n0 + n_final) / 2.0 + 8.0 * w0  # reference formulation, N_t averaged over the run (trapezoid)
     per_merge_s = kernel_ms / 1e3 / max(len(times), 1) / max(len(lefts), 1)  # the event brackets span whole batches of merge steps
-    achieved = algo / per_merge_s / 1e9 if per_merge_s else 0.0
     elapsed = sum(times)
     return {
         "metric": "BPE train seconds per 1k merges", "value": round(elapsed / len(times) / max(len(lefts), 1) * 1000, 4),
@@ -600,11 +634,8 @@ def bench_bpe_train_words(args, torch, dist, rank, world, local):
                                "deduplicated-words-with-frequencies form, %d -> %d symbols" % (w0, int(freq.sum()), corpus_bytes / 1e9, len(lefts), n0, n_final),
                    "parallelism": "single GPU"},
         "scaling": "strong",
-        "roofline": check_frac({"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "one merge step, all of its kernels",
-                     "kernel_us": round(per_merge_s * 1e6, 2), "algorithmic_bytes_per_launch": int(algo),
-                     "launches_timed": int(len(lefts) * len(times)),
-                     "note": "algorithmic bytes are the reference's full-rescan formulation (12 N_t + 8 W); effective rate, not HBM traffic"}),
+        "roofline": train_roofline(trace, stats, n0, w0, n_final, len(lefts), per_merge_s, len(lefts) * len(times),
+                                   12.0 * (n0 + n_final) / 2.0 + 8.0 * w0),  # rescan: N_t averaged over the run (trapezoid)
         "cpu_baseline": {"value": round(cpu_s / sample * 1000, 3), "unit": "s/1k-merges", "cores": 1, "kind": "port",
                          "sample": "first %d merges of the same run through oracle/swt_oracle.c (full recount per merge)" % sample},
         "final_symbols": info["n_symbols"], "parity_merges_checked": sample,
@@ -637,6 +668,7 @@ def bench_wp_train(args, torch, dist, rank, world, local):
         tok.train(sents, max_vocab)
         order = list(tok._merge_order)
         info = tok._trainer.info()
+        trace, stats = tok._trainer.step_trace(), tok._trainer.stats()
         tok.reset()
         barrier_sync(torch, dist)
         if it >= args.warmup:
@@ -654,9 +686,7 @@ def bench_wp_train(args, torch, dist, rank, world, local):
     if [tuple(m) for m in tr.merges_list] != [tuple(m) for m in order[:sample]]:
         raise SystemExit("PARITY FAILURE: device merges differ from the oracle on the first %d merges" % sample)
     n_final = int(info["n_symbols"])
-    algo = 16.0 * (n0 + n_final) / 2.0 + 8.0 * w0  # the reference's formulation: pair pass + symbol pass + rewrite read/write, per merge
     per_merge_s = kernel_ms / 1e3 / max(len(times), 1) / max(len(order), 1)
-    achieved = algo / per_merge_s / 1e9 if per_merge_s else 0.0
     elapsed = sum(times)
     return {
         "metric": "WordPiece train seconds per 1k merges", "value": round(elapsed / len(times) / max(len(order), 1) * 1000, 4),
@@ -664,11 +694,9 @@ def bench_wp_train(args, torch, dist, rank, world, local):
         "config": {"workload": "NaiveWP.train on S85k to max_vocab=%d: %d initial symbols, %d merges, %d unique words, %d -> %d symbols"
                                % (max_vocab, base, len(order), w0, n0, n_final), "parallelism": "single GPU"},
         "scaling": "strong",
-        "roofline": check_frac({"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "one merge step, all of its kernels",
-                     "kernel_us": round(per_merge_s * 1e6, 2), "algorithmic_bytes_per_launch": int(algo),
-                     "launches_timed": int(len(order) * len(times)),
-                     "note": "algorithmic bytes are the reference's full-rescan formulation; effective rate, not HBM traffic"}),
+        # rescan: the reference's pair pass + symbol pass + rewrite read/write, per merge
+        "roofline": train_roofline(trace, stats, n0, w0, n_final, len(order), per_merge_s, len(order) * len(times),
+                                   16.0 * (n0 + n_final) / 2.0 + 8.0 * w0, whole_table=True),
         "cpu_baseline": {"value": round(cpu_s / sample * 1000, 3), "unit": "s/1k-merges", "cores": 1, "kind": "port",
                          "sample": "first %d merges of the same run through oracle/swt_oracle.c (orc_wptrain_new + orc_train_run)" % sample},
         "final_symbols": info["n_symbols"],

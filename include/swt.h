@@ -237,7 +237,8 @@ int swt_bpe_train_histogram(swt_bpe_trainer *t, uint64_t *keys, uint64_t *counts
 
 /* Diagnostics of the trainer's machinery (tests, bench.py): out[0..n) = re-plans of the candidate threshold so far, the
  * threshold theta (0: full-table argmax), candidate list length, inverted-index log entries, pair-table slots, state flags
- * (bit 0: the index was abandoned for whole-stream applies), steps enqueued, distinct keys in the table. */
+ * (bit 0: the index was abandoned for whole-stream applies), steps enqueued, distinct keys in the table, index entries the
+ * apply launches have gone through, words the tie scans have covered (the last two: bench.py's bytes-per-merge model). */
 int swt_bpe_train_stats(const swt_bpe_trainer *t, uint64_t *out, uint32_t n);
 
 /* One row per merge performed by swt_bpe_train_run(_sharded) so far: rows[4 i ..] = the winning count (score bits for

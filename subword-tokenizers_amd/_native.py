@@ -441,9 +441,9 @@ class BpeTrainer:
         return rows[:n.value]
 
     def stats(self):
-        out = np.zeros(8, dtype=np.uint64)
-        check(lib().swt_bpe_train_stats(self._h, ptr(out, u64p), 8))
-        names = ("replans", "theta", "candidates", "index_entries", "table_slots", "flags", "steps", "keys")
+        out = np.zeros(10, dtype=np.uint64)
+        check(lib().swt_bpe_train_stats(self._h, ptr(out, u64p), 10))
+        names = ("replans", "theta", "candidates", "index_entries", "table_slots", "flags", "steps", "keys", "entries_scanned", "tie_words")
         return dict(zip(names, map(int, out)))
 
 

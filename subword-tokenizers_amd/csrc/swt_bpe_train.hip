@@ -709,6 +709,7 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
   for (int u = 0; u < (int)kMaxBatch; u++) { L[u] = P.l[u]; R[u] = P.r[u]; }
   const bool whole = (st->flags & kFlagIndexBroken) != 0;  // every word (only after a symbol id was reused: never on trained tables)
   const uint64_t n_ent = whole ? n_words : P.ent0[K];
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->ent_scanned += n_ent;
   // A log segment lists every pair its step made, and a lane keeps the entries of ITS pairs (by tag): of a segment born early
   // in training that is one in hundreds.  So a lane looks at kEntryFan entries per trip -- all their loads in flight together
   // -- the wave packs the matches into a queue (ballots), and goes through it 64 at a time (sparse matches: one round; a list
@@ -1206,6 +1207,7 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
     st->best_key = a.key;
     const uint64_t we = start + trip_words;
     st->win_end = (we < n_words ? we : n_words) << 32;
+    if (!dry && a.tied >= 2 && a.mx) st->tie_words += (we < n_words ? we : n_words) - start;
     if (dry) { atomicOr(&st->flags, kFlagReplan); st->halt = 3; }
   }
 #ifdef SWT_STAMPS
@@ -2232,8 +2234,9 @@ int swt_bpe_train_stats(const swt_bpe_trainer *t, uint64_t *out, uint32_t n) {
   if (!t || !out) return fail(SWT_ERR_INVALID, "null argument");
   TrainState r;
   SWT_HIP(hipMemcpy(&r, t->d_st, sizeof r, hipMemcpyDeviceToHost));
-  const uint64_t v[8] = {t->n_replans, t->theta, r.n_cand, r.idx_cursor, (uint64_t)(1ull << t->T.bits), r.flags, t->step_no, r.n_used};
-  for (uint32_t i = 0; i < n && i < 8; i++) out[i] = v[i];
+  const uint64_t v[10] = {t->n_replans, t->theta, r.n_cand, r.idx_cursor, (uint64_t)(1ull << t->T.bits), r.flags, t->step_no, r.n_used,
+                          r.ent_scanned, r.tie_words};
+  for (uint32_t i = 0; i < n && i < 10; i++) out[i] = v[i];
   return SWT_OK;
 }
 

@@ -55,6 +55,9 @@ struct TrainState {
   unsigned long long win_end;      // tie positions below this (word << 32) lie in the window EVERY workgroup scanned
   unsigned long long n_list[2];    // length of tied_idx[] / tied_key[], by step parity
   unsigned long long step_syms;    // live symbols when the step began (the tie launch notes it: no apply is in flight then)
+  // what the merge steps have looked at so far (bench.py's bytes-per-merge model; one lane adds, launches are serial)
+  unsigned long long ent_scanned;  // index entries the apply launches went through
+  unsigned long long tie_words;    // words the tie scans' first trips covered
 };
 
 struct StepCmd {

@@ -125,7 +125,8 @@ def train_sharded(corpus: List[str], max_vocab: int, rank: int, world: int, dist
     tr = ShardedBpeTrainer.from_corpus(corpus, rank, world, comm)
     try:
         merges = [tuple(m) for m in tr.train(max_vocab)]
-        info = tr.engine.info()
+        info = dict(tr.engine.info())
+        info.update(tr.engine.trainers[0].stats())  # bench.py's bytes model reads entries_scanned
     finally:
         tr.engine.close()
         comm.close()

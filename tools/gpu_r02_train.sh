@@ -8,7 +8,8 @@ for w in "bpe_train" "bpe_train --corpus lex" "wp_train" "bpe_train_1g"; do
 import json
 try:
     d=json.load(open("gpurun_out/r02_$n.json"))
-    print("$w", d["value"], d["unit"], "ms/step", d["ms_per_step"], "merge_us", d["roofline"]["kernel_us"], "frac", d["roofline"]["frac"], "cpu", d["cpu_baseline"]["value"])
+    r=d["roofline"]
+    print("$w", d["value"], d["unit"], "ms/step", d["ms_per_step"], "merge_us", r["kernel_us"], "frac", r["frac"], "bytes/merge", r["algorithmic_bytes_per_launch"], r["bytes_model"], "merges/step", r["merges_per_step"], "rescan eff GB/s", r["rescan_formulation"]["effective_gbs"], "cpu", d["cpu_baseline"]["value"])
 except Exception as e:
     print("$w: no json", e); print(open("gpurun_out/r02_$n.err").read()[-1500:])
 PY
