@@ -2331,7 +2331,8 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
   uint32_t done = 0;
   bool exhausted = false;
   int dry_runs = 0;
-  double per_step = 1.0;  // merges a step of the fast path has carried lately: sizes the next round trip
+  double per_step = 1.0;   // merges a step of the fast path has carried lately: sizes the next round trip
+  double per_level = 0.0;  // merges per count level lately (0: not seen yet): says when the candidate list will run dry
   while (done < max_steps && !exhausted) {
     const uint32_t remaining = max_steps - done;
     // One round trip: `steps` launch sequences that may log up to `cap` merges.  A step of the fast path carries one merge or
@@ -2340,7 +2341,15 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
     uint32_t steps = remaining < kRunBatch ? remaining : kRunBatch;
     uint32_t cap = steps;
     if (maybe_fast) {
-      const double want = (double)remaining / per_step * 1.05 + 1.0;
+      double want = (double)remaining / per_step * 1.05 + 1.0;
+      // A list that runs dry in mid trip turns the rest of the trip into steps that do nothing (two launches each): the
+      // maximum falls one level at a time, so the levels left above theta say about how many merges the list is good for.
+      // End the trip there -- or, when that is close, take the new threshold now.
+      if (t->cand_valid && t->theta > 1 && per_level > 0.0 && t->h_st.max_count >= t->theta) {
+        const double left = (double)(t->h_st.max_count - t->theta + 1) * per_level * 0.9;
+        if (left < 48.0 && left < (double)remaining) t->cand_valid = false;
+        else if (left / per_step + 1.0 < want) want = left / per_step + 1.0;
+      }
       if (want < (double)steps) steps = (uint32_t)want;
       if (steps < 8) steps = remaining < 8 ? remaining : 8;
       double c = (double)steps * per_step * 1.5 + 8.0;
@@ -2403,6 +2412,8 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
       done++;
     }
     t->n_applied += good;
+    if (good && fast && hlog[0].count > hlog[good - 1].count)
+      per_level = (double)good / (double)(hlog[0].count - hlog[good - 1].count + 1);
     if (good && !t->d_sfreq) t->h_st.max_count = hlog[good - 1].count;  // counts never grow: bound for the next batch
     if (stop == 3) {  // the candidate list ran dry: later steps of the batch were no-ops; new theta, go on
       t->cand_valid = false;

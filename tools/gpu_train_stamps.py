@@ -82,3 +82,15 @@ for k in range(1, 9):
     if sel.any():
         print("  K=%d: slowest lane per phase: prologue %.1f | entries %.1f  bounds+claim+stage %.1f  walk %.1f  reserve %.1f  flush %.1f us" % (
             (k, entry[sel].mean()) + tuple(pmax[1 + q][steps][sel].mean() for q in range(5))))
+
+# where the device time of the run goes, by training phase (spans + the boundaries after them)
+cost = tie + app + gap1 + gap2
+cost[~seen] = 0
+cum = np.cumsum(ks)  # merges done after each step
+print("device time by phase (tie + apply + boundaries), total %.1f ms:" % (cost.sum() / 1e3))
+for lo, hi in ((0, 100), (100, 500), (500, 1000), (1000, 2000), (2000, 4000), (4000, 100000)):
+    sel = (cum > lo) & (cum <= hi) & seen & (ks > 0)
+    if sel.any():
+        print("  merges %5d..%5d: %5d steps, %6.1f ms, %.1f us/merge (tie %.1f apply %.1f per step)" % (lo, min(hi, int(cum[-1])), int(sel.sum()), cost[sel].sum() / 1e3, cost[sel].sum() / max(1, ks[sel].sum()), tie[sel].mean(), app[sel].mean()))
+noop = seen & (ks == 0)
+print("  steps that carried nothing: %d, %.1f ms" % (int(noop.sum()), cost[noop].sum() / 1e3))
