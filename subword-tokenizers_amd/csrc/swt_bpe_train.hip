@@ -562,7 +562,10 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 constexpr int kEmitCap = 10;
 constexpr int kStage = 24;      // stream slots of a word staged in LDS before its walk
 constexpr int kEntryFan = 8;   // index entries a lane looks at per trip of an apply launch
-constexpr int kFlushBatch = 8;  // parked deltas whose table probes go out together
+constexpr int kFlushBatch = 8;
+constexpr int kBigWords = 128;   // ... when a workgroup holds at least this many words of the merge in a trip
+constexpr int kBigMerge = 8192;  // index entries from which an apply launch sums its deltas per pair in LDS first
+constexpr int kAggSlots = kTrainThreads * kStage * 4 / 16;  // (key, sum) slots the staging area holds  // parked deltas whose table probes go out together
 constexpr unsigned long long kEmitNew = 1ull << 63;  // symbol ids stay below 2^31, so bit 63 of a pair key is free
 
 // the slot of a key that is very likely in the table already: one plain load; anything else goes the insert-or-find way
@@ -719,7 +722,94 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
   const uint64_t lanes = (uint64_t)gridDim.x * blockDim.x, stride = lanes * kEntryFan;
   unsigned long long removed = 0, self_delta = 0, inserted = 0;
   uint32_t min_w = 0xFFFFFFFFu;
-  for (uint64_t e0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; e0 < n_ent; e0 += stride) {
+  // A big merge (the first few hundred of a training run: tens of thousands of words each) is bound by the table: most of its
+  // deltas go to a few hot pairs.  There the workgroup first sums its deltas per pair in LDS (the staging area, free once the
+  // walks are done) and sends every pair once.
+  const bool maybe_big = n_ent >= (uint64_t)kBigMerge && !C.pend;  // (a long list may still hold few words of THESE pairs)
+  __shared__ unsigned int blk_rounds, blk_matches;
+  unsigned long long *agg_key = reinterpret_cast<unsigned long long *>(stage_s);  // [kAggSlots] keys, then [kAggSlots] sums
+  long long *agg_sum = reinterpret_cast<long long *>(stage_s) + kAggSlots;
+  const uint32_t tmask = (uint32_t)((1ull << C.T.bits) - 1ull);
+  // One batch of table updates: `n_items` (<= kFlushBatch) items, item j = (key_of(j) -- kEmptyKey: none --, delta_of(j)).
+  // Three rounds, each with all its memory operations in flight together: probe, add, follow up.  index_at: where the index
+  // entries of the new pairs among them go (word w), or nullptr when the caller has written them.
+  auto flush_batch = [&](int n_items, auto key_of, auto delta_of, uint64_t *index_at, uint32_t w) {
+    unsigned long long key[kFlushBatch], seen[kFlushBatch], seen2[kFlushBatch];
+    long long was[kFlushBatch], dl[kFlushBatch];
+    uint32_t h[kFlushBatch], ci[kFlushBatch], ci2[kFlushBatch];
+    bool on[kFlushBatch];
+#pragma unroll
+    for (int u = 0; u < kFlushBatch; u++) {
+      // the home slot AND the one behind it (linear probing: most keys that are not at home are there)
+      key[u] = u < n_items ? key_of(u) : kEmptyKey;
+      on[u] = key[u] != kEmptyKey;
+      dl[u] = on[u] ? delta_of(u) : 0;
+      h[u] = slot_hint(C.T, key[u] & ~kEmitNew);
+      const uint32_t h2 = (h[u] + 1) & tmask;
+      seen[u] = on[u] ? C.T.keys[h[u]] : 0ull;
+      seen2[u] = on[u] ? C.T.keys[h2] : 0ull;
+      ci[u] = on[u] && C.cidx ? C.cidx[h[u]] : 0xFFFFFFFFu;
+      ci2[u] = on[u] && C.cidx ? C.cidx[h2] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < kFlushBatch; u++) {
+      const unsigned long long k = key[u] & ~kEmitNew;
+      if (on[u] && seen[u] != k && seen[u] != kEmptyKey && (seen2[u] == k || seen2[u] == kEmptyKey)) {
+        h[u] = (h[u] + 1) & tmask;  // home is taken by another key: this pair is, or goes, one slot on
+        seen[u] = seen2[u];
+        ci[u] = ci2[u];
+      }
+    }
+    // a pair the merge has just made is usually not in the table: its home slot is taken here, all of them at once
+    unsigned long long got[kFlushBatch];
+#pragma unroll
+    for (int u = 0; u < kFlushBatch; u++)
+      got[u] = (on[u] && seen[u] == kEmptyKey) ? atomicCAS(&C.T.keys[h[u]], kEmptyKey, key[u] & ~kEmitNew) : 1ull;
+#pragma unroll
+    for (int u = 0; u < kFlushBatch; u++) {
+      if (!on[u]) continue;
+      const unsigned long long k = key[u] & ~kEmitNew;
+      if (seen[u] == kEmptyKey) {
+        if (got[u] == kEmptyKey) { inserted++; seen[u] = k; }
+        else seen[u] = got[u];  // another lane was first (with this pair, or with another one)
+      }
+      if (seen[u] != k) {  // not at its home slot
+        h[u] = table_slot(C.T, k, st);
+        ci[u] = C.cidx ? C.cidx[h[u]] : 0xFFFFFFFFu;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kFlushBatch; u++) {
+      was[u] = 0;
+      if (!on[u]) continue;
+      const unsigned long long delta = (unsigned long long)dl[u];
+      const uint32_t slot = h[u];
+      if (!C.pend) {  // count_add, with the compact copy's index already here
+        if (ci[u] != 0xFFFFFFFFu)
+          (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&C.ccnt[ci[u]]), delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (dl[u] > 0 && C.theta)  // only the pairs a merge creates ever rise: they may cross theta
+          was[u] = (long long)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&C.T.cnt[slot]), delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+          (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&C.T.cnt[slot]), delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&C.pend[slot]), delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        was[u] = (long long)atomicMax(&C.tstamp[slot], C.step);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kFlushBatch; u++) {
+      if (!on[u]) continue;
+      if (!C.pend) {
+        if (dl[u] > 0 && C.theta && was[u] < (long long)C.theta && was[u] + dl[u] >= (long long)C.theta) cand_push(C, h[u]);
+      } else if ((uint32_t)was[u] < C.step) {
+        const unsigned long long q = atomicAdd(&st->n_touched, 1ull);
+        if (q < C.touched_cap) C.touched[q] = h[u];
+      }
+      if (index_at && (key[u] & kEmitNew)) index_entry(C, (*index_at)++, key[u] & ~kEmitNew, first_m, K, w);
+    }
+  };
+  for (uint64_t eb = (uint64_t)blockIdx.x * blockDim.x; eb < n_ent; eb += stride) {  // the same trips for the whole workgroup
+    const uint64_t e0 = eb + (uint64_t)(threadIdx.x - lane);
     int n_q = 0;  // the wave's matches of this trip, packed into its queue in entry order
     {
       uint32_t we[kEntryFan], tg[kEntryFan], wt[kEntryFan];
@@ -749,7 +839,18 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
         n_q += __popcll(mm);
       }
     }
-   for (int round = 0; round * 64 < n_q; round++) {
+   int n_rounds = (n_q + 63) >> 6;
+   bool big = false;
+   if (maybe_big) {  // the workgroup's words of this trip: many -> the summing rounds, which end in workgroup barriers
+     if (threadIdx.x == 0) { blk_rounds = 0; blk_matches = 0; }
+     __syncthreads();
+     if (lane == 0) { atomicMax(&blk_rounds, (unsigned int)n_rounds); atomicAdd(&blk_matches, (unsigned int)n_q); }
+     __syncthreads();
+     big = blk_matches >= (unsigned int)kBigWords;
+     if (big) n_rounds = (int)blk_rounds;
+     __syncthreads();  // (the next trip resets the two)
+   }
+   for (int round = 0; round < n_rounds; round++) {
     const int qi = round * 64 + lane;
     uint32_t w = qi < n_q ? queue[qi] : 0xFFFFFFFFu;
     int n_park = 0, n_new = 0;
@@ -793,88 +894,53 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
     if (lane == 0 && total) base = atomicAdd(&st->idx_cursor, (unsigned long long)total);
     base = __shfl(base, 0);
     SWT_STAMP(ts, 4);
-    if (w != 0xFFFFFFFFu && n_park) {
+    if (big) {
+      // the index entries of the new pairs, then the deltas into the workgroup's LDS sums
+      const long long fw = (w != 0xFFFFFFFFu && n_park) ? (long long)freq[w] : 0;
+      uint64_t at = base + x - (uint32_t)n_new;
+      for (int j = 0; j < n_park; j++) {
+        const unsigned long long pk = park[j * kTrainThreads];
+        if (pk & kEmitNew) index_entry(C, at++, pk & ~kEmitNew, first_m, K, w);
+      }
+      __syncthreads();  // every walk of the round is done: the staging area is free
+      for (int i = threadIdx.x; i < kAggSlots; i += blockDim.x) { agg_key[i] = kEmptyKey; agg_sum[i] = 0; }
+      __syncthreads();
+      int n_left = 0;  // deltas that found no room in the sums: they stay parked (in front) and go out one by one
+      for (int j = 0; j < n_park; j++) {
+        const unsigned long long pk = park[j * kTrainThreads], k = pk & ~kEmitNew;
+        const long long d = (pk & kEmitNew) ? fw : -fw;
+        uint32_t hs = (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 40) % (uint32_t)kAggSlots;
+        bool put = false;
+        for (int probe = 0; probe < 12 && !put; probe++) {
+          unsigned long long old = agg_key[hs];
+          if (old == kEmptyKey) {
+            old = atomicCAS(&agg_key[hs], kEmptyKey, k);
+            if (old == kEmptyKey) old = k;
+          }
+          if (old == k) { atomicAdd(reinterpret_cast<unsigned long long *>(&agg_sum[hs]), (unsigned long long)d); put = true; }
+          hs = hs + 1 == (uint32_t)kAggSlots ? 0u : hs + 1;
+        }
+        if (!put) park[(n_left++) * kTrainThreads] = pk;
+      }
+      __syncthreads();
+      // every pair of the sums once (kAggSlots / 256 slots a lane, one batch)
+      flush_batch(kAggSlots / kTrainThreads,
+                  [&](int u) -> unsigned long long { const long long sm = agg_sum[threadIdx.x + u * kTrainThreads]; return sm ? agg_key[threadIdx.x + u * kTrainThreads] : kEmptyKey; },
+                  [&](int u) -> long long { return agg_sum[threadIdx.x + u * kTrainThreads]; }, nullptr, 0u);
+      for (int j0 = 0; j0 < n_left; j0 += kFlushBatch)
+        flush_batch(n_left - j0 < kFlushBatch ? n_left - j0 : kFlushBatch,
+                    [&](int u) -> unsigned long long { return park[(j0 + u) * kTrainThreads] & ~kEmitNew; },
+                    [&](int u) -> long long { return (park[(j0 + u) * kTrainThreads] & kEmitNew) ? fw : -fw; }, nullptr, 0u);
+      __syncthreads();  // the next round stages into the area again
+    } else if (w != 0xFFFFFFFFu && n_park) {
       SWT_COUNT(28);
       if (n_park > kFlushBatch) SWT_COUNT(26);
       const long long f = freq[w];  // L1: loaded a moment ago
       uint64_t at = base + x - (uint32_t)n_new;
-      for (int j0 = 0; j0 < n_park; j0 += kFlushBatch) {
-        // three rounds, each with all its memory operations in flight together: probe, add, follow up
-        unsigned long long key[kFlushBatch], seen[kFlushBatch], seen2[kFlushBatch];
-        long long was[kFlushBatch];
-        uint32_t h[kFlushBatch], ci[kFlushBatch], ci2[kFlushBatch];
-        const uint32_t tmask = (uint32_t)((1ull << C.T.bits) - 1ull);
-#pragma unroll
-        for (int u = 0; u < kFlushBatch; u++) {
-          // the home slot AND the one behind it (linear probing: most keys that are not at home are there)
-          const bool on = j0 + u < n_park;
-          key[u] = on ? park[(j0 + u) * kTrainThreads] : 0ull;
-          h[u] = slot_hint(C.T, key[u] & ~kEmitNew);
-          const uint32_t h2 = (h[u] + 1) & tmask;
-          seen[u] = on ? C.T.keys[h[u]] : 0ull;
-          seen2[u] = on ? C.T.keys[h2] : 0ull;
-          ci[u] = on && C.cidx ? C.cidx[h[u]] : 0xFFFFFFFFu;
-          ci2[u] = on && C.cidx ? C.cidx[h2] : 0xFFFFFFFFu;
-        }
-#pragma unroll
-        for (int u = 0; u < kFlushBatch; u++) {
-          const unsigned long long k = key[u] & ~kEmitNew;
-          if (j0 + u < n_park && seen[u] != k && seen[u] != kEmptyKey && (seen2[u] == k || seen2[u] == kEmptyKey)) {
-            h[u] = (h[u] + 1) & tmask;  // home is taken by another key: this pair is, or goes, one slot on
-            seen[u] = seen2[u];
-            ci[u] = ci2[u];
-          }
-        }
-        // a pair the merge has just made is usually not in the table: its home slot is taken here, all of them at once
-        unsigned long long got[kFlushBatch];
-#pragma unroll
-        for (int u = 0; u < kFlushBatch; u++)
-          got[u] = (j0 + u < n_park && seen[u] == kEmptyKey) ? atomicCAS(&C.T.keys[h[u]], kEmptyKey, key[u] & ~kEmitNew) : 1ull;
-#pragma unroll
-        for (int u = 0; u < kFlushBatch; u++) {
-          if (j0 + u >= n_park) continue;
-          const unsigned long long k = key[u] & ~kEmitNew;
-          if (seen[u] == kEmptyKey) {
-            if (got[u] == kEmptyKey) { inserted++; seen[u] = k; }
-            else seen[u] = got[u];  // another lane was first (with this pair, or with another one)
-          }
-          if (seen[u] != k) {  // not at its home slot
-            h[u] = table_slot(C.T, k, st);
-            ci[u] = C.cidx ? C.cidx[h[u]] : 0xFFFFFFFFu;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < kFlushBatch; u++) {
-          was[u] = 0;
-          if (j0 + u >= n_park) continue;
-          const bool is_new = (key[u] & kEmitNew) != 0;
-          const unsigned long long delta = (unsigned long long)(is_new ? f : -f);
-          const uint32_t slot = h[u];
-          if (!C.pend) {  // count_add, with the compact copy's index already here
-            if (ci[u] != 0xFFFFFFFFu)
-              (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&C.ccnt[ci[u]]), delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (is_new && C.theta)
-              was[u] = (long long)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&C.T.cnt[slot]), delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else
-              (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&C.T.cnt[slot]), delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } else {
-            (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&C.pend[slot]), delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            was[u] = (long long)atomicMax(&C.tstamp[slot], C.step);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < kFlushBatch; u++) {
-          if (j0 + u >= n_park) continue;
-          const bool is_new = (key[u] & kEmitNew) != 0;
-          if (!C.pend) {
-            if (is_new && C.theta && was[u] < (long long)C.theta && was[u] + f >= (long long)C.theta) cand_push(C, h[u]);
-          } else if ((uint32_t)was[u] < C.step) {
-            const unsigned long long q = atomicAdd(&st->n_touched, 1ull);
-            if (q < C.touched_cap) C.touched[q] = h[u];
-          }
-          if (is_new) index_entry(C, at++, key[u] & ~kEmitNew, first_m, K, w);
-        }
-      }
+      for (int j0 = 0; j0 < n_park; j0 += kFlushBatch)
+        flush_batch(n_park - j0 < kFlushBatch ? n_park - j0 : kFlushBatch,
+                    [&](int u) -> unsigned long long { return park[(j0 + u) * kTrainThreads]; },
+                    [&](int u) -> long long { return (park[(j0 + u) * kTrainThreads] & kEmitNew) ? f : -f; }, &at, w);
 #ifdef SWT_STAMPS
       SWT_STAMP(ts, 5);
       if (e0 < stride && C.step > 512 && atomicAdd(&g_reported[C.step & (kSpanSteps - 1)], 1u) == 0) {  // ts[0] is the kernel's start
