@@ -43,6 +43,7 @@
 // then accumulates its deltas per table slot in pend[] and lists the touched slots; the runner packs them into a fixed-size
 // record block, all-gathers the blocks (RCCL) and every rank adds every block to its replica.
 #include <algorithm>
+#include <hipcub/hipcub.hpp>
 
 #include "swt_common.h"
 #include "swt_train.h"
@@ -1769,6 +1770,31 @@ static unsigned grid_for(uint64_t n, int threads, unsigned cap = 1u << 20) {
   return (unsigned)g;
 }
 
+// ---- squeezing the holes out -------------------------------------------------------------------------------------------
+// Merges leave holes (stable addresses are what lets a step touch only the words it changes), and late in training two slots
+// in three are holes: every walk and every tie scan steps over them.  Nothing but woff[] refers to a stream address between
+// steps (the index lists WORDS), so at a re-plan the host may rewrite the stream without them: count, scan, copy.
+__global__ void live_count_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff, uint64_t n_words,
+                                  unsigned long long *__restrict__ out) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w > n_words) return;
+  unsigned long long n = 0;
+  if (w < n_words)
+    for (uint64_t i = woff[w], e = woff[w + 1]; i < e; i++) n += sym[i] != kHole ? 1 : 0;
+  out[w] = n;  // out[n_words] = 0: the exclusive sum leaves the total there
+}
+
+__global__ void squeeze_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff, const uint64_t *__restrict__ new_woff,
+                               uint64_t n_words, uint32_t *__restrict__ out) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  uint64_t o = new_woff[w];
+  for (uint64_t i = woff[w], e = woff[w + 1]; i < e; i++) {
+    const uint32_t x = sym[i];
+    if (x != kHole) out[o++] = x;
+  }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------
 
 TrainCtx swt_bpe_trainer::ctx() const {
@@ -1853,6 +1879,32 @@ static int table_resize(swt_bpe_trainer *t, uint32_t bits) {
   t->T = nt;
   t->cand_valid = false;
   return sharded_arrays(t);
+}
+
+// the stream without its holes (between steps, unsharded BPE; the caller has synchronised h_st)
+static int squeeze_stream(swt_bpe_trainer *t) {
+  if (!t->n_words || t->sharded) return SWT_OK;
+  if (!t->d_sym_alt) {
+    SWT_HIP(hipMalloc((void **)&t->d_sym_alt, (size_t)(t->n_syms0 + 16) * 4));
+    SWT_HIP(hipMalloc((void **)&t->d_woff_alt, (size_t)(t->n_words + 2) * 8));
+  }
+  const unsigned g = grid_for(t->n_words + 1, 256);
+  unsigned long long *lens = reinterpret_cast<unsigned long long *>(t->d_woff_alt);
+  hipLaunchKernelGGL(live_count_kernel, dim3(g), dim3(256), 0, t->stream, t->d_sym, t->d_woff, t->n_words, lens);
+  size_t tmp_bytes = 0;
+  SWT_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, lens, lens, (int)(t->n_words + 1), t->stream));
+  int rc = t->tmp.reserve(tmp_bytes + 16);
+  if (rc) return rc;
+  SWT_HIP(hipcub::DeviceScan::ExclusiveSum(t->tmp.p, tmp_bytes, lens, lens, (int)(t->n_words + 1), t->stream));
+  hipLaunchKernelGGL(squeeze_kernel, dim3(g), dim3(256), 0, t->stream, t->d_sym, t->d_woff, t->d_woff_alt, t->n_words, t->d_sym_alt);
+  unsigned long long total = 0;
+  SWT_HIP(hipMemcpyAsync(&total, t->d_woff_alt + t->n_words, 8, hipMemcpyDeviceToHost, t->stream));
+  SWT_HIP(hipStreamSynchronize(t->stream));
+  std::swap(t->d_sym, t->d_sym_alt);
+  std::swap(t->d_woff, t->d_woff_alt);
+  t->extent = total;
+  t->n_squeezes++;
+  return SWT_OK;
 }
 
 // theta from the histogram of the counts, then the list of the slots that pass it
@@ -2051,6 +2103,7 @@ static int finish_create(swt_bpe_trainer *t) {
 static int trainer_adopt(swt_bpe_trainer *t, DeviceWords &dw) {
   t->n_words = dw.n_words;
   t->n_syms0 = dw.n_syms;
+  t->extent = dw.n_syms;
   t->d_sym = dw.d_sym;
   t->d_woff = dw.d_woff;
   t->d_freq = dw.d_freq;
@@ -2069,6 +2122,7 @@ static int trainer_upload(swt_bpe_trainer *t, const uint32_t *syms, const uint64
   const uint64_t n_syms = word_off[n_words];
   t->n_words = n_words;
   t->n_syms0 = n_syms;
+  t->extent = n_syms;
   if (n_words >= 0xFFFFFFFFull || n_syms >= 0xFFFFFFFFull) return fail(SWT_ERR_UNSUPPORTED, "more than 2^32 - 1 unique words or symbols");
   for (uint64_t w = 0; w < n_words; w++) {
     if (word_off[w + 1] < word_off[w]) return fail(SWT_ERR_INVALID, "word offsets must be non-decreasing");
@@ -2269,7 +2323,7 @@ void swt_bpe_train_destroy(swt_bpe_trainer *t) {
   (void)hipStreamSynchronize(t->stream);
   for (void *p : {(void *)t->d_sym, (void *)t->d_woff, (void *)t->d_freq, (void *)t->d_st, (void *)t->d_parts, (void *)t->d_cmd,
                   (void *)t->d_steplog, (void *)t->d_sfreq, (void *)t->d_cand, (void *)t->d_ccnt, (void *)t->d_ckey, (void *)t->d_cidx, (void *)t->d_buckets, (void *)t->d_idx_tag,
-                  (void *)t->d_idx_word, (void *)t->d_wstamp, (void *)t->d_wkey, (void *)t->d_tied_idx, (void *)t->d_tied_key, (void *)t->d_gpos, (void *)t->d_seg_start, (void *)t->d_seg_of, (void *)t->d_pend,
+                  (void *)t->d_idx_word, (void *)t->d_wstamp, (void *)t->d_wkey, (void *)t->d_tied_idx, (void *)t->d_tied_key, (void *)t->d_gpos, (void *)t->d_sym_alt, (void *)t->d_woff_alt, (void *)t->d_seg_start, (void *)t->d_seg_of, (void *)t->d_pend,
                   (void *)t->d_tstamp, (void *)t->d_touched, (void *)t->d_block, (void *)t->d_blocks_all, (void *)t->d_tie_line,
                   (void *)t->d_tie_all, (void *)t->d_halt, (void *)t->K.keys, (void *)t->K.start, (void *)t->K.len, (void *)t->K.fill,
                   (void *)t->K.words})
@@ -2430,7 +2484,11 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
     if (t->h_st.max_count == 0 || by_sym < per) per = by_sym;
     if ((rc = ensure_room(t, per * cap))) return rc;
     if ((rc = ensure_steps(t, steps, first_merged + done + cap))) return rc;
-    if ((!t->cand_valid || (!t->theta && !t->d_sfreq) || t->h_st.n_cand > kCandHigh) && (rc = t->replan())) return rc;
+    if (!t->cand_valid || (!t->theta && !t->d_sfreq) || t->h_st.n_cand > kCandHigh) {
+      // a host stop anyway: when three slots in ten are holes, the stream is rewritten without them
+      if (maybe_fast && t->h_st.n_syms && t->h_st.n_syms * 10 < t->extent * 7 && (rc = squeeze_stream(t))) return rc;
+      if ((rc = t->replan())) return rc;
+    }
     const bool fast = t->theta && maybe_fast;
     if (!fast) {
       if (steps > remaining) steps = remaining;
@@ -2501,10 +2559,10 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
 int swt_bpe_train_export(swt_bpe_trainer *t, uint32_t *syms, uint64_t syms_cap, uint64_t *word_off, uint32_t *freq) {
   if (!t || !word_off) return fail(SWT_ERR_INVALID, "null argument");
   SWT_HIP(hipStreamSynchronize(t->stream));
-  std::vector<uint32_t> all(t->n_syms0 + 1);
+  std::vector<uint32_t> all(t->extent + 1);
   std::vector<uint64_t> woff(t->n_words + 1);
   SWT_HIP(hipMemcpy(woff.data(), t->d_woff, (t->n_words + 1) * 8, hipMemcpyDeviceToHost));
-  if (t->n_syms0) SWT_HIP(hipMemcpy(all.data(), t->d_sym, t->n_syms0 * 4, hipMemcpyDeviceToHost));
+  if (t->extent) SWT_HIP(hipMemcpy(all.data(), t->d_sym, t->extent * 4, hipMemcpyDeviceToHost));
   uint64_t o = 0;
   for (uint64_t w = 0; w < t->n_words; w++) {
     word_off[w] = o;

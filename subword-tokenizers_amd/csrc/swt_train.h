@@ -134,6 +134,10 @@ struct swt_bpe_trainer {
   hipStream_t stream = 0;
   uint32_t *d_sym = nullptr;
   uint64_t *d_woff = nullptr;
+  uint64_t extent = 0;            // stream slots behind d_woff[n_words] (n_syms0 until the first squeeze)
+  uint32_t *d_sym_alt = nullptr;  // the other half of the squeeze's ping-pong (swt_bpe_train.hip: squeeze_stream)
+  uint64_t *d_woff_alt = nullptr;
+  uint64_t n_squeezes = 0;
   uint32_t *d_freq = nullptr;
   swt::PairTable T{nullptr, nullptr, 0};
   swt::K0Index K{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
