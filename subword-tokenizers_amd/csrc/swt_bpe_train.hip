@@ -585,25 +585,33 @@ struct BatchPlan {
 
 // where the words of member q are listed: the static index of the initial pairs, or the log segment of the step that made the
 // later-born of its two symbols (every occurrence of a pair is created in that ONE step)
-__device__ __forceinline__ unsigned long long plan_member(const TrainCtx &C, BatchPlan &P, int q) {
-  const uint32_t l = P.l[q], r = P.r[q];
+__device__ __forceinline__ TiedPlan plan_lookup(const TrainCtx &C, uint32_t l, uint32_t r) {
   const uint32_t sl = seg_of_symbol(C, l), sr = seg_of_symbol(C, r);
   const uint32_t seg = sl > sr ? sl : sr;
-  unsigned long long n_ent = 0;
-  P.tags[q] = nullptr;
-  P.want[q] = 0;
+  TiedPlan t{0, 0, 0, 0};
   if (seg == 0) {
     const uint32_t h = k0_find(C.K, pair_key(l, r));
-    if (h != 0xFFFFFFFFu) { P.list[q] = C.K.words + C.K.start[h]; n_ent = C.K.len[h]; }
-    else P.list[q] = C.K.words;
+    if (h != 0xFFFFFFFFu) { t.kind = 1; t.start = C.K.start[h]; t.n_ent = C.K.len[h]; }
   } else {
     const uint64_t s0 = C.seg_start[seg], s1 = C.seg_start[seg + 1];
-    P.list[q] = C.idx_word + s0;
-    P.tags[q] = C.idx_tag + s0;
-    n_ent = s1 - s0;
-    P.want[q] = (sl >= sr) ? ((r << 1) | 1u) : (l << 1);  // the later-born symbol is the segment's m; (m, m') counts as m left
+    t.kind = 2;
+    t.start = s0;
+    t.n_ent = s1 - s0;
+    t.want = (sl >= sr) ? ((r << 1) | 1u) : (l << 1);  // the later-born symbol is the segment's m; (m, m') counts as m left
   }
-  return n_ent;
+  return t;
+}
+
+// member q of the plan takes the list `t`; returns its length
+__device__ __forceinline__ unsigned long long plan_take(const TrainCtx &C, BatchPlan &P, int q, const TiedPlan &t) {
+  P.list[q] = t.kind == 2 ? C.idx_word + t.start : C.K.words + t.start;
+  P.tags[q] = t.kind == 2 ? C.idx_tag + t.start : nullptr;
+  P.want[q] = t.want;
+  return t.kind ? t.n_ent : 0ull;
+}
+
+__device__ __forceinline__ unsigned long long plan_member(const TrainCtx &C, BatchPlan &P, int q) {
+  return plan_take(C, P, q, plan_lookup(C, P.l[q], P.r[q]));
 }
 
 // the index entry of a new pair: the symbol beside the merged one, and the side the merged one is on.  When both symbols were
@@ -1038,7 +1046,6 @@ constexpr int kCandRegs = 8;              // candidates a lane holds in register
 // the tied pairs of a step, in LDS
 struct TieSets {
   unsigned long long key[kTieSetSlots];  // the pairs (open addressing)
-  unsigned long long pos[kTieSetSlots];  // earliest position this workgroup saw of each (word << 32 | offset of the left symbol)
   uint32_t idx[kTieSetSlots];            // its place in the candidate list
   uint32_t lefts[kTieSetSlots];          // the symbols some tied pair has on its left ...
   uint32_t rights[kTieSetSlots];         // ... and on its right (for "dangerous", see above)
@@ -1068,23 +1075,27 @@ __device__ __forceinline__ bool symset_has(const uint32_t *set, uint32_t s) {
   }
 }
 
-__device__ __forceinline__ void tset_clear(TieSets &S) {
+// (the symbol sets are the planner's: `with_syms`)
+__device__ __forceinline__ void tset_clear(TieSets &S, bool with_syms) {
   for (int i = threadIdx.x; i < kTieSetSlots; i += blockDim.x) {
     S.key[i] = kEmptyKey;
-    S.pos[i] = kEmptyKey;
-    S.lefts[i] = kHole;
-    S.rights[i] = kHole;
+    if (with_syms) {
+      S.lefts[i] = kHole;
+      S.rights[i] = kHole;
+    }
   }
 }
 
-__device__ __forceinline__ void tset_insert(TieSets &S, unsigned long long key, uint32_t cand_i) {
+__device__ __forceinline__ void tset_insert(TieSets &S, unsigned long long key, uint32_t cand_i, bool with_syms) {
   uint32_t h = tset_hash(key);
   for (;;) {  // a slot may be listed twice: the set takes a key once
     const unsigned long long old = atomicCAS(&S.key[h], kEmptyKey, key);
     if (old == kEmptyKey) {
       S.idx[h] = cand_i;
-      symset_insert(S.lefts, (uint32_t)(key >> 32));
-      symset_insert(S.rights, (uint32_t)key);
+      if (with_syms) {
+        symset_insert(S.lefts, (uint32_t)(key >> 32));
+        symset_insert(S.rights, (uint32_t)key);
+      }
       break;
     }
     if (old == key) break;
@@ -1120,8 +1131,9 @@ __device__ __forceinline__ BlockArg block_reduce(unsigned long long m, unsigned 
 // rounds of independent loads instead of a chain per candidate.
 // `spec` = cand[threadIdx.x + u * kTrainThreads], requested by the caller together with the state (before n_cand was known:
 // entries past n_cand are stale and unused), which takes the gather of the unmirrored tail from three round trips to two.
+// The sets are empty when this is called (tset_clear, a barrier ago); `with_syms`: the symbol sets are wanted too.
 __device__ __forceinline__ BlockArg block_argmax(const TrainCtx &C, unsigned long long n_cand, unsigned long long n_synced, TieSets &S,
-                                                 const uint32_t (&spec)[kCandRegs]) {
+                                                 const uint32_t (&spec)[kCandRegs], bool with_syms) {
   if (n_cand <= (unsigned long long)kTrainThreads * kCandRegs) {
     long long v[kCandRegs];
     unsigned long long key[kCandRegs];
@@ -1151,12 +1163,10 @@ __device__ __forceinline__ BlockArg block_argmax(const TrainCtx &C, unsigned lon
     }
     const BlockArg a = block_reduce(m, c, k);
     if (a.tied >= 2 && a.tied <= kTieSet && a.mx) {
-      tset_clear(S);
-      __syncthreads();
       if ((unsigned long long)lm == a.mx) {
 #pragma unroll
         for (int u = 0; u < kCandRegs; u++)
-          if (key[u] != kEmptyKey) tset_insert(S, key[u], (uint32_t)(threadIdx.x + u * kTrainThreads));
+          if (key[u] != kEmptyKey) tset_insert(S, key[u], (uint32_t)(threadIdx.x + u * kTrainThreads), with_syms);
       }
       __syncthreads();
     }
@@ -1171,11 +1181,9 @@ __device__ __forceinline__ BlockArg block_argmax(const TrainCtx &C, unsigned lon
   }
   const BlockArg a = block_reduce(m, c, k);
   if (a.tied >= 2 && a.tied <= kTieSet && a.mx) {
-    tset_clear(S);
-    __syncthreads();
     for (uint64_t i = threadIdx.x; i < n_cand; i += blockDim.x) {
       const uint32_t slot = C.cand[i];
-      if ((unsigned long long)C.T.cnt[slot] == a.mx) tset_insert(S, C.T.keys[slot], (uint32_t)i);
+      if ((unsigned long long)C.T.cnt[slot] == a.mx) tset_insert(S, C.T.keys[slot], (uint32_t)i, with_syms);
     }
     __syncthreads();
   }
@@ -1198,6 +1206,7 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
   if (threadIdx.x == 0) { hdr[0] = st->flags; hdr[1] = st->run_done[par]; hdr[2] = st->halt; }
   const unsigned long long n_cand = st->n_cand, n_synced = st->n_synced, plateau = st->plateau, idx_cursor = st->idx_cursor;
   const unsigned long long n_old = st->n_list[par ^ 1u], n_syms_now = st->n_syms;
+  tset_clear(S, blockIdx.x == gridDim.x - 1);  // while the state travels (the barrier below covers it)
   const uint64_t cursor_w = st->cursor_w;
   uint32_t cand_spec[kCandRegs];  // see block_argmax
 #pragma unroll
@@ -1207,7 +1216,14 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
   }
   __syncthreads();
   const unsigned int flags = (unsigned int)hdr[0];
-  const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+  // The LAST workgroup scans no words: it is the step's planner -- it publishes the maximum, mirrors the new candidates, and
+  // lists the tied pairs with where their words are (what fast_apply_kernel would otherwise look up, two round trips, after
+  // it has chosen) -- all of it beside the scan, not in front of it.
+  // The one before it is the housekeeper: the candidates the last merge pushed get their compact copy, the other half of
+  // gpos[] is wiped for the next step.
+  const bool planner = blockIdx.x == gridDim.x - 1, keeper = blockIdx.x == gridDim.x - 2;
+  const bool lead = planner && threadIdx.x == 0;
+  const unsigned int n_scan = gridDim.x - 2;  // workgroups that scan
   // the step's index segment begins where the log stands (no apply is in flight).  A step that does nothing says so too: its
   // number is taken, and the segment before it ends where this one begins
   if (lead) C.seg_start[C.step] = idx_cursor;
@@ -1231,7 +1247,7 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
   __shared__ uint32_t wbuf_s[kTrainThreads / 64][kTieStage * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t *wbuf = wbuf_s[wave];
-  const uint64_t trip_words = (uint64_t)gridDim.x * (kTrainThreads / 64) * kTieWords;
+  const uint64_t trip_words = (uint64_t)n_scan * (kTrainThreads / 64) * kTieWords;
   const uint64_t wave_off = ((uint64_t)blockIdx.x * (kTrainThreads / 64) + wave) * kTieWords;
   uint64_t wo = 0, s0 = 0, s1 = 0;  // wo: lanes 0..kTieWords hold the bounds of the wave's words
   uint32_t pre[kTieStage];
@@ -1246,8 +1262,8 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
       pre[k_] = at_ < s1 ? sym[at_] : kHole;                                      \
     }                                                                             \
   } while (0)
-  SWT_TIE_FETCH(cursor_w + wave_off);
-  if (blockIdx.x == 0) {
+  if (!planner && !keeper) SWT_TIE_FETCH(cursor_w + wave_off);
+  if (keeper) {
     // the candidates the last merge pushed get their compact copy now (no count moves while this launch runs); every
     // workgroup of THIS launch still gathers them from the table, fast_apply_kernel then moves n_synced up
     for (uint64_t i = n_synced + threadIdx.x; i < n_cand; i += blockDim.x) {
@@ -1256,13 +1272,14 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
       C.ckey[i] = C.T.keys[slot];
       C.cidx[slot] = (uint32_t)i;
     }
-    if (lead) st->n_synced_next = n_cand;
+    if (threadIdx.x == 0) st->n_synced_next = n_cand;
     // the positions the step before the last left in the other half of gpos[] have been read: that half is the next step's
     for (uint64_t i = threadIdx.x; i < n_old; i += blockDim.x)
       C.gpos[(size_t)(par ^ 1u) * C.cand_cap + (C.tied_idx[(par ^ 1u) * kTieSet + i] & 0x7FFFFFFFu)] = kEmptyKey;
+    return;
   }
   SWT_STAMP(ts, 2);
-  const BlockArg a = block_argmax(C, n_cand, n_synced, S, cand_spec);
+  const BlockArg a = block_argmax(C, n_cand, n_synced, S, cand_spec, planner);
   SWT_STAMP(ts, 3);
   const bool dry = a.mx < C.theta && C.theta > 1;
   const unsigned long long mx = a.mx;
@@ -1278,30 +1295,38 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
     if (dry) { atomicOr(&st->flags, kFlagReplan); st->halt = 3; }
   }
 #ifdef SWT_STAMPS
-  if (lead && (dry || a.tied < 2 || a.mx == 0)) {  // no tie: the launch ends here
+  const bool stamper = blockIdx.x == 0 && threadIdx.x == 0;  // a scanning workgroup's view
+  if (stamper && (dry || a.tied < 2 || a.mx == 0)) {  // no tie: the launch ends here
     for (int q = 0; q < 3; q++) atomicAdd(&g_phase[0][5 + q], ts[q + 1] - ts[q]);
     atomicAdd(&g_phase[0][14], 1ull);
   }
   int n_trips = 0;
 #endif
-  if (dry || a.tied < 2 || a.mx == 0) return;
-  if (blockIdx.x == 0 && use_set) {
-    // the tied pairs as a list, for fast_apply_kernel: place in the candidate list | dangerous << 31, and the key
-    __shared__ unsigned int n_listed;
-    if (threadIdx.x == 0) n_listed = 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < kTieSetSlots; i += blockDim.x) {
-      const unsigned long long key = S.key[i];
-      if (key == kEmptyKey) continue;
-      const uint32_t qa = (uint32_t)(key >> 32), qb = (uint32_t)key;
-      const bool danger = symset_has(S.rights, qa) || symset_has(S.lefts, qb);  // a twin pair is its own witness
-      const unsigned int k = atomicAdd(&n_listed, 1u);
-      C.tied_idx[par * kTieSet + k] = S.idx[i] | (danger ? 0x80000000u : 0u);
-      C.tied_key[par * kTieSet + k] = key;
+  if (planner) {
+    if (!dry && a.mx && a.tied < 2) {
+      // one pair holds the maximum: its list, ready for fast_apply_kernel
+      if (threadIdx.x == 0) C.tied_plan[par * kTieSet] = plan_lookup(C, (uint32_t)(a.key >> 32), (uint32_t)a.key);
+    } else if (!dry && a.mx && use_set) {
+      // the tied pairs as a list: place in the candidate list | dangerous << 31, the key, where its words are
+      __shared__ unsigned int n_listed;
+      if (threadIdx.x == 0) n_listed = 0;
+      __syncthreads();
+      for (int i = threadIdx.x; i < kTieSetSlots; i += blockDim.x) {
+        const unsigned long long key = S.key[i];
+        if (key == kEmptyKey) continue;
+        const uint32_t qa = (uint32_t)(key >> 32), qb = (uint32_t)key;
+        const bool danger = symset_has(S.rights, qa) || symset_has(S.lefts, qb);  // a twin pair is its own witness
+        const unsigned int k = atomicAdd(&n_listed, 1u);
+        C.tied_idx[par * kTieSet + k] = S.idx[i] | (danger ? 0x80000000u : 0u);
+        C.tied_key[par * kTieSet + k] = key;
+        C.tied_plan[par * kTieSet + k] = plan_lookup(C, qa, qb);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) st->n_list[par] = n_listed;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) st->n_list[par] = n_listed;
+    return;
   }
+  if (dry || a.tied < 2 || a.mx == 0) return;
   unsigned long long *best = &st->best2[par];
   __shared__ unsigned long long blk_seen;
   __shared__ unsigned int blk_hit;
@@ -1357,7 +1382,7 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
             const unsigned long long got = S.key[h];
             const int slot = got == key ? (int)h : (got == kEmptyKey ? -1 : tset_find(S, key));  // a collision on the first probe: walk on
             if (slot >= 0) {
-              atomicMin(&S.pos[slot], at);
+              atomicMin(&C.gpos[(size_t)par * C.cand_cap + S.idx[slot]], at);  // one address per tied pair: no answer is waited for
               mine = at < mine ? at : mine;
             }
           } else {
@@ -1398,16 +1423,9 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
     if (blk_hit) break;  // later trips only hold later words
   }
 #undef SWT_TIE_FETCH
-  if (use_set) {
-    // what this workgroup saw, to the step's positions (one address per tied pair)
-    for (int i = threadIdx.x; i < kTieSetSlots; i += blockDim.x) {
-      const unsigned long long at = S.pos[i];
-      if (at != kEmptyKey) atomicMin(&C.gpos[(size_t)par * C.cand_cap + S.idx[i]], at);
-    }
-  }
 #ifdef SWT_STAMPS
   SWT_STAMP(ts, 6);
-  if (lead) {  // phases: state loads, mirror + prefetch, argmax (+ set), -, first word scanned, the rest of the trips
+  if (stamper) {  // phases: state loads, mirror + prefetch, argmax (+ set), -, first word scanned, the rest of the trips
     if (n_trips == 0) { ts[4] = ts[3]; ts[5] = ts[3]; ts[7] = ts[3]; }
     for (int q = 0; q < 3; q++) atomicAdd(&g_phase[0][q], ts[q + 1] - ts[q]);
     atomicAdd(&g_phase[0][3], ts[5] - ts[3]);
@@ -1453,26 +1471,30 @@ __global__ __launch_bounds__(kTrainThreads) void fast_apply_kernel(uint32_t *__r
     for (int u = 0; u < (int)kMaxBatch; u++) { P.l[u] = kHole; P.r[u] = kHole; }
   }
   __syncthreads();
+  TiedPlan my_plan{0, 0, 0, 0};  // lane t: the list of tied pair t (the tie launch's planner has looked it up) ...
+  unsigned int my_rank = 0xFFFFFFFFu;  // ... and its place among the pairs that were seen, by position
   if (mx && tied >= 2 && n_list) {
-    // the tied pairs that were seen, by position
+    unsigned int my_k = 0xFFFFFFFFu;
+    unsigned long long my_pos = kEmptyKey;
     if (threadIdx.x < n_list) {
       const uint32_t info = C.tied_idx[par * kTieSet + threadIdx.x];
       const unsigned long long key = C.tied_key[par * kTieSet + threadIdx.x];
-      const unsigned long long pos = C.gpos[(size_t)par * C.cand_cap + (info & 0x7FFFFFFFu)];
-      if (pos != kEmptyKey) {
-        const unsigned int k = atomicAdd(&n_found, 1u);
-        f_pos[k] = pos;
-        f_key[k] = key;
-        f_dng[k] = info >> 31;
+      my_plan = C.tied_plan[par * kTieSet + threadIdx.x];
+      my_pos = C.gpos[(size_t)par * C.cand_cap + (info & 0x7FFFFFFFu)];
+      if (my_pos != kEmptyKey) {
+        my_k = atomicAdd(&n_found, 1u);
+        f_pos[my_k] = my_pos;
+        f_key[my_k] = key;
+        f_dng[my_k] = info >> 31;
       }
     }
     __syncthreads();
     const unsigned int nf = n_found;
-    if (threadIdx.x < nf) {
-      const unsigned long long mine = f_pos[threadIdx.x];
+    if (my_k != 0xFFFFFFFFu) {
       unsigned int rank = 0;
-      for (unsigned int u = 0; u < nf; u++) rank += f_pos[u] < mine ? 1u : 0u;  // positions are distinct
-      if (rank < kMaxBatch) ord[rank] = threadIdx.x;
+      for (unsigned int u = 0; u < nf; u++) rank += f_pos[u] < my_pos ? 1u : 0u;  // positions are distinct
+      my_rank = rank;
+      if (rank < kMaxBatch) ord[rank] = my_k;
     }
     __syncthreads();
     if (threadIdx.x < 64 && nf) {
@@ -1523,7 +1545,12 @@ __global__ __launch_bounds__(kTrainThreads) void fast_apply_kernel(uint32_t *__r
       key = pos != kEmptyKey ? C.wkey[pos >> 32] : kEmptyKey;
       p1_pos = pos;
     }
-    if (key != kEmptyKey) { P.l[0] = (uint32_t)(key >> 32); P.r[0] = (uint32_t)key; P.K = 1; }
+    if (key != kEmptyKey) {
+      P.l[0] = (uint32_t)(key >> 32);
+      P.r[0] = (uint32_t)key;
+      P.K = 1;
+      P.ent0[1] = (flags & kFlagIndexBroken) ? 0ull : (tied >= 2 ? plan_member(C, P, 0) : plan_take(C, P, 0, C.tied_plan[par * kTieSet]));
+    }
   }
   __syncthreads();
   const uint32_t K = P.K;
@@ -1531,11 +1558,11 @@ __global__ __launch_bounds__(kTrainThreads) void fast_apply_kernel(uint32_t *__r
     if (lead) { st->halt = 2; st->run_done[par ^ 1u] = run_done; }
     return;
   }
-  if (threadIdx.x < K && !(flags & kFlagIndexBroken)) P.ent0[threadIdx.x + 1] = plan_member(C, P, (int)threadIdx.x);
+  if (my_rank < K) P.ent0[my_rank + 1] = (flags & kFlagIndexBroken) ? 0ull : plan_take(C, P, (int)my_rank, my_plan);  // lengths ...
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0) {  // ... to running sums
     P.ent0[0] = 0;
-    for (uint32_t q = 0; q < K; q++) P.ent0[q + 1] = (flags & kFlagIndexBroken) ? 0ull : P.ent0[q] + P.ent0[q + 1];
+    for (uint32_t q = 0; q < K; q++) P.ent0[q + 1] += P.ent0[q];
   }
 #ifdef SWT_STAMPS
   if (lead) g_kstep[C.step & (kSpanSteps - 1)] = K;
@@ -1820,6 +1847,7 @@ TrainCtx swt_bpe_trainer::ctx() const {
   C.wkey = d_wkey;
   C.tied_idx = d_tied_idx;
   C.tied_key = d_tied_key;
+  C.tied_plan = d_tied_plan;
   C.gpos = d_gpos;
   C.step = step_no;
   C.pend = sharded ? d_pend : nullptr;
@@ -1919,6 +1947,7 @@ int swt_bpe_trainer::replan() {
     SWT_HIP(hipMalloc((void **)&d_buckets, 512 * 8));
     SWT_HIP(hipMalloc((void **)&d_tied_idx, 2 * kTieSet * 4));
     SWT_HIP(hipMalloc((void **)&d_tied_key, 2 * kTieSet * 8));
+    SWT_HIP(hipMalloc((void **)&d_tied_plan, 2 * kTieSet * sizeof(TiedPlan)));
     SWT_HIP(hipMalloc((void **)&d_gpos, 2 * (size_t)cand_cap * 8));
   }
   if (!d_cidx || cidx_bits != T.bits) {  // one place per table slot
@@ -2199,7 +2228,7 @@ void swt_bpe_trainer::enqueue_fast_step(uint32_t first_merged, uint32_t limit) {
   // every workgroup of the tie launch reads the whole candidate list: few of them for a small corpus, kTieBlocks at most
   // a trip of the tie scan covers 64 words per workgroup (16 lanes a word, kTieWords words a wave)
   const unsigned tie_blocks = grid_for(n_words, 64, kTieBlocks);
-  hipLaunchKernelGGL(fast_tie_kernel, dim3(tie_blocks), dim3(kTrainThreads), 0, stream, d_sym, d_woff, n_words, C, limit);
+  hipLaunchKernelGGL(fast_tie_kernel, dim3(tie_blocks + 2), dim3(kTrainThreads), 0, stream, d_sym, d_woff, n_words, C, limit);  // + housekeeper, planner
   hipLaunchKernelGGL(fast_apply_kernel, dim3(kFastApplyBlocks), dim3(kTrainThreads), 0, stream, d_sym, d_woff, d_freq, n_words, C,
                      d_steplog, first_merged, limit);
 }
@@ -2323,7 +2352,7 @@ void swt_bpe_train_destroy(swt_bpe_trainer *t) {
   (void)hipStreamSynchronize(t->stream);
   for (void *p : {(void *)t->d_sym, (void *)t->d_woff, (void *)t->d_freq, (void *)t->d_st, (void *)t->d_parts, (void *)t->d_cmd,
                   (void *)t->d_steplog, (void *)t->d_sfreq, (void *)t->d_cand, (void *)t->d_ccnt, (void *)t->d_ckey, (void *)t->d_cidx, (void *)t->d_buckets, (void *)t->d_idx_tag,
-                  (void *)t->d_idx_word, (void *)t->d_wstamp, (void *)t->d_wkey, (void *)t->d_tied_idx, (void *)t->d_tied_key, (void *)t->d_gpos, (void *)t->d_sym_alt, (void *)t->d_woff_alt, (void *)t->d_seg_start, (void *)t->d_seg_of, (void *)t->d_pend,
+                  (void *)t->d_idx_word, (void *)t->d_wstamp, (void *)t->d_wkey, (void *)t->d_tied_idx, (void *)t->d_tied_key, (void *)t->d_tied_plan, (void *)t->d_gpos, (void *)t->d_sym_alt, (void *)t->d_woff_alt, (void *)t->d_seg_start, (void *)t->d_seg_of, (void *)t->d_pend,
                   (void *)t->d_tstamp, (void *)t->d_touched, (void *)t->d_block, (void *)t->d_blocks_all, (void *)t->d_tie_line,
                   (void *)t->d_tie_all, (void *)t->d_halt, (void *)t->K.keys, (void *)t->K.start, (void *)t->K.len, (void *)t->K.fill,
                   (void *)t->K.words})

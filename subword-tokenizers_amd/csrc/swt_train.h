@@ -96,6 +96,13 @@ struct K0Index {
   uint32_t bits;
 };
 
+// where the words of a pair are listed: kind 0 nowhere (an empty list), 1 the static index of the initial pairs
+// (K.words + start), 2 a segment of the log (idx_word / idx_tag + start, entries of other pairs told apart by `want`)
+struct TiedPlan {
+  unsigned long long start, n_ent;
+  uint32_t kind, want;
+};
+
 // everything a training kernel needs, by value
 struct TrainCtx {
   PairTable T;
@@ -117,6 +124,7 @@ struct TrainCtx {
   unsigned long long *wkey;  // fast path: the tied pair a tie scan found in word w
   uint32_t *tied_idx;        // fast path, [2][kTieSet]: candidate index of every tied pair | danger << 31 (see fast_tie_kernel)
   unsigned long long *tied_key;  // their keys
+  TiedPlan *tied_plan;       // fast path, [2][kTieSet]: where the words of each tied pair are listed (fast_tie_kernel's planner)
   unsigned long long *gpos;  // fast path, [2][cand_cap]: first position of a tied pair within the scanned words, by candidate index
   uint32_t step;
   long long *pend;         // sharded: per-slot pending deltas (nullptr: deltas go straight into cnt)
@@ -169,6 +177,7 @@ struct swt_bpe_trainer {
   unsigned long long *d_wkey = nullptr;
   uint32_t *d_tied_idx = nullptr;
   unsigned long long *d_tied_key = nullptr, *d_gpos = nullptr;
+  swt::TiedPlan *d_tied_plan = nullptr;
   uint64_t idx_cap = 0;
   unsigned long long *d_seg_start = nullptr;
   uint64_t seg_start_cap = 0;
