@@ -43,6 +43,7 @@
 // then accumulates its deltas per table slot in pend[] and lists the touched slots; the runner packs them into a fixed-size
 // record block, all-gathers the blocks (RCCL) and every rank adds every block to its replica.
 #include <algorithm>
+#include <cstdlib>
 #include <hipcub/hipcub.hpp>
 
 #include "swt_common.h"
@@ -1983,6 +1984,8 @@ int swt_bpe_trainer::replan() {
   if (!any_lower) th = 1;  // everything passes: the list is the whole table, and an empty list means no pair is left
   // a plateau wider than the list (say a million pairs of count 1): full-table argmax until the next re-plan
   theta = above > cand_cap / 2 ? 0 : th;
+  cand_built = above;
+  since_replan = 0;
   const unsigned int flags = h_st.flags & ~kFlagReplan;
   SWT_HIP(hipMemsetAsync(&d_st->n_cand, 0, 8, stream));
   SWT_HIP(hipMemcpyAsync(&d_st->flags, &flags, 4, hipMemcpyHostToDevice, stream));
@@ -2480,8 +2483,7 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
   uint32_t done = 0;
   bool exhausted = false;
   int dry_runs = 0;
-  double per_step = 1.0;   // merges a step of the fast path has carried lately: sizes the next round trip
-  double per_level = 0.0;  // merges per count level lately (0: not seen yet): says when the candidate list will run dry
+  double per_step = 1.0;  // merges a step of the fast path has carried lately: sizes the next round trip
   while (done < max_steps && !exhausted) {
     const uint32_t remaining = max_steps - done;
     // One round trip: `steps` launch sequences that may log up to `cap` merges.  A step of the fast path carries one merge or
@@ -2490,15 +2492,7 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
     uint32_t steps = remaining < kRunBatch ? remaining : kRunBatch;
     uint32_t cap = steps;
     if (maybe_fast) {
-      double want = (double)remaining / per_step * 1.05 + 1.0;
-      // A list that runs dry in mid trip turns the rest of the trip into steps that do nothing (two launches each): the
-      // maximum falls one level at a time, so the levels left above theta say about how many merges the list is good for.
-      // End the trip there -- or, when that is close, take the new threshold now.
-      if (t->cand_valid && t->theta > 1 && per_level > 0.0 && t->h_st.max_count >= t->theta) {
-        const double left = (double)(t->h_st.max_count - t->theta + 1) * per_level * 0.9;
-        if (left < 48.0 && left < (double)remaining) t->cand_valid = false;
-        else if (left / per_step + 1.0 < want) want = left / per_step + 1.0;
-      }
+      const double want = (double)remaining / per_step * 1.05 + 1.0;
       if (want < (double)steps) steps = (uint32_t)want;
       if (steps < 8) steps = remaining < 8 ? remaining : 8;
       double c = (double)steps * per_step * 1.5 + 8.0;
@@ -2519,6 +2513,22 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
       if ((rc = t->replan())) return rc;
     }
     const bool fast = t->theta && maybe_fast;
+    if (fast && t->theta > 1 && t->cand_built) {
+      // A list that runs dry in mid trip turns the rest of the trip into steps that do nothing (two launches each).  A list of
+      // n pairs has been good for about dry_ratio * n merges: the trip ends there, and the next one starts with a new threshold.
+      const double budget = t->dry_ratio * (double)t->cand_built - (double)t->since_replan;
+      if (budget < 24.0 && (double)remaining > budget && t->since_replan) {
+        if (t->dry_ratio < 2.0) t->dry_ratio *= 1.1;  // it never ran dry: the list may be good for more than was thought
+        t->cand_valid = false;
+        continue;  // re-plan now (a cheaper stop than a dry trip)
+      }
+      const double most = budget / per_step + 1.0;
+      if (most < (double)steps) {
+        steps = most < 8.0 ? 8u : (uint32_t)most;
+        if (steps > remaining) steps = remaining;
+        if (cap > steps * kMaxBatch) cap = steps * kMaxBatch;
+      }
+    }
     if (!fast) {
       if (steps > remaining) steps = remaining;
       cap = steps;
@@ -2564,11 +2574,18 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
       t->trace.push_back(hlog[i]);
       done++;
     }
+    if (getenv("SWT_TRAIN_DEBUG"))
+      fprintf(stderr, "trip: steps %u cap %u -> %u merges, stop %llu, per_step %.2f, listed %llu since %llu ratio %.2f, max %llu theta %llu\n", steps, cap,
+              good, stop, per_step, (unsigned long long)t->cand_built, (unsigned long long)t->since_replan, t->dry_ratio,
+              (unsigned long long)(good ? hlog[good - 1].count : 0), (unsigned long long)t->theta);
     t->n_applied += good;
-    if (good && fast && hlog[0].count > hlog[good - 1].count)
-      per_level = (double)good / (double)(hlog[0].count - hlog[good - 1].count + 1);
+    t->since_replan += good;
     if (good && !t->d_sfreq) t->h_st.max_count = hlog[good - 1].count;  // counts never grow: bound for the next batch
     if (stop == 3) {  // the candidate list ran dry: later steps of the batch were no-ops; new theta, go on
+      if (fast && t->theta > 1 && t->cand_built && t->since_replan) {
+        t->dry_ratio = 0.9 * (double)t->since_replan / (double)t->cand_built;
+        t->dry_ratio = t->dry_ratio < 0.3 ? 0.3 : (t->dry_ratio > 2.0 ? 2.0 : t->dry_ratio);
+      }
       t->cand_valid = false;
       if (!good && ++dry_runs > 64) return fail(SWT_ERR_STATE, "the candidate list cannot be rebuilt");
     } else if (stop) {

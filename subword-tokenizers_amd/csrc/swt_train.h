@@ -22,7 +22,10 @@ constexpr uint32_t kTieSet = 256;       // tied pairs a workgroup keeps in its L
 #endif
 constexpr uint32_t kTieBlocks = SWT_TIE_BLOCKS;
 constexpr uint32_t kApplyBlocks = 512;
-constexpr uint32_t kFastApplyBlocks = 128;
+#ifndef SWT_APPLY_BLOCKS
+#define SWT_APPLY_BLOCKS 128
+#endif
+constexpr uint32_t kFastApplyBlocks = SWT_APPLY_BLOCKS;
 constexpr uint32_t kPackBlocks = 16;
 constexpr uint32_t kSegBase = 0xFFFFFFFFu;  // seg_of[]: the id names a symbol of the initial stream
 
@@ -172,6 +175,10 @@ struct swt_bpe_trainer {
   unsigned long long *d_buckets = nullptr;
   bool cand_valid = false;
   uint64_t n_replans = 0;
+  // when will the list run dry?  A list of n pairs has so far been good for about dry_ratio * n merges
+  uint64_t cand_built = 0;    // pairs the last re-plan listed
+  uint64_t since_replan = 0;  // merges since then
+  double dry_ratio = 0.6;
   // index
   uint32_t *d_idx_tag = nullptr, *d_idx_word = nullptr, *d_wstamp = nullptr;
   unsigned long long *d_wkey = nullptr;
