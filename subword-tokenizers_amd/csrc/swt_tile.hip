@@ -75,22 +75,25 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const T *__restrict__ t
   }
 }
 
-// A tile's tokens are contiguous in the output: copy its run and turn local sentence offsets into global ones.
+// A tile's tokens are contiguous in the output: copy its run and turn local sentence offsets into global ones.  A tile holds
+// a few dozen tokens: one WAVE per tile (a workgroup per tile spent most of the launch on dispatching 66 k workgroups).
 __global__ __launch_bounds__(kThreads) void gather_kernel(const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
                                                           uint64_t n_tiles, uint64_t n_sent, const uint32_t *__restrict__ scratch,
                                                           const uint32_t *__restrict__ sent_local, const uint32_t *__restrict__ tile_tok,
                                                           const uint32_t *__restrict__ tile_base, const unsigned long long *__restrict__ blk_base,
                                                           const uint64_t *__restrict__ n_tokens, uint32_t *__restrict__ out_ids,
                                                           uint64_t *__restrict__ out_off) {
-  const uint64_t t = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const uint64_t t = (uint64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (t >= n_tiles) return;
   const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
-  if (t == n_tiles - 1 && threadIdx.x == 0) out_off[n_sent] = *n_tokens;
+  if (t == n_tiles - 1 && lane == 0) out_off[n_sent] = *n_tokens;
   if (s_lo == s_hi) return;
   const uint64_t base = blk_base[t >> 10] + tile_base[t];
   const uint32_t n = tile_tok[t];
   const uint32_t *src = scratch + sent_off[s_lo];
-  for (uint32_t i = threadIdx.x; i < n; i += kThreads) out_ids[base + i] = src[i];
-  for (uint64_t s = s_lo + threadIdx.x; s < s_hi; s += kThreads) out_off[s] = base + sent_local[s];
+  for (uint32_t i = lane; i < n; i += 64) out_ids[base + i] = src[i];
+  for (uint64_t s = s_lo + lane; s < s_hi; s += 64) out_off[s] = base + sent_local[s];
 }
 
 int TileWorkspace::reserve(uint64_t n_bytes, uint64_t n_sent, uint64_t n_tiles) {
@@ -141,7 +144,7 @@ void launch_scan_gather(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_
   unsigned long long *blk_tot = b + 1, *blk_base = b + 1 + nb;
   hipLaunchKernelGGL(tile_scan_kernel<uint32_t>, dim3((unsigned)nb), dim3(1024), 0, st, ws.tile_tok.as<uint32_t>(), n_tiles,
                      ws.tile_base.as<uint32_t>(), blk_tot, blk_base, ticket, d_n_tokens);
-  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)n_tiles), dim3(kThreads), 0, st, d_sent_off, ws.plan.as<uint64_t>(), n_tiles,
+  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n_tiles + kThreads / 64 - 1) / (kThreads / 64))), dim3(kThreads), 0, st, d_sent_off, ws.plan.as<uint64_t>(), n_tiles,
                      n_sent, ws.scratch.as<uint32_t>(), ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(),
                      ws.tile_base.as<uint32_t>(), blk_base, d_n_tokens, d_out_ids, d_out_off);
 }
