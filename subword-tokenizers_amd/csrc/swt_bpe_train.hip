@@ -222,21 +222,42 @@ __device__ __forceinline__ uint32_t k0_find(const K0Index &K, unsigned long long
   }
 }
 
-// pass 0: occurrences per key; pass 1: fill the lists (start[] holds each list's base by then)
+// pass 0: occurrences per key; pass 1: fill the lists (start[] holds each list's base by then).  One lane per word, eight
+// pairs at a time: their probes go out together, then their atomics (a lane that walked its word pair by pair paid two
+// dependent round trips per symbol).
 __global__ __launch_bounds__(kTrainThreads) void k0_pass_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
                                                                 uint64_t n_words, K0Index K, int pass) {
   const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n_words) return;
   const uint64_t b0 = woff[w], b1 = woff[w + 1];
   if (b1 - b0 < 2) return;
-  uint32_t a = sym[b0];
-  for (uint64_t i = b0 + 1; i < b1; i++) {
-    const uint32_t b = sym[i];
-    const uint32_t h = k0_find(K, pair_key(a, b));
-    a = b;
-    if (h == 0xFFFFFFFFu) continue;
-    const uint32_t k = atomicAdd(&K.fill[h], 1u);
-    if (pass == 1) K.words[(uint64_t)K.start[h] + k] = (uint32_t)w;
+  for (uint64_t base = b0; base + 1 < b1; base += 8) {
+    uint32_t s9[9];
+#pragma unroll
+    for (int u = 0; u < 9; u++) s9[u] = base + u < b1 ? sym[base + u] : kHole;
+    unsigned long long key[8], seen[8];
+    uint32_t h[8], got[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      key[u] = base + u + 1 < b1 ? pair_key(s9[u], s9[u + 1]) : kEmptyKey;
+      h[u] = hash_slot(key[u], K.bits);
+      seen[u] = key[u] != kEmptyKey ? K.keys[h[u]] : kEmptyKey;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      if (key[u] == kEmptyKey) { h[u] = 0xFFFFFFFFu; continue; }
+      if (seen[u] != key[u]) h[u] = seen[u] == kEmptyKey ? 0xFFFFFFFFu : k0_find(K, key[u]);  // not at its home slot: walk on
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) got[u] = h[u] != 0xFFFFFFFFu ? atomicAdd(&K.fill[h[u]], 1u) : 0u;
+    if (pass == 1) {
+      uint32_t at[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) at[u] = h[u] != 0xFFFFFFFFu ? K.start[h[u]] : 0u;
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (h[u] != 0xFFFFFFFFu) K.words[(uint64_t)at[u] + got[u]] = (uint32_t)w;
+    }
   }
 }
 

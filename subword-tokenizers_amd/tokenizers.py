@@ -158,16 +158,20 @@ class NaiveBPE(SubwordTokenizer):
             lefts, rights, counts = trainer.run(want, first)
             if len(lefts) < want:
                 exhausted = True  # bpe.py:98-99: no pair left
-            for i in range(len(lefts)):
-                left, right = int(lefts[i]), int(rights[i])
+            # (plain Python ints and local names: this loop runs once per merge, beside a device that needs ~15 us for one)
+            strings, intern, base = syms.strings, syms.intern, N.SYM_BASE
+            vocab_add, merges_append, applied_append, done_add = self.vocab.add, self.merges_list.append, applied.append, done.add
+            for i, (left, right) in enumerate(zip(lefts.tolist(), rights.tolist())):
                 if (left, right) in done:  # symbols only ever merge: a merged pair cannot come back
                     raise RuntimeError("pair histogram inconsistent: %r selected twice" % ((left, right),))
-                done.add((left, right))
-                ls, rs = syms.string(left), syms.string(right)
-                merged = syms.intern(ls + rs)
-                self.vocab.add(ls + rs)  # bpe.py:103
-                self.merges_list.append((ls, rs))  # bpe.py:104
-                applied.append((left, right, merged))
+                done_add((left, right))
+                ls = chr(left) if left < base else strings[left - base]   # _SymbolTable.string
+                rs = chr(right) if right < base else strings[right - base]
+                joined = ls + rs
+                merged = intern(joined)
+                vocab_add(joined)  # bpe.py:103
+                merges_append((ls, rs))  # bpe.py:104
+                applied_append((left, right, merged))
                 if merged != first + i:
                     # two different merges spelled the same string (never observed).  The device
                     # continued with a fresh id; rebuild the state with the right one and carry on from here.
