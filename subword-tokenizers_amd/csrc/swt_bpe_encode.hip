@@ -141,13 +141,24 @@ __device__ __forceinline__ bool bit_at(const unsigned long long *m, uint32_t p) 
 // Packed = true: the table value of a pair is rank << 16 | (merged - SWT_SYM_BASE), so a merge round learns the
 // merged symbol without touching memory (tables below 65,534 merges); false: the value is the rank and the merged
 // symbol is read from merged_of_rank[].
-template <bool Packed, int Cap>
+// Mode: 0 = tiles of running text (plan, sent_local / tile_tok for the scan + gather), 1 = the unique-word pass of the dedup
+// path (every "sentence" is a unique word: rec / drec / uslot), 2 = one workgroup writing the caller's arrays (DirectOut).  A
+// template parameter, not a run-time test: each form keeps only its own arguments in scalar registers (one kernel for all
+// three spilled 44 of them).
+template <bool Packed, int Cap, int Mode>
 __global__ __launch_bounds__(64) void bpe_encode_kernel(
     const uint8_t *__restrict__ text, uint64_t n_bytes, const uint64_t *__restrict__ sent_off,
     const uint64_t *__restrict__ plan, const uint8_t *__restrict__ cls_tab, const BpeSlot *__restrict__ slots,
     uint32_t bits, const uint32_t *__restrict__ merged_of_rank, uint32_t *__restrict__ scratch,
     uint32_t *__restrict__ sent_local, uint32_t *__restrict__ tile_tok, const uint32_t *__restrict__ uslot,
-    unsigned long long *__restrict__ rec, unsigned long long *__restrict__ drec, DirectOut direct, uint32_t dbg) {
+    unsigned long long *__restrict__ rec, unsigned long long *__restrict__ drec, DirectOut direct, uint32_t dbg_arg) {
+#ifdef SWT_ABLATION
+  const uint32_t dbg = dbg_arg;
+#else
+  constexpr uint32_t dbg = 0;  // the ablation switches exist in -DSWT_ABLATION builds only
+  (void)dbg_arg;
+#endif
+  constexpr bool kDirect = Mode == 2, kRec = Mode == 1;
   // uslot/rec/drec (dedup path, every "sentence" s is unique word s): the word's token run -- its place in scratch and its
   // length -- goes straight to drec[s] (dense: stays in L2 for the last pass) and length | s to the word's table slot, and
   // nobody needs a scan or a gather of this launch's output.
@@ -157,9 +168,9 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
   const unsigned long long lt = (1ull << lane) - 1ull;  // lanes below me
   const unsigned long long le = (2ull << lane) - 1ull;  // me and below
   const uint64_t t = blockIdx.x;
-  const uint64_t s_lo = direct.off ? 0 : plan[t], s_hi = direct.off ? direct.n_sent : plan[t + 1];
+  const uint64_t s_lo = kDirect ? 0 : plan[t], s_hi = kDirect ? direct.n_sent : plan[t + 1];
   if (s_lo == s_hi) {
-    if (lane == 0) tile_tok[t] = 0;
+    if (Mode == 0 && lane == 0) tile_tok[t] = 0;
     return;
   }
   {
@@ -298,8 +309,8 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
         uint32_t mine = 0;
         for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
           if (sent_off[s] >= g.end) break;
-          if (direct.off) direct.off[s] = run; else sent_local[s] = run;
-          if (rec) {
+          if (kDirect) direct.off[s] = run; else if (Mode == 0) sent_local[s] = run;
+          if (kRec) {
             drec[s] = (unsigned long long)(span_base + run) | ((unsigned long long)g.ntok << 32);
             rec[uslot[s]] = (unsigned long long)s | ((unsigned long long)g.ntok << 32);
           }
@@ -561,8 +572,8 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
       if (rel > ce || (rel == ce && !last)) break;
       uint32_t e = total;
       if (rel < ce && (rel >> 6) < nblk) e = L.blkpre[rel >> 6] + __popcll(L.vmask[rel >> 6] & ((1ull << (rel & 63)) - 1ull));
-      if (direct.off) direct.off[s] = run + e; else sent_local[s] = run + e;
-      if (rec && rel < ce) {  // a word never straddles the cut, so its end lies in this chunk too
+      if (kDirect) direct.off[s] = run + e; else if (Mode == 0) sent_local[s] = run + e;
+      if (kRec && rel < ce) {  // a word never straddles the cut, so its end lies in this chunk too
         const uint64_t rel2 = sent_off[s + 1] - abase;
         uint32_t e2 = total;
         if (rel2 < ce && (rel2 >> 6) < nblk) e2 = L.blkpre[rel2 >> 6] + __popcll(L.vmask[rel2 >> 6] & ((1ull << (rel2 & 63)) - 1ull));
@@ -579,8 +590,8 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
     __syncthreads();
   }
   if (lane == 0) {
-    if (direct.off) { direct.off[s_hi] = run; *direct.n_tokens = run; }
-    else tile_tok[t] = run;
+    if (kDirect) { direct.off[s_hi] = run; *direct.n_tokens = run; }
+    else if (Mode == 0) tile_tok[t] = run;
   }
 }
 
@@ -623,10 +634,16 @@ template <bool Packed, int Cap>
 static void launch_encode_kernel_as(swt_bpe_table *t, uint64_t n_tiles, const TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes,
                                     const uint64_t *d_sent_off, const uint8_t *d_cls, const uint32_t *d_uslot,
                                     unsigned long long *d_rec, unsigned long long *d_drec, hipStream_t st) {
-  hipLaunchKernelGGL((bpe_encode_kernel<Packed, Cap>), dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
-                     ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, ws.scratch.as<uint32_t>(),
-                     ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, DirectOut{nullptr, nullptr, 0},
-                     (uint32_t)ablation_knob(0));
+  if (d_rec)
+    hipLaunchKernelGGL((bpe_encode_kernel<Packed, Cap, 1>), dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
+                       ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, ws.scratch.as<uint32_t>(),
+                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, DirectOut{nullptr, nullptr, 0},
+                       (uint32_t)ablation_knob(0));
+  else
+    hipLaunchKernelGGL((bpe_encode_kernel<Packed, Cap, 0>), dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
+                       ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, ws.scratch.as<uint32_t>(),
+                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, DirectOut{nullptr, nullptr, 0},
+                       (uint32_t)ablation_knob(0));
 }
 
 extern "C" {
@@ -634,8 +651,8 @@ extern "C" {
 // diagnostics (not part of include/swt.h): resident workgroups per CU the runtime grants the encode kernel
 int swt_debug_occupancy(int which) {
   int n = -1;
-  hipError_t e = which ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<false, kBpeCap>, 64, 0)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<true, kBpeCap>, 64, 0);
+  hipError_t e = which ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<false, kBpeCap, 0>, 64, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<true, kBpeCap, 0>, 64, 0);
   return e == hipSuccess ? n : -(int)e;
 }
 
@@ -735,11 +752,11 @@ static int bpe_encode_direct(swt_bpe_table *t, TileWorkspace &ws, const uint8_t 
     if ((rc = ws.reserve(64, 0, 1))) return rc;
     const DirectOut direct{d_out_off, d_n_tokens, n_sent};
     if (t->packed)
-      hipLaunchKernelGGL((bpe_encode_kernel<true, kBpeCap>), dim3(1), dim3(64), 0, st, d_text, n_bytes, d_sent_off, (const uint64_t *)nullptr, d_cls,
+      hipLaunchKernelGGL((bpe_encode_kernel<true, kBpeCap, 2>), dim3(1), dim3(64), 0, st, d_text, n_bytes, d_sent_off, (const uint64_t *)nullptr, d_cls,
                          t->d_slots, t->bits, t->d_merged, d_out_ids, ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(),
                          (const uint32_t *)nullptr, (unsigned long long *)nullptr, (unsigned long long *)nullptr, direct, 0u);
     else
-      hipLaunchKernelGGL((bpe_encode_kernel<false, kBpeCap>), dim3(1), dim3(64), 0, st, d_text, n_bytes, d_sent_off, (const uint64_t *)nullptr, d_cls,
+      hipLaunchKernelGGL((bpe_encode_kernel<false, kBpeCap, 2>), dim3(1), dim3(64), 0, st, d_text, n_bytes, d_sent_off, (const uint64_t *)nullptr, d_cls,
                          t->d_slots, t->bits, t->d_merged, d_out_ids, ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(),
                          (const uint32_t *)nullptr, (unsigned long long *)nullptr, (unsigned long long *)nullptr, direct, 0u);
     SWT_HIP(hipGetLastError());
