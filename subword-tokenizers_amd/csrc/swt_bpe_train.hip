@@ -44,7 +44,7 @@
 // record block, all-gathers the blocks (RCCL) and every rank adds every block to its replica.
 #include <algorithm>
 #include <cstdlib>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "swt_common.h"
 #include "swt_train.h"
@@ -1942,10 +1942,10 @@ static int squeeze_stream(swt_bpe_trainer *t) {
   unsigned long long *lens = reinterpret_cast<unsigned long long *>(t->d_woff_alt);
   hipLaunchKernelGGL(live_count_kernel, dim3(g), dim3(256), 0, t->stream, t->d_sym, t->d_woff, t->n_words, lens);
   size_t tmp_bytes = 0;
-  SWT_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, lens, lens, (int)(t->n_words + 1), t->stream));
+  SWT_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, lens, lens, 0ull, (size_t)(t->n_words + 1), rocprim::plus<unsigned long long>(), t->stream));
   int rc = t->tmp.reserve(tmp_bytes + 16);
   if (rc) return rc;
-  SWT_HIP(hipcub::DeviceScan::ExclusiveSum(t->tmp.p, tmp_bytes, lens, lens, (int)(t->n_words + 1), t->stream));
+  SWT_HIP(rocprim::exclusive_scan(t->tmp.p, tmp_bytes, lens, lens, 0ull, (size_t)(t->n_words + 1), rocprim::plus<unsigned long long>(), t->stream));
   hipLaunchKernelGGL(squeeze_kernel, dim3(g), dim3(256), 0, t->stream, t->d_sym, t->d_woff, t->d_woff_alt, t->n_words, t->d_sym_alt);
   unsigned long long total = 0;
   SWT_HIP(hipMemcpyAsync(&total, t->d_woff_alt + t->n_words, 8, hipMemcpyDeviceToHost, t->stream));

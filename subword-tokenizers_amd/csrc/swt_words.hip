@@ -16,7 +16,8 @@
 // Words of 255 bytes or more are never matched against each other (each occurrence becomes its own entry with
 // frequency 1): counts are frequency-weighted sums and first-occurrence order is preserved, so the merges are the
 // same (the dedup is an optimisation of the reference's, not part of its semantics).
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "swt_tile.h"
 #include "swt_words.h"
@@ -392,9 +393,9 @@ int device_words_from_text(const uint8_t *d_text, uint64_t n_bytes, const uint64
     hipLaunchKernelGGL(words_collect_kernel, dim3(grid_of(cap, 256, 8192)), dim3(256), 0, 0, T, d_keys, d_vals, d_cnt + 2);
     W_HIP(hipMemcpy(&n_uniq, d_cnt + 2, 8, hipMemcpyDeviceToHost));
     size_t tmp_bytes = 0;
-    W_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, d_vals2, (int)n_uniq, 0, 40));
+    W_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, d_vals2, (size_t)n_uniq, 0u, 40u));
     W_HIP(hipMalloc(&d_tmp, tmp_bytes + 16));
-    W_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_vals, d_vals2, (int)n_uniq, 0, 40));
+    W_HIP(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_vals, d_vals2, (size_t)n_uniq, 0u, 40u));
     (void)hipFree(d_tmp);
     d_tmp = nullptr;
     // symbol counts, offsets, symbols
@@ -405,9 +406,9 @@ int device_words_from_text(const uint8_t *d_text, uint64_t n_bytes, const uint64
                        out->d_freq);
     W_HIP(hipMemset(d_nchar + n_uniq, 0, 4));
     hipLaunchKernelGGL(widen_scan_kernel, dim3(grid_of(n_uniq + 1, 256, 8192)), dim3(256), 0, 0, d_nchar, out->d_woff, n_uniq + 1);
-    W_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, out->d_woff, out->d_woff, (int)(n_uniq + 1)));
+    W_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, out->d_woff, out->d_woff, (uint64_t)0, (size_t)(n_uniq + 1), rocprim::plus<uint64_t>()));
     W_HIP(hipMalloc(&d_tmp, tmp_bytes + 16));
-    W_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, out->d_woff, out->d_woff, (int)(n_uniq + 1)));
+    W_HIP(rocprim::exclusive_scan(d_tmp, tmp_bytes, out->d_woff, out->d_woff, (uint64_t)0, (size_t)(n_uniq + 1), rocprim::plus<uint64_t>()));
     uint64_t n_syms = 0;
     W_HIP(hipMemcpy(&n_syms, out->d_woff + n_uniq, 8, hipMemcpyDeviceToHost));
     W_HIP(hipMalloc((void **)&out->d_sym, (n_syms + 16) * 4));
