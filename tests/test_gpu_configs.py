@@ -60,6 +60,33 @@ def _same_histogram(tr):
     assert np.array_equal(keys[order], uk) and np.array_equal(cnts[order].astype(np.int64), uc)
 
 
+# ------------------------------------------------------------------------------------------------ configs[1], training half
+
+def test_config1_training_to_8000_all_merges(swt, dev, oracle, synth):
+    """configs[1]'s training half at spec on the S85k-lex stand-in: FastBPE.train to vocab 8,000 -- EVERY merge (7,9xx of them, most
+    of them taken several per step from plateaus of tied pairs, with re-plans and stream squeezes in between), the vocabulary
+    and the final symbol stream against the oracle's full recount per merge (bpe.py:88-111)."""
+    sents = synth.s85k()
+    tok = swt.FastBPE()
+    tok.train(sents, 8000)
+    orc = oracle.OracleBPETrainer(sents)
+    orc.run(8000)
+    want = [tuple(m) for m in orc.merges_list]
+    got = [tuple(m) for m in tok.merges_list]
+    bad = next((i for i, (a, b) in enumerate(zip(got, want)) if a != b), None)
+    assert bad is None and len(got) == len(want), (bad, len(got), len(want), got[bad] if bad is not None else None, want[bad] if bad is not None else None)
+    assert len(tok.vocab) == orc.vocab_size == 8000
+    gs, go, gf = tok._trainer.export()
+    ws, wo, wf = orc.export()
+    assert np.array_equal(go, wo) and np.array_equal(gf, wf)
+    # symbol ids are labels by first appearance of the merged string on both sides
+    assert np.array_equal(gs, ws)
+    st = tok._trainer.stats()
+    assert st["flags"] & 1 == 0  # the index was never abandoned
+    _same_histogram(tok._trainer)
+    tok.reset()
+
+
 # ------------------------------------------------------------------------------------------------ configs[2]
 
 def test_config2_wp_one_million_sentences(wp30k, oracle, synth):

@@ -12,7 +12,7 @@ N.init(0)
 import ctypes
 ABL = ctypes.CDLL(N._build.LIB_PATH).swt_ablation_knob
 bpe = tokenizers.FastBPE(); bpe.merges_list = list(synth.pretrained_merges()[:8000]); bpe._build_table()
-sents = synth.s85k()
+sents = synth.s85k_open() if os.environ.get("SWT_ABLATE_OPEN") else synth.s85k()
 text, off = N.pack_utf8([s.lower() for s in sents])
 nb, ns = int(text.size), len(sents)
 d_text = torch.from_numpy(text.copy()).cuda(); d_off = torch.from_numpy(off.view(np.int64).copy()).cuda()
