@@ -1296,8 +1296,14 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
     }
     if (threadIdx.x == 0) st->n_synced_next = n_cand;
     // the positions the step before the last left in the other half of gpos[] have been read: that half is the next step's
-    for (uint64_t i = threadIdx.x; i < n_old; i += blockDim.x)
-      C.gpos[(size_t)(par ^ 1u) * C.cand_cap + (C.tied_idx[(par ^ 1u) * kTieSet + i] & 0x7FFFFFFFu)] = kEmptyKey;
+    for (uint64_t i = threadIdx.x; i < n_old; i += blockDim.x) {
+      const size_t ci = (size_t)(par ^ 1u) * C.cand_cap + (C.tied_idx[(par ^ 1u) * kTieSet + i] & 0x7FFFFFFFu);
+      C.gpos[ci] = kEmptyKey;
+      C.gnb_min[2 * ci] = 0xFFFFFFFFu;
+      C.gnb_min[2 * ci + 1] = 0xFFFFFFFFu;
+      C.gnb_max[2 * ci] = 0u;
+      C.gnb_max[2 * ci + 1] = 0u;
+    }
     return;
   }
   SWT_STAMP(ts, 2);
@@ -1380,6 +1386,7 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
       const uint64_t b0 = __shfl(wo, wi), b1 = __shfl(wo, wi + 1);
       const uint32_t o0 = (uint32_t)(b0 - s0), len = w < n_words ? (uint32_t)(b1 - b0) : 0u;
       uint32_t carry = kHole, carry_i = 0;  // the word's last live symbol before this round of sixteen slots
+      uint32_t carry2 = kHole;              // ... and the live symbol before that one
       bool done = false;                    // table-probe mode: this word has its hit
       for (uint32_t base = 0; __any(base < len && !done); base += 16) {
         const uint32_t p = base + (uint32_t)j;
@@ -1393,6 +1400,14 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
         const uint32_t from = __shfl(y, grp * 16 + src);
         const uint32_t px = below ? from : carry;
         const uint32_t pxi = below ? base + (uint32_t)src : carry_i;
+        // the neighbours of the pair (px, y): the live symbol before px, and the one after y when this round shows it
+        const uint32_t px_of_src = __shfl(px, grp * 16 + src);
+        const uint32_t nb_l = below ? px_of_src : carry2;
+        const uint32_t above = gm & ~((2u << j) - 1u);
+        const int nxt = above ? __builtin_ctz(above) : j;
+        const uint32_t y_of_nxt = __shfl(y, grp * 16 + nxt);
+        const bool r_known = above != 0 || base + 16 >= len;  // else the word goes on behind this round
+        const uint32_t nb_r = above ? y_of_nxt : kHole;
         bool hit = false;  // table-probe mode only
         unsigned long long key = kEmptyKey;
         const unsigned long long at = (unsigned long long)((w << 32) | pxi);
@@ -1404,8 +1419,21 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
             const unsigned long long got = S.key[h];
             const int slot = got == key ? (int)h : (got == kEmptyKey ? -1 : tset_find(S, key));  // a collision on the first probe: walk on
             if (slot >= 0) {
-              atomicMin(&C.gpos[(size_t)par * C.cand_cap + S.idx[slot]], at);  // one address per tied pair: no answer is waited for
+              const size_t ci = (size_t)par * C.cand_cap + S.idx[slot];
+              atomicMin(&C.gpos[ci], at);  // one address per tied pair: no answer is waited for
               mine = at < mine ? at : mine;
+              // What clears a "dangerous" pair (a, b): a new pair (x, ab) reaches the maximum only if EVERY occurrence has x
+              // before it.  An occurrence that starts its word, or whose left neighbour x makes (x, a) a pair that is not
+              // tied, says no for every x (both extremes go in); otherwise x itself goes in, and two different ones say no
+              // as well (min < max).  The same on the right.
+              const bool l_free = nb_l == kHole || tset_find(S, pair_key(nb_l, px)) < 0;
+              atomicMin(&C.gnb_min[2 * ci], l_free ? 0u : nb_l);
+              atomicMax(&C.gnb_max[2 * ci], l_free ? 0xFFFFFFFFu : nb_l);
+              if (r_known) {
+                const bool r_free = nb_r == kHole || tset_find(S, pair_key(y, nb_r)) < 0;
+                atomicMin(&C.gnb_min[2 * ci + 1], r_free ? 0u : nb_r);
+                atomicMax(&C.gnb_max[2 * ci + 1], r_free ? 0xFFFFFFFFu : nb_r);
+              }
             }
           } else {
             hit = (unsigned long long)table_get(C.T, key) == mx;  // a plateau wider than the set: membership by table probe
@@ -1424,8 +1452,8 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
         }
         // the group's last live symbol of this round is the next round's carry
         const int top = gm ? 31 - __builtin_clz(gm) : j;
-        const uint32_t last = __shfl(y, grp * 16 + top);
-        if (gm) { carry = last; carry_i = base + (uint32_t)top; }
+        const uint32_t last = __shfl(y, grp * 16 + top), before_last = __shfl(px, grp * 16 + top);
+        if (gm) { carry = last; carry_i = base + (uint32_t)top; carry2 = before_last; }
       }
       if (!use_set && __any(done)) break;  // the wave's later words are later
     }
@@ -1502,12 +1530,15 @@ __global__ __launch_bounds__(kTrainThreads) void fast_apply_kernel(uint32_t *__r
       const uint32_t info = C.tied_idx[par * kTieSet + threadIdx.x];
       const unsigned long long key = C.tied_key[par * kTieSet + threadIdx.x];
       my_plan = C.tied_plan[par * kTieSet + threadIdx.x];
-      my_pos = C.gpos[(size_t)par * C.cand_cap + (info & 0x7FFFFFFFu)];
+      const size_t ci = (size_t)par * C.cand_cap + (info & 0x7FFFFFFFu);
+      my_pos = C.gpos[ci];
+      const uint32_t l_lo = C.gnb_min[2 * ci], l_hi = C.gnb_max[2 * ci], r_lo = C.gnb_min[2 * ci + 1], r_hi = C.gnb_max[2 * ci + 1];
       if (my_pos != kEmptyKey) {
         my_k = atomicAdd(&n_found, 1u);
         f_pos[my_k] = my_pos;
         f_key[my_k] = key;
-        f_dng[my_k] = info >> 31;
+        // dangerous by the symbol sets, unless the occurrences the scan saw clear it on both sides (twins stay dangerous)
+        f_dng[my_k] = (info >> 31) && !(l_lo < l_hi && r_lo < r_hi && (uint32_t)(key >> 32) != (uint32_t)key);
       }
     }
     __syncthreads();
@@ -1871,6 +1902,8 @@ TrainCtx swt_bpe_trainer::ctx() const {
   C.tied_key = d_tied_key;
   C.tied_plan = d_tied_plan;
   C.gpos = d_gpos;
+  C.gnb_min = d_gnb_min;
+  C.gnb_max = d_gnb_max;
   C.step = step_no;
   C.pend = sharded ? d_pend : nullptr;
   C.tstamp = d_tstamp;
@@ -1971,6 +2004,8 @@ int swt_bpe_trainer::replan() {
     SWT_HIP(hipMalloc((void **)&d_tied_key, 2 * kTieSet * 8));
     SWT_HIP(hipMalloc((void **)&d_tied_plan, 2 * kTieSet * sizeof(TiedPlan)));
     SWT_HIP(hipMalloc((void **)&d_gpos, 2 * (size_t)cand_cap * 8));
+    SWT_HIP(hipMalloc((void **)&d_gnb_min, 4 * (size_t)cand_cap * 4));
+    SWT_HIP(hipMalloc((void **)&d_gnb_max, 4 * (size_t)cand_cap * 4));
   }
   if (!d_cidx || cidx_bits != T.bits) {  // one place per table slot
     if (d_cidx) (void)hipFree(d_cidx);
@@ -2376,7 +2411,7 @@ void swt_bpe_train_destroy(swt_bpe_trainer *t) {
   (void)hipStreamSynchronize(t->stream);
   for (void *p : {(void *)t->d_sym, (void *)t->d_woff, (void *)t->d_freq, (void *)t->d_st, (void *)t->d_parts, (void *)t->d_cmd,
                   (void *)t->d_steplog, (void *)t->d_sfreq, (void *)t->d_cand, (void *)t->d_ccnt, (void *)t->d_ckey, (void *)t->d_cidx, (void *)t->d_buckets, (void *)t->d_idx_tag,
-                  (void *)t->d_idx_word, (void *)t->d_wstamp, (void *)t->d_wkey, (void *)t->d_tied_idx, (void *)t->d_tied_key, (void *)t->d_tied_plan, (void *)t->d_gpos, (void *)t->d_sym_alt, (void *)t->d_woff_alt, (void *)t->d_seg_start, (void *)t->d_seg_of, (void *)t->d_pend,
+                  (void *)t->d_idx_word, (void *)t->d_wstamp, (void *)t->d_wkey, (void *)t->d_tied_idx, (void *)t->d_tied_key, (void *)t->d_tied_plan, (void *)t->d_gpos, (void *)t->d_gnb_min, (void *)t->d_gnb_max, (void *)t->d_sym_alt, (void *)t->d_woff_alt, (void *)t->d_seg_start, (void *)t->d_seg_of, (void *)t->d_pend,
                   (void *)t->d_tstamp, (void *)t->d_touched, (void *)t->d_block, (void *)t->d_blocks_all, (void *)t->d_tie_line,
                   (void *)t->d_tie_all, (void *)t->d_halt, (void *)t->K.keys, (void *)t->K.start, (void *)t->K.len, (void *)t->K.fill,
                   (void *)t->K.words})
@@ -2558,6 +2593,8 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
       SWT_HIP(hipMemsetAsync(&t->d_st->run_done[0], 0, 7 * 8, t->stream));
       SWT_HIP(hipMemsetAsync(&t->d_st->best2[0], 0xFF, 2 * 8, t->stream));  // steps that did nothing may have left either parity behind
       SWT_HIP(hipMemsetAsync(t->d_gpos, 0xFF, 2 * (size_t)t->cand_cap * 8, t->stream));
+      SWT_HIP(hipMemsetAsync(t->d_gnb_min, 0xFF, 4 * (size_t)t->cand_cap * 4, t->stream));
+      SWT_HIP(hipMemsetAsync(t->d_gnb_max, 0, 4 * (size_t)t->cand_cap * 4, t->stream));
     }
     prof_begin(t->stream);  // one bracket around the whole batch of merge steps: bench.py divides by the merges done
     for (uint32_t i = 0; i < steps; i++) {

@@ -128,6 +128,8 @@ struct TrainCtx {
   uint32_t *tied_idx;        // fast path, [2][kTieSet]: candidate index of every tied pair | danger << 31 (see fast_tie_kernel)
   unsigned long long *tied_key;  // their keys
   TiedPlan *tied_plan;       // fast path, [2][kTieSet]: where the words of each tied pair are listed (fast_tie_kernel's planner)
+  uint32_t *gnb_min, *gnb_max;  // fast path, [2][cand_cap][2]: smallest / largest left (0) and right (1) neighbour seen of a tied pair's
+                                // occurrences (fast_tie_kernel: what clears a "dangerous" pair); none seen: min > max
   unsigned long long *gpos;  // fast path, [2][cand_cap]: first position of a tied pair within the scanned words, by candidate index
   uint32_t step;
   long long *pend;         // sharded: per-slot pending deltas (nullptr: deltas go straight into cnt)
@@ -185,6 +187,7 @@ struct swt_bpe_trainer {
   uint32_t *d_tied_idx = nullptr;
   unsigned long long *d_tied_key = nullptr, *d_gpos = nullptr;
   swt::TiedPlan *d_tied_plan = nullptr;
+  uint32_t *d_gnb_min = nullptr, *d_gnb_max = nullptr;
   uint64_t idx_cap = 0;
   unsigned long long *d_seg_start = nullptr;
   uint64_t seg_start_cap = 0;
