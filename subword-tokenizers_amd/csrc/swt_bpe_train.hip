@@ -1631,6 +1631,7 @@ __global__ __launch_bounds__(kTrainThreads) void fast_apply_kernel(uint32_t *__r
     if (tied >= 2 && pos != kEmptyKey) { st->plateau = mx; st->cursor_w = (uint32_t)(pos >> 32); }
     else if (st->plateau != mx) { st->plateau = mx; st->cursor_w = 0; }
     st->run_done[par ^ 1u] = run_done + K;
+    st->run_active += 1;
   }
   if (blockIdx.x == 0 && threadIdx.x < K) {  // one lane per member: its birth step, its log line
     const uint32_t q = threadIdx.x, merged = P.first_m + q;
@@ -2590,7 +2591,7 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
       cap = steps;
     } else {
       // the step counters of the fast path start from zero, and no position of an earlier round trip is left
-      SWT_HIP(hipMemsetAsync(&t->d_st->run_done[0], 0, 7 * 8, t->stream));
+      SWT_HIP(hipMemsetAsync(&t->d_st->run_done[0], 0, 8 * 8, t->stream));
       SWT_HIP(hipMemsetAsync(&t->d_st->best2[0], 0xFF, 2 * 8, t->stream));  // steps that did nothing may have left either parity behind
       SWT_HIP(hipMemsetAsync(t->d_gpos, 0xFF, 2 * (size_t)t->cand_cap * 8, t->stream));
       SWT_HIP(hipMemsetAsync(t->d_gnb_min, 0xFF, 4 * (size_t)t->cand_cap * 4, t->stream));
@@ -2648,10 +2649,11 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
       if (!good && ++dry_runs > 64) return fail(SWT_ERR_STATE, "the candidate list cannot be rebuilt");
     } else if (stop) {
       exhausted = true;  // bpe.py:98-99: no pair left
-    } else if (fast) {
-      // every step ran: what they carried; a round trip that filled its cap could have carried more
-      const double seen = (double)good / (double)steps;
-      per_step = good >= cap ? per_step * 1.5 : (seen < 1.0 ? 1.0 : seen);
+    }
+    if (fast && good && t->h_st.run_active) {
+      // what a working step carried (the steps after a dry point or a full log do nothing and do not count)
+      per_step = (double)good / (double)t->h_st.run_active;
+      if (per_step < 1.0) per_step = 1.0;
       if (per_step > (double)kMaxBatch) per_step = (double)kMaxBatch;
     }
     if (good) dry_runs = 0;

@@ -8,7 +8,7 @@
 namespace swt {
 
 constexpr uint32_t kMaxRunSteps = 4096;  // rows of the step log = merges per host round trip
-constexpr uint32_t kMaxBatch = 8;        // merges ONE step of the fast path may carry: tied pairs that cannot affect each other
+constexpr uint32_t kMaxBatch = 16;       // merges ONE step of the fast path may carry: tied pairs that cannot affect each other
 constexpr uint32_t kRunBatch = 256;     // merges enqueued per host round trip
 constexpr uint32_t kArgParts = 256;     // workgroup partials of an argmax launch (combined by every consumer)
 constexpr uint32_t kCandBlocks = 32;    // cand_argmax_kernel
@@ -58,6 +58,7 @@ struct TrainState {
   unsigned long long win_end;      // tie positions below this (word << 32) lie in the window EVERY workgroup scanned
   unsigned long long n_list[2];    // length of tied_idx[] / tied_key[], by step parity
   unsigned long long step_syms;    // live symbols when the step began (the tie launch notes it: no apply is in flight then)
+  unsigned long long run_active;   // steps of this round trip that carried merges
   // what the merge steps have looked at so far (bench.py's bytes-per-merge model; one lane adds, launches are serial)
   unsigned long long ent_scanned;  // index entries the apply launches went through
   unsigned long long tie_words;    // words the tie scans' first trips covered
