@@ -586,8 +586,14 @@ constexpr int kEmitCap = 10;
 constexpr int kStage = 24;      // stream slots of a word staged in LDS before its walk
 constexpr int kEntryFan = 8;   // index entries a lane looks at per trip of an apply launch
 constexpr int kFlushBatch = 8;
-constexpr int kBigWords = 128;   // ... when a workgroup holds at least this many words of the merge in a trip
-constexpr int kBigMerge = 8192;  // index entries from which an apply launch sums its deltas per pair in LDS first
+#ifndef SWT_BIG_WORDS
+#define SWT_BIG_WORDS 128
+#endif
+constexpr int kBigWords = SWT_BIG_WORDS;   // ... when a workgroup holds at least this many words of the merge in a trip
+#ifndef SWT_BIG_MERGE
+#define SWT_BIG_MERGE 8192
+#endif
+constexpr int kBigMerge = SWT_BIG_MERGE;  // index entries from which an apply launch sums its deltas per pair in LDS first
 constexpr int kAggSlots = kTrainThreads * kStage * 4 / 16;  // (key, sum) slots the staging area holds  // parked deltas whose table probes go out together
 constexpr unsigned long long kEmitNew = 1ull << 63;  // symbol ids stay below 2^31, so bit 63 of a pair key is free
 
