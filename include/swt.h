@@ -82,6 +82,12 @@ int swt_utf8_lower(uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, uin
  * running code-point counts.  Writes byte_off[n_sent + 1] (a code point starts at every byte that is not a continuation
  * byte), lowercases in place and flags as above. */
 int swt_utf8_prepare(uint8_t *text, uint64_t n_bytes, const uint64_t *cp_off, uint64_t n_sent, uint64_t *byte_off, uint8_t *need_host);
+/* And for a host that knows nothing but the strings (Python: "\0".join(texts).encode(), and one bytes.count to make sure the
+ * texts hold no U+0000 of their own): joined = the sentences with ONE zero byte between neighbours (n_joined bytes, exactly
+ * n_sent - 1 of them zero).  Writes the text without the separators (n_joined - (n_sent - 1) bytes, lowercased as above) to
+ * text_out, byte_off[n_sent + 1] and the flags.  SWT_ERR_INVALID when the separators do not add up. */
+int swt_utf8_prepare_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint8_t *text_out, uint64_t *byte_off,
+                            uint8_t *need_host);
 int swt_utf8_lower_dev(uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off, uint64_t n_sent, uint8_t *d_need_host,
                        void *stream);
 

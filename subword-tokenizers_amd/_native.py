@@ -57,6 +57,7 @@ SIGNATURES = {
     "swt_lower_of": (C.c_uint32, [C.c_uint32]),
     "swt_utf8_lower": (C.c_int, [u8p, u64p, C.c_uint64, u8p]),
     "swt_utf8_prepare": (C.c_int, [u8p, C.c_uint64, u64p, C.c_uint64, u64p, u8p]),
+    "swt_utf8_prepare_joined": (C.c_int, [u8p, C.c_uint64, C.c_uint64, u8p, u64p, u8p]),
     "swt_utf8_lower_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "swt_token_histogram": (C.c_int, [u32p, C.c_uint64, C.c_uint32, u64p, u64p]),
     "swt_token_histogram_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -181,23 +182,34 @@ def lower_of(cp):
 
 
 def pack_and_lower(texts):
-    """list[str] -> (uint8 bytes of the LOWERCASED texts, uint64 byte offsets[n+1]).  The host joins and encodes once and
-    counts code points (len(str)); byte offsets and str.lower() come from the device (swt_utf8_prepare); the few sentences
-    it flags are lowercased here and spliced in."""
+    """list[str] -> (uint8 bytes of the LOWERCASED texts, uint64 byte offsets[n+1]).  The host joins (with U+0000 between the
+    texts) and encodes once; the sentence offsets and str.lower() come from the device (swt_utf8_prepare_joined; texts that
+    hold U+0000 themselves go by their code-point lengths, swt_utf8_prepare); the few sentences the device flags are lowercased
+    here and spliced in."""
     n = len(texts)
     if n <= 64 and sum(map(len, texts)) <= 16384:
         # the reference-style call (one sentence, or a few): a device round trip costs more than str.lower() here
         return pack_utf8([t.lower() for t in texts])
-    cp_off = np.zeros(n + 1, dtype=np.uint64)
-    if n:
-        np.cumsum(np.fromiter(map(len, texts), dtype=np.uint64, count=n), out=cp_off[1:])
-    data = "".join(texts).encode("utf-8", "surrogatepass")
-    buf = np.frombuffer(data, dtype=np.uint8).copy() if data else np.zeros(0, dtype=np.uint8)
     off = np.zeros(n + 1, dtype=np.uint64)
-    if n == 0 or buf.size == 0:
-        return buf, off
+    if n == 0:
+        return np.zeros(0, dtype=np.uint8), off
     need = np.zeros(n, dtype=np.uint8)
-    check(lib().swt_utf8_prepare(ptr(buf, u8p), int(buf.size), ptr(cp_off, u64p), n, ptr(off, u64p), ptr(need, u8p)))
+    # one join with U+0000 between the texts and one encode; the device finds the separators (as long as the texts hold no
+    # U+0000 of their own: one bytes.count tells), closes the gaps, lowercases
+    data = "\x00".join(texts).encode("utf-8", "surrogatepass")
+    if len(data) + 1 == n:  # nothing but separators: every text is empty
+        return np.zeros(0, dtype=np.uint8), off
+    if data.count(0) == n - 1:
+        joined = np.frombuffer(data, dtype=np.uint8)
+        buf = np.empty(joined.size - (n - 1), dtype=np.uint8)
+        check(lib().swt_utf8_prepare_joined(ptr(joined, u8p), int(joined.size), n, ptr(buf, u8p), ptr(off, u64p), ptr(need, u8p)))
+    else:
+        # a text with U+0000 in it: code-point lengths tell the sentences apart (len(str) is free, byte lengths are not)
+        cp_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(np.fromiter(map(len, texts), dtype=np.uint64, count=n), out=cp_off[1:])
+        data = "".join(texts).encode("utf-8", "surrogatepass")
+        buf = np.frombuffer(data, dtype=np.uint8).copy()
+        check(lib().swt_utf8_prepare(ptr(buf, u8p), int(buf.size), ptr(cp_off, u64p), n, ptr(off, u64p), ptr(need, u8p)))
     if need.any():
         data = buf.tobytes()
         parts = [texts[i].lower().encode("utf-8", "surrogatepass") if need[i] else data[int(off[i]):int(off[i + 1])] for i in range(n)]

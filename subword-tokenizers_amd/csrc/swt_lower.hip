@@ -149,6 +149,46 @@ __global__ __launch_bounds__(64) void cp_to_byte_kernel(const uint8_t *__restric
   if (lane == 0) byte_off[s] = found;
 }
 
+// ---- sentence offsets from a SEPARATOR -----------------------------------------------------------------------------------
+// Cheaper still for the host: join the strings with U+0000 between them (one call, like the plain join), let the device find
+// the separators, close the gaps and note where every sentence starts.  (The caller has made sure that the text holds no
+// U+0000 of its own: exactly n_sent - 1 zero bytes.)  Same block scheme as above: zero bytes per 1-KiB block, a scan, and
+// a pass that moves every other byte down by the number of separators before it.
+__global__ __launch_bounds__(64) void sep_count_kernel(const uint8_t *__restrict__ text, uint64_t n_bytes, uint32_t *__restrict__ blk_cnt) {
+  const uint64_t b0 = (uint64_t)blockIdx.x * kOffBlock;
+  uint32_t c = 0;
+  for (uint32_t i = threadIdx.x; i < kOffBlock; i += 64) {
+    const uint64_t g = b0 + i;
+    if (g < n_bytes && text[g] == 0) c++;
+  }
+  for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = c;
+}
+
+__global__ __launch_bounds__(64) void sep_split_kernel(const uint8_t *__restrict__ text, uint64_t n_bytes, uint64_t n_sent,
+                                                       const uint32_t *__restrict__ blk_local, const unsigned long long *__restrict__ blk_base,
+                                                       uint8_t *__restrict__ out, uint64_t *__restrict__ byte_off) {
+  const uint64_t b = blockIdx.x, b0 = b * kOffBlock;
+  const int lane = threadIdx.x;
+  uint64_t z = blk_base[b >> 10] + blk_local[b];  // separators before this block
+  if (b == 0 && lane == 0) {
+    byte_off[0] = 0;
+    byte_off[n_sent] = n_bytes - (n_sent ? n_sent - 1 : 0);
+  }
+  for (uint32_t i = 0; i < kOffBlock && b0 + i < n_bytes; i += 64) {
+    const uint64_t g = b0 + i + lane;
+    const uint8_t c = g < n_bytes ? text[g] : (uint8_t)1;
+    const bool sep = g < n_bytes && c == 0;
+    const unsigned long long M = __ballot(sep);
+    const uint64_t mine = z + (uint64_t)__popcll(M & ((1ull << lane) - 1ull));  // separators before this byte
+    if (g < n_bytes) {
+      if (!sep) out[g - mine] = c;
+      else if (mine + 1 < n_sent) byte_off[mine + 1] = g - mine;  // sentence mine + 1 starts behind this separator
+    }
+    z += (uint64_t)__popcll(M);
+  }
+}
+
 }  // namespace swt
 
 using namespace swt;
@@ -217,6 +257,40 @@ int swt_utf8_prepare(uint8_t *text, uint64_t n_bytes, const uint64_t *cp_off, ui
       rc = fail(SWT_ERR_INVALID, "cp_off[n_sent] = %llu is not the number of code points in the text", (unsigned long long)cp_off[n_sent]);
   }
   d_text.release(); d_cp.release(); d_off.release(); d_flag.release(); ws.release();
+  return rc;
+}
+
+int swt_utf8_prepare_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint8_t *text_out, uint64_t *byte_off, uint8_t *need_host) {
+  if (!byte_off || (n_sent && !need_host) || (n_joined && (!joined || !text_out))) return fail(SWT_ERR_INVALID, "null argument");
+  if (n_sent == 0 ? n_joined != 0 : n_joined + 1 < n_sent) return fail(SWT_ERR_INVALID, "fewer bytes than separators");
+  if (n_sent + 1 > 0x7FFFFFFFull) return fail(SWT_ERR_UNSUPPORTED, "too many sentences for one call");
+  int rc = ensure_device();
+  if (rc) return rc;
+  const uint64_t n_bytes = n_joined - (n_sent ? n_sent - 1 : 0);
+  DevBuf d_in, d_text, d_off, d_flag;
+  TileWorkspace ws;
+  const uint64_t n_blocks = n_joined ? (n_joined + kOffBlock - 1) / kOffBlock : 1;
+  if ((rc = d_in.reserve(n_joined + 16)) || (rc = d_text.reserve(n_bytes + 16)) || (rc = d_off.reserve((n_sent + 1) * 8)) ||
+      (rc = d_flag.reserve(n_sent + 16)) || (rc = ws.reserve(0, 0, n_blocks)))
+    return rc;
+  if (n_joined) SWT_HIP(hipMemcpy(d_in.p, joined, n_joined, hipMemcpyHostToDevice));
+  SWT_HIP(hipMemset(d_off.p, 0xFF, (n_sent + 1) * 8));  // a start that no separator announces stays ~0: the caller counted wrong
+  hipLaunchKernelGGL(sep_count_kernel, dim3((unsigned)n_blocks), dim3(64), 0, nullptr, d_in.as<uint8_t>(), n_joined, ws.tile_tok.as<uint32_t>());
+  launch_scan_only(n_blocks, ws, ws.plan.as<uint64_t>(), nullptr);
+  const uint64_t nb = (n_blocks + 1023) / 1024;
+  hipLaunchKernelGGL(sep_split_kernel, dim3((unsigned)n_blocks), dim3(64), 0, nullptr, d_in.as<uint8_t>(), n_joined, n_sent, ws.tile_base.as<uint32_t>(),
+                     ws.blk.as<unsigned long long>() + 1 + nb, d_text.as<uint8_t>(), d_off.as<uint64_t>());
+  SWT_HIP(hipGetLastError());
+  rc = swt_utf8_lower_dev(d_text.as<uint8_t>(), n_bytes, d_off.as<uint64_t>(), n_sent, d_flag.as<uint8_t>(), nullptr);
+  if (!rc) {
+    SWT_HIP(hipMemcpy(byte_off, d_off.p, (n_sent + 1) * 8, hipMemcpyDeviceToHost));
+    if (n_bytes) SWT_HIP(hipMemcpy(text_out, d_text.p, n_bytes, hipMemcpyDeviceToHost));
+    if (n_sent) SWT_HIP(hipMemcpy(need_host, d_flag.p, n_sent, hipMemcpyDeviceToHost));
+    for (uint64_t s = 0; s <= n_sent && !rc; s++)
+      if (byte_off[s] == ~0ull || (s && byte_off[s] < byte_off[s - 1]))
+        rc = fail(SWT_ERR_INVALID, "the joined text does not hold exactly n_sent - 1 separators");
+  }
+  d_in.release(); d_text.release(); d_off.release(); d_flag.release(); ws.release();
   return rc;
 }
 

@@ -682,6 +682,17 @@ def test_train_plateaus_many_merges_per_step(dev, oracle):
             assert carried > 1.2, "the steps carried %.2f merges each: the plateaus were not batched" % carried
 
 
+def test_pack_and_lower_by_separator_and_by_code_points(dev, corpora):
+    """_native.pack_and_lower: the U+0000-joined form (swt_utf8_prepare_joined) and the code-point form (swt_utf8_prepare, taken
+    when a text holds U+0000 itself) both give the bytes and offsets of [t.lower() for t in texts] (utils.py:27)"""
+    base = corpora["pan"][:400] + ["", "ŻÓŁĆ gęślą", "İstanbul ΣΑΣ ς", "a" * 5000, "", "\U0001F600 emoji", " "] + corpora["t5k"][:300]
+    for texts in (base, base + ["nul \x00 inside", "\x00"], [""] * 100, ["x"] * 70, ["", "", "ß" * 9000] + [""] * 70):
+        text, off = dev.pack_and_lower(list(texts))
+        want = [t.lower().encode("utf-8", "surrogatepass") for t in texts]
+        assert off.tolist() == np.concatenate([[0], np.cumsum([len(w) for w in want])]).tolist()
+        assert text.tobytes() == b"".join(want)
+
+
 def _wp_order_cases(golden, ref_dir):
     import json
     for c in golden("wp_train_order.json"):
