@@ -725,6 +725,12 @@ def main():
     if args.warmup is None:
         args.warmup = defaults[1]
 
+    # ONE line on stdout, whatever the libraries print (RCCL writes a version banner to fd 1 when a communicator is made):
+    # everything else goes to stderr, the JSON line to the stdout this process was given
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     torch, dist, rank, world, local = dist_setup(args.gpus)
     fn = {"headline": bench_headline, "bpe_encode": bench_bpe_encode, "wp_encode": bench_wp_encode, "bpe_train": bench_bpe_train,
           "wp_train": bench_wp_train, "bpe_train_1g": bench_bpe_train_words, "mixed_encode": bench_mixed_encode}[args.workload]
@@ -735,7 +741,7 @@ def main():
             "dtype": res.pop("dtype"), "data": "synthetic", "config": res.pop("config")}
     line.update(res)
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=real_stdout, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
