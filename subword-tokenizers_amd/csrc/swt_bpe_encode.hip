@@ -37,8 +37,15 @@ constexpr uint8_t kClsWs = 1, kClsPunct = 2;
 constexpr uint32_t kNoRank = 0xFFFFFFFFu;
 constexpr int kClsLds = 1024;    // code points whose class is served from LDS (64 lanes x 16 B)
 
-constexpr int kBpeTile = 128;   // bytes of sentence starts per tile (256 / 512-byte chunks before: fewer resident waves, 10 % slower)
-constexpr int kBpeCap = 256;    // staged bytes per chunk
+#ifndef SWT_BPE_TILE
+#define SWT_BPE_TILE 192
+#endif
+#ifndef SWT_BPE_CAP
+#define SWT_BPE_CAP 256
+#endif
+constexpr int kBpeTile = SWT_BPE_TILE;   // bytes of sentence starts per tile.  Measured on S85k-open with 256-byte chunks (tools/gpu_enc_sweep.sh):
+                                         // 96: 489 us, 128: 481, 160: 467, 192: 453, 224: 456, 256: 460; 512-byte chunks: 558 (fewer resident waves)
+constexpr int kBpeCap = SWT_BPE_CAP;    // staged bytes per chunk
 constexpr uint64_t kDirectBytes = 1024, kDirectSents = 64;  // up to here one workgroup and one launch do the whole call
 constexpr uint32_t kNoPos = 0xFFFFu;
 
