@@ -35,7 +35,10 @@ struct alignas(16) BpeSlot {
 
 constexpr uint8_t kClsWs = 1, kClsPunct = 2;
 constexpr uint32_t kNoRank = 0xFFFFFFFFu;
-constexpr int kClsLds = 1024;    // code points whose class is served from LDS (64 lanes x 16 B)
+#ifndef SWT_CLS_LDS
+#define SWT_CLS_LDS 1024
+#endif
+constexpr int kClsLds = SWT_CLS_LDS;    // code points whose class is served from LDS (16 B a lane)
 
 #ifndef SWT_BPE_TILE
 #define SWT_BPE_TILE 192
@@ -182,8 +185,10 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
   }
   {
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (cls_tab) v = reinterpret_cast<const uint4 *>(cls_tab)[lane];
-    reinterpret_cast<uint4 *>(L.cls_lo)[lane] = v;
+    if (lane < kClsLds / 16) {
+      if (cls_tab) v = reinterpret_cast<const uint4 *>(cls_tab)[lane];
+      reinterpret_cast<uint4 *>(L.cls_lo)[lane] = v;
+    }
   }
   const uint64_t span_base = sent_off[s_lo], span_end = sent_off[s_hi];
   uint32_t *const tile_out = scratch + span_base;
