@@ -193,6 +193,29 @@ __global__ __launch_bounds__(64) void sep_split_kernel(const uint8_t *__restrict
 
 using namespace swt;
 
+// The device buffers of the host entry points below: grow-only and kept between calls of the calling thread (a call used to
+// pay four or five hipMalloc / hipFree pairs), given back when a call ends holding more than kPrepareKeep bytes, and released
+// on every error path by the guard that owns them.
+namespace {
+constexpr size_t kPrepareKeep = (size_t)256 << 20;
+struct PrepareWs {
+  DevBuf in, text, cp, off, flag;
+  TileWorkspace ws;
+  void release() { in.release(); text.release(); cp.release(); off.release(); flag.release(); ws.release(); }
+  size_t held() const { return in.cap + text.cap + cp.cap + off.cap + flag.cap; }
+  ~PrepareWs() { release(); }
+};
+struct PrepareGuard {  // an error in mid call: nothing of a half-written state is kept
+  PrepareWs &w;
+  bool ok = false;
+  ~PrepareGuard() { if (!ok || w.held() > kPrepareKeep) w.release(); }
+};
+PrepareWs &prepare_ws() {
+  static thread_local PrepareWs w;
+  return w;
+}
+}  // namespace
+
 extern "C" {
 
 uint32_t swt_lower_of(uint32_t cp) { return cp < kNumCodePoints ? host_lower_table()[cp] : cp; }
@@ -240,8 +263,10 @@ int swt_utf8_prepare(uint8_t *text, uint64_t n_bytes, const uint64_t *cp_off, ui
   if (n_sent + 1 > 0x7FFFFFFFull) return fail(SWT_ERR_UNSUPPORTED, "too many sentences for one call");
   int rc = ensure_device();
   if (rc) return rc;
-  DevBuf d_text, d_cp, d_off, d_flag;
-  TileWorkspace ws;
+  PrepareWs &W = prepare_ws();
+  PrepareGuard guard{W};
+  DevBuf &d_text = W.text, &d_cp = W.cp, &d_off = W.off, &d_flag = W.flag;
+  TileWorkspace &ws = W.ws;
   if ((rc = d_text.reserve(n_bytes + 16)) || (rc = d_cp.reserve((n_sent + 1) * 8)) || (rc = d_off.reserve((n_sent + 1) * 8)) ||
       (rc = d_flag.reserve(n_sent + 16)))
     return rc;
@@ -256,7 +281,7 @@ int swt_utf8_prepare(uint8_t *text, uint64_t n_bytes, const uint64_t *cp_off, ui
     if (byte_off[n_sent] != n_bytes)
       rc = fail(SWT_ERR_INVALID, "cp_off[n_sent] = %llu is not the number of code points in the text", (unsigned long long)cp_off[n_sent]);
   }
-  d_text.release(); d_cp.release(); d_off.release(); d_flag.release(); ws.release();
+  guard.ok = rc == SWT_OK;
   return rc;
 }
 
@@ -267,8 +292,10 @@ int swt_utf8_prepare_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n
   int rc = ensure_device();
   if (rc) return rc;
   const uint64_t n_bytes = n_joined - (n_sent ? n_sent - 1 : 0);
-  DevBuf d_in, d_text, d_off, d_flag;
-  TileWorkspace ws;
+  PrepareWs &W = prepare_ws();
+  PrepareGuard guard{W};
+  DevBuf &d_in = W.in, &d_text = W.text, &d_off = W.off, &d_flag = W.flag;
+  TileWorkspace &ws = W.ws;
   const uint64_t n_blocks = n_joined ? (n_joined + kOffBlock - 1) / kOffBlock : 1;
   if ((rc = d_in.reserve(n_joined + 16)) || (rc = d_text.reserve(n_bytes + 16)) || (rc = d_off.reserve((n_sent + 1) * 8)) ||
       (rc = d_flag.reserve(n_sent + 16)) || (rc = ws.reserve(0, 0, n_blocks)))
@@ -290,7 +317,7 @@ int swt_utf8_prepare_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n
       if (byte_off[s] == ~0ull || (s && byte_off[s] < byte_off[s - 1]))
         rc = fail(SWT_ERR_INVALID, "the joined text does not hold exactly n_sent - 1 separators");
   }
-  d_in.release(); d_text.release(); d_off.release(); d_flag.release(); ws.release();
+  guard.ok = rc == SWT_OK;
   return rc;
 }
 
@@ -303,14 +330,16 @@ int swt_utf8_lower(uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, uin
   if (n_bytes && !text) return fail(SWT_ERR_INVALID, "null text");
   int rc = ensure_device();
   if (rc) return rc;
-  DevBuf d_text, d_off, d_flag;
+  PrepareWs &W = prepare_ws();
+  PrepareGuard guard{W};
+  DevBuf &d_text = W.text, &d_off = W.off, &d_flag = W.flag;
   if ((rc = d_text.reserve(n_bytes + 16)) || (rc = d_off.reserve((n_sent + 1) * 8)) || (rc = d_flag.reserve(n_sent + 16))) return rc;
   if (n_bytes) SWT_HIP(hipMemcpy(d_text.p, text, n_bytes, hipMemcpyHostToDevice));
   SWT_HIP(hipMemcpy(d_off.p, sent_off, (n_sent + 1) * 8, hipMemcpyHostToDevice));
   rc = swt_utf8_lower_dev(d_text.as<uint8_t>(), n_bytes, d_off.as<uint64_t>(), n_sent, d_flag.as<uint8_t>(), nullptr);
   if (!rc && n_bytes) SWT_HIP(hipMemcpy(text, d_text.p, n_bytes, hipMemcpyDeviceToHost));
   if (!rc && n_sent) SWT_HIP(hipMemcpy(need_host, d_flag.p, n_sent, hipMemcpyDeviceToHost));
-  d_text.release(); d_off.release(); d_flag.release();
+  guard.ok = rc == SWT_OK;
   return rc;
 }
 
