@@ -2568,7 +2568,10 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
     const uint64_t by_sym = 2 * (t->n_base + t->n_applied + cap + 1) + 1;
     uint64_t per = new_pairs_bound(t, t->h_st.max_count);
     if (t->h_st.max_count == 0 || by_sym < per) per = by_sym;
-    if ((rc = ensure_room(t, per * cap))) return rc;
+    uint64_t extra = per * cap;
+    // (every new pair costs the stream a symbol: a round trip cannot make more than two per live symbol)
+    if (!t->sharded && t->h_st.n_syms && 2 * t->h_st.n_syms + 64 < extra) extra = 2 * t->h_st.n_syms + 64;
+    if ((rc = ensure_room(t, extra))) return rc;
     if ((rc = ensure_steps(t, steps, first_merged + done + cap))) return rc;
     if (!t->cand_valid || (!t->theta && !t->d_sfreq) || t->h_st.n_cand > kCandHigh) {
       // a host stop anyway: when three slots in ten are holes, the stream is rewritten without them
