@@ -198,6 +198,12 @@ typedef struct swt_bpe_trainer swt_bpe_trainer;
  * (source/bpe.py:70-81).  n_base_symbols = number of distinct code points (the initial len(vocab)). */
 int swt_bpe_train_create_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent,
                               swt_bpe_trainer **out);
+/* The same from the sentences joined with ONE zero byte between neighbours (exactly n_sent - 1 zero bytes: the input of
+ * swt_utf8_prepare_joined, which also says what "lowercased" means here): the device finds the separators, lowercases and
+ * takes the census without the prepared text travelling to the host and back.  need_host[n_sent] comes back as from
+ * swt_utf8_lower; when it flags a sentence, *out stays NULL (SWT_OK) and the caller lowercases on the host and uses
+ * swt_bpe_train_create_text. */
+int swt_bpe_train_create_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint8_t *need_host, swt_bpe_trainer **out);
 /* NaiveWP.train's state instead (source/wordpiece.py:44-63): the same split and word dedup, symbols
  * = the word's first code point c and SWT_WP_CONT + c ("##c") for the others, plus exact symbol frequencies.  The handle
  * works with every swt_bpe_train_* call below; the step maximises the likelihood score freq / (f_left * f_right)

@@ -62,6 +62,7 @@ SIGNATURES = {
     "swt_token_histogram": (C.c_int, [u32p, C.c_uint64, C.c_uint32, u64p, u64p]),
     "swt_token_histogram_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "swt_bpe_train_create_text": (C.c_int, [u8p, u64p, C.c_uint64, vpp]),
+    "swt_bpe_train_create_joined": (C.c_int, [u8p, C.c_uint64, C.c_uint64, u8p, vpp]),
     "swt_wp_train_create_text": (C.c_int, [u8p, u64p, C.c_uint64, vpp]),
     "swt_bpe_train_create_words": (C.c_int, [u32p, u64p, u32p, C.c_uint64, vpp]),
     "swt_bpe_train_destroy": (None, [C.c_void_p]),
@@ -368,6 +369,23 @@ class BpeTrainer:
         n_sent = int(sent_off.size - 1)
         check(lib().swt_bpe_train_create_text(ptr(text_u8, u8p), ptr(sent_off, u64p), n_sent, C.byref(h)))
         return cls(h)
+
+    @classmethod
+    def from_texts(cls, texts):
+        """list[str] -> trainer, the prepared text never leaving the device (swt_bpe_train_create_joined); None when the texts do
+        not lend themselves to it (few of them, a U+0000 inside, a code point only the host lowercases): the caller then goes
+        pack_and_lower -> from_text."""
+        n = len(texts)
+        if n <= 64:
+            return None
+        data = "\x00".join(texts).encode("utf-8", "surrogatepass")
+        if len(data) + 1 == n or data.count(0) != n - 1:
+            return None
+        joined = np.frombuffer(data, dtype=np.uint8)
+        need = np.zeros(n, dtype=np.uint8)
+        h = C.c_void_p()
+        check(lib().swt_bpe_train_create_joined(ptr(joined, u8p), int(joined.size), n, ptr(need, u8p), C.byref(h)))
+        return cls(h) if h.value else None
 
     @classmethod
     def from_text_wordpiece(cls, text_u8, sent_off):

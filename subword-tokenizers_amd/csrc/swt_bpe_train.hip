@@ -2364,6 +2364,29 @@ static int words_from_text(const uint8_t *text, const uint64_t *sent_off, uint64
   return SWT_OK;
 }
 
+// The same from the texts joined with U+0000 (swt_utf8_prepare_joined's input): offsets, lowercase and the word census without
+// the prepared text travelling to the host and back.  need_host[s] = 1: sentence s holds a code point only the host lowercases;
+// then *out stays NULL and the caller takes the host-array way.
+int swt_bpe_train_create_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint8_t *need_host, swt_bpe_trainer **out) {
+  if (!out || (n_sent && !need_host) || (n_joined && !joined)) return fail(SWT_ERR_INVALID, "null argument");
+  *out = nullptr;
+  const uint8_t *d_text = nullptr;
+  const uint64_t *d_off = nullptr;
+  uint64_t n_bytes = 0;
+  int rc = prepare_joined_dev(joined, n_joined, n_sent, need_host, &d_text, &d_off, &n_bytes);
+  if (rc) return rc;
+  for (uint64_t s2 = 0; s2 < n_sent; s2++)
+    if (need_host[s2]) return SWT_OK;
+  DeviceWords dw;
+  if ((rc = device_words_from_text(d_text, n_bytes, d_off, n_sent, &dw))) return rc;
+  auto *t = new swt_bpe_trainer();
+  rc = trainer_adopt(t, dw);
+  if (!rc) rc = finish_create(t);  // histogram, index
+  if (rc) { swt_bpe_train_destroy(t); return rc; }
+  *out = t;
+  return SWT_OK;
+}
+
 // bpe.py:70-81 on the device (swt_words.hip): split (utils.py:27), Counter(words) in first-occurrence order, symbolise.
 int swt_bpe_train_create_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, swt_bpe_trainer **out) {
   swt_bpe_trainer *t = nullptr;

@@ -216,6 +216,42 @@ PrepareWs &prepare_ws() {
 }
 }  // namespace
 
+namespace swt {
+// The separator form on the device: the text without its separators, lowercased, and the sentence offsets stay in the calling
+// thread's workspace (valid until its next prepare / lower call) for a consumer on the device (swt_bpe_train_create_joined);
+// need_host[] comes back to the host.  The caller has checked the arguments.
+int prepare_joined_dev(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint8_t *need_host, const uint8_t **d_text,
+                       const uint64_t **d_off, uint64_t *n_bytes_out) {
+  if (n_sent == 0 ? n_joined != 0 : n_joined + 1 < n_sent) return fail(SWT_ERR_INVALID, "fewer bytes than separators");
+  if (n_sent + 1 > 0x7FFFFFFFull) return fail(SWT_ERR_UNSUPPORTED, "too many sentences for one call");
+  int rc = ensure_device();
+  if (rc) return rc;
+  PrepareWs &W = prepare_ws();
+  const uint64_t n_bytes = n_joined - (n_sent ? n_sent - 1 : 0);
+  const uint64_t n_blocks = n_joined ? (n_joined + kOffBlock - 1) / kOffBlock : 1;
+  if ((rc = W.in.reserve(n_joined + 16)) || (rc = W.text.reserve(n_bytes + 64)) || (rc = W.off.reserve((n_sent + 1) * 8)) ||
+      (rc = W.flag.reserve(n_sent + 16)) || (rc = W.ws.reserve(0, 0, n_blocks)))
+    return rc;
+  if (n_joined) SWT_HIP(hipMemcpy(W.in.p, joined, n_joined, hipMemcpyHostToDevice));
+  SWT_HIP(hipMemset(W.off.p, 0xFF, (n_sent + 1) * 8));  // a start that no separator announces stays ~0: the caller counted wrong
+  hipLaunchKernelGGL(sep_count_kernel, dim3((unsigned)n_blocks), dim3(64), 0, nullptr, W.in.as<uint8_t>(), n_joined, W.ws.tile_tok.as<uint32_t>());
+  launch_scan_only(n_blocks, W.ws, W.ws.plan.as<uint64_t>(), nullptr);
+  const uint64_t nb = (n_blocks + 1023) / 1024;
+  hipLaunchKernelGGL(sep_split_kernel, dim3((unsigned)n_blocks), dim3(64), 0, nullptr, W.in.as<uint8_t>(), n_joined, n_sent,
+                     W.ws.tile_base.as<uint32_t>(), W.ws.blk.as<unsigned long long>() + 1 + nb, W.text.as<uint8_t>(), W.off.as<uint64_t>());
+  SWT_HIP(hipGetLastError());
+  uint64_t n_sep = 0;  // the scan's total: with exactly n_sent - 1 separators every sentence start was written once
+  SWT_HIP(hipMemcpy(&n_sep, W.ws.plan.p, 8, hipMemcpyDeviceToHost));
+  if (n_sep != (n_sent ? n_sent - 1 : 0)) return fail(SWT_ERR_INVALID, "the joined text holds %llu separators, not n_sent - 1", (unsigned long long)n_sep);
+  if ((rc = swt_utf8_lower_dev(W.text.as<uint8_t>(), n_bytes, W.off.as<uint64_t>(), n_sent, W.flag.as<uint8_t>(), nullptr))) return rc;
+  if (n_sent) SWT_HIP(hipMemcpy(need_host, W.flag.p, n_sent, hipMemcpyDeviceToHost));
+  if (d_text) *d_text = W.text.as<uint8_t>();
+  if (d_off) *d_off = W.off.as<uint64_t>();
+  if (n_bytes_out) *n_bytes_out = n_bytes;
+  return SWT_OK;
+}
+}  // namespace swt
+
 extern "C" {
 
 uint32_t swt_lower_of(uint32_t cp) { return cp < kNumCodePoints ? host_lower_table()[cp] : cp; }
@@ -287,35 +323,13 @@ int swt_utf8_prepare(uint8_t *text, uint64_t n_bytes, const uint64_t *cp_off, ui
 
 int swt_utf8_prepare_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint8_t *text_out, uint64_t *byte_off, uint8_t *need_host) {
   if (!byte_off || (n_sent && !need_host) || (n_joined && (!joined || !text_out))) return fail(SWT_ERR_INVALID, "null argument");
-  if (n_sent == 0 ? n_joined != 0 : n_joined + 1 < n_sent) return fail(SWT_ERR_INVALID, "fewer bytes than separators");
-  if (n_sent + 1 > 0x7FFFFFFFull) return fail(SWT_ERR_UNSUPPORTED, "too many sentences for one call");
-  int rc = ensure_device();
-  if (rc) return rc;
-  const uint64_t n_bytes = n_joined - (n_sent ? n_sent - 1 : 0);
   PrepareWs &W = prepare_ws();
   PrepareGuard guard{W};
-  DevBuf &d_in = W.in, &d_text = W.text, &d_off = W.off, &d_flag = W.flag;
-  TileWorkspace &ws = W.ws;
-  const uint64_t n_blocks = n_joined ? (n_joined + kOffBlock - 1) / kOffBlock : 1;
-  if ((rc = d_in.reserve(n_joined + 16)) || (rc = d_text.reserve(n_bytes + 16)) || (rc = d_off.reserve((n_sent + 1) * 8)) ||
-      (rc = d_flag.reserve(n_sent + 16)) || (rc = ws.reserve(0, 0, n_blocks)))
-    return rc;
-  if (n_joined) SWT_HIP(hipMemcpy(d_in.p, joined, n_joined, hipMemcpyHostToDevice));
-  SWT_HIP(hipMemset(d_off.p, 0xFF, (n_sent + 1) * 8));  // a start that no separator announces stays ~0: the caller counted wrong
-  hipLaunchKernelGGL(sep_count_kernel, dim3((unsigned)n_blocks), dim3(64), 0, nullptr, d_in.as<uint8_t>(), n_joined, ws.tile_tok.as<uint32_t>());
-  launch_scan_only(n_blocks, ws, ws.plan.as<uint64_t>(), nullptr);
-  const uint64_t nb = (n_blocks + 1023) / 1024;
-  hipLaunchKernelGGL(sep_split_kernel, dim3((unsigned)n_blocks), dim3(64), 0, nullptr, d_in.as<uint8_t>(), n_joined, n_sent, ws.tile_base.as<uint32_t>(),
-                     ws.blk.as<unsigned long long>() + 1 + nb, d_text.as<uint8_t>(), d_off.as<uint64_t>());
-  SWT_HIP(hipGetLastError());
-  rc = swt_utf8_lower_dev(d_text.as<uint8_t>(), n_bytes, d_off.as<uint64_t>(), n_sent, d_flag.as<uint8_t>(), nullptr);
+  uint64_t n_bytes = 0;
+  int rc = swt::prepare_joined_dev(joined, n_joined, n_sent, need_host, nullptr, nullptr, &n_bytes);
   if (!rc) {
-    SWT_HIP(hipMemcpy(byte_off, d_off.p, (n_sent + 1) * 8, hipMemcpyDeviceToHost));
-    if (n_bytes) SWT_HIP(hipMemcpy(text_out, d_text.p, n_bytes, hipMemcpyDeviceToHost));
-    if (n_sent) SWT_HIP(hipMemcpy(need_host, d_flag.p, n_sent, hipMemcpyDeviceToHost));
-    for (uint64_t s = 0; s <= n_sent && !rc; s++)
-      if (byte_off[s] == ~0ull || (s && byte_off[s] < byte_off[s - 1]))
-        rc = fail(SWT_ERR_INVALID, "the joined text does not hold exactly n_sent - 1 separators");
+    SWT_HIP(hipMemcpy(byte_off, W.off.p, (n_sent + 1) * 8, hipMemcpyDeviceToHost));
+    if (n_bytes) SWT_HIP(hipMemcpy(text_out, W.text.p, n_bytes, hipMemcpyDeviceToHost));
   }
   guard.ok = rc == SWT_OK;
   return rc;

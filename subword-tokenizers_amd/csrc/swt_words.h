@@ -16,5 +16,8 @@ struct DeviceWords {
 // utils.py:26-29 split + bpe.py:73-81 Counter/symbolise over lowercased UTF-8 resident in HBM.  The arrays handed
 // back are owned by the caller (hipFree).
 int device_words_from_text(const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off, uint64_t n_sent, DeviceWords *out);
+// swt_lower.hip: U+0000-joined host text -> lowercased text + sentence offsets in the calling thread's device workspace
+int prepare_joined_dev(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint8_t *need_host, const uint8_t **d_text,
+                       const uint64_t **d_off, uint64_t *n_bytes_out);
 
 }  // namespace swt

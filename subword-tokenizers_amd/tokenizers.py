@@ -143,8 +143,11 @@ class NaiveBPE(SubwordTokenizer):
         if not isinstance(max_vocab, int):
             raise TypeError("Maximum vocabulary size must be an integer.")
         self.reset()
-        text, off = N.pack_and_lower(corpus)
-        trainer = N.BpeTrainer.from_text(text, off)  # bpe.py:70-81 (split, Counter, symbolise)
+        text = off = None
+        trainer = N.BpeTrainer.from_texts(corpus)  # bpe.py:70-81 (lower, split, Counter, symbolise), the text staying on the device
+        if trainer is None:
+            text, off = N.pack_and_lower(corpus)
+            trainer = N.BpeTrainer.from_text(text, off)
         syms = _SymbolTable()
         self.vocab.update(chr(int(c)) for c in trainer.base_symbols())  # bpe.py:75
         applied: List[Tuple[int, int, int]] = []  # (left, right, merged) ids in order, for the collision replay
@@ -176,6 +179,8 @@ class NaiveBPE(SubwordTokenizer):
                     # two different merges spelled the same string (never observed).  The device
                     # continued with a fresh id; rebuild the state with the right one and carry on from here.
                     trainer.close()
+                    if text is None:
+                        text, off = N.pack_and_lower(corpus)
                     trainer = N.BpeTrainer.from_text(text, off)
                     for l_, r_, m_ in applied:
                         trainer.apply(l_, r_, m_)

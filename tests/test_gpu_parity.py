@@ -584,6 +584,11 @@ def test_train_device_word_census_edge_shapes(swt, oracle, dev, corpora):
         (["!!!???...,,, a,b;c", "(a)(b)(c)", "a-b-c-d " * 50], 30),
         (["zażółć gęślą jaźń " * 60, "ŻÓŁĆ żółć", "中文 中文 字 字"], 50),
         (corpora["pan"][:150] + ["", " ", "\t"], 200),
+        # more than 64 sentences: the texts go to the device joined with U+0000 (swt_bpe_train_create_joined) ...
+        (corpora["pan"][:120] + ["zażółć gęślą jaźń"] * 5, 150),
+        # ... unless a sentence needs the host's str.lower() (U+0130, final sigma) or holds U+0000 itself
+        (corpora["pan"][:120] + ["İstanbul ΣΑΣ ΌΣΟΣ"] * 3, 150),
+        (corpora["pan"][:120] + ["nul \x00 inside", "\x00"], 150),
     ]
     for corpus, max_vocab in cases:
         tok = swt.NaiveBPE()
