@@ -339,7 +339,10 @@ def bench_headline(args, torch, dist, rank, world, local):
     corpora = [("S85k-lex", synth.sentences(85000, 85000 + rank) if rank else synth.s85k()),
                ("S85k-open", synth.sentences_open(85000, 85000 + rank) if rank else synth.s85k_open())]
     runs = [encode_corpus_bench(args, torch, dist, rank, N, bpe, sents, merges, name, cpu_leg=True) for name, sents in corpora]
-    train = train_bench(args, torch, dist, rank, world, N, corpora[1][1], args.max_vocab or 8000, "S85k-open")
+    # encode: every rank has its own shard-shaped corpus; training: ONE corpus, which the sharded runner cuts into the ranks'
+    # sentence ranges (train_sharded) -- so every rank must hold the same sentences, rank 0's
+    train_sents = corpora[1][1] if rank == 0 else synth.s85k_open()
+    train = train_bench(args, torch, dist, rank, world, N, train_sents, args.max_vocab or 8000, "S85k-open")
     head, other = sorted(runs, key=lambda r: r["mb_s"])
     out = {
         "metric": "FastBPE encode MB/s (value; tokens bit-exact) + BPE train s/1k-merges (train.s_per_1k_merges)",
