@@ -135,6 +135,14 @@ int swt_bpe_table_set_option(swt_bpe_table *t, int option, int value);
 int swt_bpe_encode(swt_bpe_table *t, const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent,
                    uint32_t *out_ids, uint64_t out_cap, uint64_t *out_off, uint64_t *n_tokens, uint32_t flags);
 
+/* Host-buffer form for a caller that holds strings, not offsets (Python's FastBPE.tokenize over a list: bpe.py:245-249 per
+ * text): joined = the sentences with ONE zero byte between neighbours, as for swt_utf8_prepare_joined, NOT yet lowercased.
+ * The device finds the separators, lowercases (utils.py:27) and encodes; the prepared text never travels back to the host.
+ * out_cap >= n_joined is always sufficient.  need_host[n_sent] as from swt_utf8_lower: when it flags a sentence nothing is
+ * encoded, *n_tokens = UINT64_MAX (SWT_OK), and the caller lowercases on the host and uses swt_bpe_encode. */
+int swt_bpe_encode_joined(swt_bpe_table *t, const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint32_t *out_ids,
+                          uint64_t out_cap, uint64_t *out_off, uint64_t *n_tokens, uint8_t *need_host, uint32_t flags);
+
 /* Device-buffer form.  d_out_ids needs room for n_bytes ids (worst case); d_out_off[n_sent+1].
  * d_n_tokens (device, 1 element) receives the total. */
 int swt_bpe_encode_dev(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off,
@@ -165,6 +173,10 @@ int swt_wp_trie_node_path(const swt_wp_trie *t, uint32_t node_id, uint32_t *out,
 
 int swt_wp_encode(swt_wp_trie *t, const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent,
                   uint32_t *out_ids, uint64_t out_cap, uint64_t *out_off, uint8_t *status, uint64_t *n_tokens);
+/* From the sentences joined with ONE zero byte between neighbours, not yet lowercased (wordpiece.py:248 lower() happens on the
+ * device): see swt_bpe_encode_joined, including the meaning of need_host and *n_tokens = UINT64_MAX. */
+int swt_wp_encode_joined(swt_wp_trie *t, const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint32_t *out_ids,
+                         uint64_t out_cap, uint64_t *out_off, uint8_t *status, uint64_t *n_tokens, uint8_t *need_host);
 int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off,
                       uint64_t n_sent, uint32_t *d_out_ids, uint64_t *d_out_off, uint8_t *d_status,
                       uint64_t *d_n_tokens, void *stream);

@@ -69,5 +69,35 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+PYHOST_SRC = os.path.join(CSRC, "swt_pyhost.c")
+PYHOST_PATH = os.path.join(LIB_DIR, "_swt_pyhost.so")
+
+
+def build_pyhost(force=False):
+    """Compile csrc/swt_pyhost.c (list[str] -> joined UTF-8, CPython C API; loaded with ctypes.PyDLL) with the C compiler.
+    Returns its path, or None where no compiler / Python.h is to be had: the callers then join and encode in Python."""
+    import sysconfig
+    os.makedirs(LIB_DIR, exist_ok=True)
+    stamp_path = os.path.join(LIB_DIR, "pyhost.stamp")
+    with open(PYHOST_SRC, "rb") as fh:
+        stamp = hashlib.sha256(fh.read() + sysconfig.get_python_version().encode()).hexdigest()
+    if not force and os.path.exists(PYHOST_PATH) and os.path.exists(stamp_path):
+        with open(stamp_path) as f:
+            if f.read().strip() == stamp:
+                return PYHOST_PATH
+    cc = os.environ.get("CC") or shutil.which("gcc") or shutil.which("cc")
+    inc = sysconfig.get_paths().get("include")
+    if not cc or not inc or not os.path.exists(os.path.join(inc, "Python.h")):
+        return None
+    r = subprocess.run([cc, "-O2", "-Wall", "-shared", "-fPIC", "-I", inc, PYHOST_SRC, "-o", PYHOST_PATH],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        return None
+    with open(stamp_path, "w") as f:
+        f.write(stamp)
+    return PYHOST_PATH
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_pyhost(force=True))

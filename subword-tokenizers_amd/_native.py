@@ -43,6 +43,7 @@ SIGNATURES = {
     "swt_bpe_table_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "swt_wp_trie_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "swt_bpe_encode": (C.c_int, [C.c_void_p, u8p, u64p, C.c_uint64, u32p, C.c_uint64, u64p, u64p, C.c_uint32]),
+    "swt_bpe_encode_joined": (C.c_int, [C.c_void_p, u8p, C.c_uint64, C.c_uint64, u32p, C.c_uint64, u64p, u64p, u8p, C.c_uint32]),
     "swt_bpe_encode_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_uint32, C.c_void_p]),
     "swt_wp_trie_create": (C.c_int, [u32p, u64p, C.c_uint32, vpp]),
@@ -52,6 +53,7 @@ SIGNATURES = {
     "swt_wp_trie_node": (C.c_int, [C.c_void_p, u32p, C.c_uint64, u32p, i32p, u8p, u32p, C.c_uint32, u32p]),
     "swt_wp_trie_node_path": (C.c_int, [C.c_void_p, C.c_uint32, u32p, C.c_uint64, u64p]),
     "swt_wp_encode": (C.c_int, [C.c_void_p, u8p, u64p, C.c_uint64, u32p, C.c_uint64, u64p, u8p, u64p]),
+    "swt_wp_encode_joined": (C.c_int, [C.c_void_p, u8p, C.c_uint64, C.c_uint64, u32p, C.c_uint64, u64p, u8p, u64p, u8p]),
     "swt_wp_encode_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "swt_lower_of": (C.c_uint32, [C.c_uint32]),
@@ -182,6 +184,49 @@ def lower_of(cp):
     return int(lib().swt_lower_of(cp))
 
 
+_pyhost = None
+
+
+def pyhost():
+    """csrc/swt_pyhost.c through ctypes.PyDLL (the GIL stays held), or None where it could not be built."""
+    global _pyhost
+    if _pyhost is None:
+        path = _build.build_pyhost()
+        dll = False
+        if path:
+            try:
+                dll = C.PyDLL(path)
+                dll.swt_py_join_bound.argtypes = [C.py_object]
+                dll.swt_py_join_bound.restype = C.c_longlong
+                dll.swt_py_join_fill.argtypes = [C.py_object, C.c_void_p, C.c_longlong, C.POINTER(C.c_longlong)]
+                dll.swt_py_join_fill.restype = C.c_longlong
+            except OSError:
+                dll = False
+        _pyhost = dll
+    return _pyhost or None
+
+
+def join_texts(texts, error="Text must be a string."):
+    """list[str] -> (uint8 array: the UTF-8 (surrogatepass) of the texts with ONE zero byte between neighbours, the number of
+    U+0000 inside the texts).  TypeError(error) when an item is not a str.  One pass over the strings in C where
+    csrc/swt_pyhost.c could be built, str.join + str.encode otherwise."""
+    h = pyhost()
+    if h is not None:
+        bound = h.swt_py_join_bound(texts)
+        if bound < 0:
+            raise TypeError(error)
+        buf = np.empty(bound + 32, dtype=np.uint8)
+        n_nul = C.c_longlong()
+        w = h.swt_py_join_fill(texts, buf.ctypes.data, bound + 32, C.byref(n_nul))
+        if w < 0:
+            raise RuntimeError("swt_py_join_fill: the list changed during the call")
+        return buf[:w], int(n_nul.value)
+    if not all(isinstance(t, str) for t in texts):
+        raise TypeError(error)
+    data = "\x00".join(texts).encode("utf-8", "surrogatepass")
+    return np.frombuffer(data, dtype=np.uint8), data.count(0) - max(len(texts) - 1, 0)
+
+
 def pack_and_lower(texts):
     """list[str] -> (uint8 bytes of the LOWERCASED texts, uint64 byte offsets[n+1]).  The host joins (with U+0000 between the
     texts) and encodes once; the sentence offsets and str.lower() come from the device (swt_utf8_prepare_joined; texts that
@@ -195,13 +240,12 @@ def pack_and_lower(texts):
     if n == 0:
         return np.zeros(0, dtype=np.uint8), off
     need = np.zeros(n, dtype=np.uint8)
-    # one join with U+0000 between the texts and one encode; the device finds the separators (as long as the texts hold no
-    # U+0000 of their own: one bytes.count tells), closes the gaps, lowercases
-    data = "\x00".join(texts).encode("utf-8", "surrogatepass")
-    if len(data) + 1 == n:  # nothing but separators: every text is empty
+    # one join with U+0000 between the texts; the device finds the separators (as long as the texts hold no U+0000 of their
+    # own), closes the gaps, lowercases
+    joined, n_nul = join_texts(texts)
+    if joined.size + 1 == n:  # nothing but separators: every text is empty
         return np.zeros(0, dtype=np.uint8), off
-    if data.count(0) == n - 1:
-        joined = np.frombuffer(data, dtype=np.uint8)
+    if n_nul == 0:
         buf = np.empty(joined.size - (n - 1), dtype=np.uint8)
         check(lib().swt_utf8_prepare_joined(ptr(joined, u8p), int(joined.size), n, ptr(buf, u8p), ptr(off, u64p), ptr(need, u8p)))
     else:
@@ -285,6 +329,19 @@ class BpeTable:
                                    ptr(out_off, u64p), C.byref(nt), flags))
         return out[:nt.value], out_off
 
+    def encode_joined(self, joined, n_sent, flags=0):
+        """join_texts' bytes in (not lowercased) -> (ids, offsets), the prepared text staying on the device; None when a sentence
+        needs the host's str.lower() (the caller goes pack_and_lower -> encode)"""
+        out = np.empty(max(int(joined.size), 1), dtype=np.uint32)
+        out_off = np.zeros(n_sent + 1, dtype=np.uint64)
+        need = np.zeros(max(n_sent, 1), dtype=np.uint8)
+        nt = C.c_uint64()
+        check(lib().swt_bpe_encode_joined(self._h, ptr(joined, u8p), int(joined.size), n_sent, ptr(out, u32p), out.size,
+                                          ptr(out_off, u64p), C.byref(nt), ptr(need, u8p), flags))
+        if nt.value == 0xFFFFFFFFFFFFFFFF:
+            return None
+        return out[:nt.value], out_off
+
     def encode_dev(self, d_text, n_bytes, d_off, n_sent, d_out, d_out_off, d_ntok, flags=0, stream=0):
         """device pointers (ints) in; enqueues on `stream` and returns"""
         check(lib().swt_bpe_encode_dev(self._h, d_text, n_bytes, d_off, n_sent, d_out, d_out_off, d_ntok, flags, stream))
@@ -353,6 +410,19 @@ class WpTrie:
                                   ptr(out_off, u64p), ptr(status, u8p), C.byref(nt)))
         return out[:nt.value], out_off, status[:n_sent]
 
+    def encode_joined(self, joined, n_sent):
+        """join_texts' bytes in (not lowercased) -> (ids, offsets, status), or None when a sentence needs the host's str.lower()"""
+        out = np.empty(max(int(joined.size), 1), dtype=np.uint32)
+        out_off = np.zeros(n_sent + 1, dtype=np.uint64)
+        status = np.zeros(max(n_sent, 1), dtype=np.uint8)
+        need = np.zeros(max(n_sent, 1), dtype=np.uint8)
+        nt = C.c_uint64()
+        check(lib().swt_wp_encode_joined(self._h, ptr(joined, u8p), int(joined.size), n_sent, ptr(out, u32p), out.size,
+                                         ptr(out_off, u64p), ptr(status, u8p), C.byref(nt), ptr(need, u8p)))
+        if nt.value == 0xFFFFFFFFFFFFFFFF:
+            return None
+        return out[:nt.value], out_off, status[:n_sent]
+
     def encode_dev(self, d_text, n_bytes, d_off, n_sent, d_out, d_out_off, d_status, d_ntok, stream=0):
         check(lib().swt_wp_encode_dev(self._h, d_text, n_bytes, d_off, n_sent, d_out, d_out_off, d_status, d_ntok, stream))
 
@@ -371,17 +441,16 @@ class BpeTrainer:
         return cls(h)
 
     @classmethod
-    def from_texts(cls, texts):
+    def from_texts(cls, texts, joined=None):
         """list[str] -> trainer, the prepared text never leaving the device (swt_bpe_train_create_joined); None when the texts do
         not lend themselves to it (few of them, a U+0000 inside, a code point only the host lowercases): the caller then goes
-        pack_and_lower -> from_text."""
+        pack_and_lower -> from_text.  joined: join_texts(texts), if the caller has it already."""
         n = len(texts)
         if n <= 64:
             return None
-        data = "\x00".join(texts).encode("utf-8", "surrogatepass")
-        if len(data) + 1 == n or data.count(0) != n - 1:
+        joined, n_nul = joined if joined is not None else join_texts(texts, "Corpus must be a list of strings.")
+        if joined.size + 1 == n or n_nul:
             return None
-        joined = np.frombuffer(data, dtype=np.uint8)
         need = np.zeros(n, dtype=np.uint8)
         h = C.c_void_p()
         check(lib().swt_bpe_train_create_joined(ptr(joined, u8p), int(joined.size), n, ptr(need, u8p), C.byref(h)))

@@ -11,6 +11,7 @@
 
 #include "swt_common.h"
 #include "swt_tile.h"
+#include "swt_words.h"
 #include "unicode_lower.inc"
 
 namespace swt {
@@ -248,6 +249,26 @@ int prepare_joined_dev(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent
   if (d_text) *d_text = W.text.as<uint8_t>();
   if (d_off) *d_off = W.off.as<uint64_t>();
   if (n_bytes_out) *n_bytes_out = n_bytes;
+  return SWT_OK;
+}
+
+int with_prepared_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint8_t *need_host, bool *consumed,
+                         PreparedConsumer consume, void *ctx) {
+  *consumed = false;
+  PrepareWs &W = prepare_ws();
+  PrepareGuard guard{W};
+  const uint8_t *d_text = nullptr;
+  const uint64_t *d_off = nullptr;
+  uint64_t n_bytes = 0;
+  int rc = prepare_joined_dev(joined, n_joined, n_sent, need_host, &d_text, &d_off, &n_bytes);
+  if (rc) return rc;
+  bool host = false;
+  for (uint64_t s2 = 0; s2 < n_sent && !host; s2++) host = need_host[s2] != 0;
+  if (!host) {
+    if ((rc = consume(ctx, d_text, n_bytes, d_off))) return rc;
+    *consumed = true;
+  }
+  guard.ok = true;
   return SWT_OK;
 }
 }  // namespace swt

@@ -1,0 +1,156 @@
+// swt_pyhost.c -- the host side ABOVE the C ABI for a Python caller: list[str] -> the UTF-8 of "\0".join(texts) in one pass
+// over the strings' internal representation (PEP 393), into a buffer the caller owns.  "\0".join(texts).encode("utf-8",
+// "surrogatepass") + the isinstance check + bytes.count cost ~18 ms for the 85,000 sentences of S85k in CPython; this is ~2 ms.
+// Loaded with ctypes.PyDLL (the GIL is held, nothing here calls back into the interpreter).  Not part of libswt_hip.so:
+// that library knows nothing of Python.
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+#include <stdint.h>
+#include <string.h>
+#include <emmintrin.h>  // SSE2: part of every x86-64
+#include <tmmintrin.h>  // SSSE3: used behind __builtin_cpu_supports only
+
+// Upper bound of the joined size in bytes (separators included).  -1: not a list; -2 - i: item i is not a str.
+long long swt_py_join_bound(PyObject *list) {
+  if (!PyList_Check(list)) return -1;
+  const Py_ssize_t n = PyList_GET_SIZE(list);
+  long long total = n;
+  for (Py_ssize_t i = 0; i < n; i++) {
+    PyObject *o = PyList_GET_ITEM(list, i);
+    if (!PyUnicode_Check(o)) return -2 - (long long)i;
+    if (PyUnicode_READY(o) < 0) { PyErr_Clear(); return -2 - (long long)i; }
+    const long long len = PyUnicode_GET_LENGTH(o);
+    if (PyUnicode_IS_ASCII(o)) total += len;
+    else {
+      const int kind = PyUnicode_KIND(o);
+      total += len * (kind == PyUnicode_1BYTE_KIND ? 2 : kind == PyUnicode_2BYTE_KIND ? 3 : 4);
+    }
+  }
+  return total;
+}
+
+static inline uint8_t *put_cp(uint8_t *d, uint32_t c) {
+  if (c < 0x80) { *d++ = (uint8_t)c; }
+  else if (c < 0x800) { *d++ = (uint8_t)(0xC0 | (c >> 6)); *d++ = (uint8_t)(0x80 | (c & 0x3F)); }
+  else if (c < 0x10000) {  // lone surrogates included: errors="surrogatepass"
+    *d++ = (uint8_t)(0xE0 | (c >> 12)); *d++ = (uint8_t)(0x80 | ((c >> 6) & 0x3F)); *d++ = (uint8_t)(0x80 | (c & 0x3F));
+  } else {
+    *d++ = (uint8_t)(0xF0 | (c >> 18)); *d++ = (uint8_t)(0x80 | ((c >> 12) & 0x3F)); *d++ = (uint8_t)(0x80 | ((c >> 6) & 0x3F));
+    *d++ = (uint8_t)(0x80 | (c & 0x3F));
+  }
+  return d;
+}
+
+// Two-byte strings (PEP 393 kind 2: one 'l-stroke' makes the whole sentence two-byte), mostly ASCII in practice.
+// SSE2 form: eight code points at a time, the ASCII runs between the others copied as words.
+static uint8_t *ucs2_sse2(const uint16_t *p, Py_ssize_t len, uint8_t *d) {
+  const __m128i hi = _mm_set1_epi16((short)0xFF80), zero = _mm_setzero_si128();
+  Py_ssize_t k = 0;
+  for (; k + 8 <= len; k += 8) {
+    const __m128i x = _mm_loadu_si128((const __m128i *)(p + k));
+    // bit j: code point j of the eight is not ASCII
+    unsigned m = (unsigned)_mm_movemask_epi8(_mm_packs_epi16(_mm_cmpeq_epi16(_mm_and_si128(x, hi), zero), zero)) ^ 0xFFu;
+    uint64_t asc;  // the eight low bytes (right for the ASCII ones)
+    _mm_storel_epi64((__m128i *)&asc, _mm_packus_epi16(_mm_and_si128(x, _mm_set1_epi16(0x00FF)), zero));
+    unsigned pos = 0;
+    while (m & 0xFFu) {  // ASCII run up to the next other code point (eight bytes stored, the run's length kept), then that one
+      const unsigned j = (unsigned)__builtin_ctz(m);
+      memcpy(d, &asc, 8);
+      d += j - pos;
+      d = put_cp(d, p[k + j]);
+      asc = j + 1 - pos >= 8 ? 0 : asc >> (8 * (j + 1 - pos));
+      pos = j + 1;
+      m &= m - 1;
+    }
+    memcpy(d, &asc, 8);
+    d += 8 - pos;
+  }
+  for (; k < len; k++) d = put_cp(d, p[k]);
+  return d;
+}
+
+// SSSE3 form (every x86-64 server since 2006; chosen at run time): no branch on the data.  Each of eight code points below
+// U+0800 becomes a 16-bit lane holding its one or two UTF-8 bytes, and a byte shuffle picked by the 8-bit "has two bytes" mask
+// closes the gaps; a group with a code point from U+0800 up goes one by one.
+static uint8_t g_shuf[256][16], g_len[256];  // g_len[m] = 8 + the bits set in m (no popcnt instruction in baseline x86-64)
+static int g_shuf_ready;
+static void shuf_init(void) {
+  for (int m = 0; m < 256; m++) {
+    int o = 0;
+    for (int j = 0; j < 8; j++) {
+      g_shuf[m][o++] = (uint8_t)(2 * j);
+      if ((m >> j) & 1) g_shuf[m][o++] = (uint8_t)(2 * j + 1);
+    }
+    g_len[m] = (uint8_t)o;
+    while (o < 16) g_shuf[m][o++] = 0x80;
+  }
+  g_shuf_ready = 1;
+}
+
+__attribute__((target("ssse3"))) static uint8_t *ucs2_ssse3(const uint16_t *p, Py_ssize_t len, uint8_t *d) {
+  const __m128i zero = _mm_setzero_si128();
+  Py_ssize_t k = 0;
+  for (; k + 8 <= len; k += 8) {
+    const __m128i x = _mm_loadu_si128((const __m128i *)(p + k));
+    if (_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_and_si128(x, _mm_set1_epi16((short)0xF800)), zero)) != 0xFFFF) {
+      for (int j = 0; j < 8; j++) d = put_cp(d, p[k + j]);
+      continue;
+    }
+    const __m128i ascii = _mm_cmpeq_epi16(_mm_and_si128(x, _mm_set1_epi16((short)0xFF80)), zero);
+    const unsigned m = (unsigned)_mm_movemask_epi8(_mm_packs_epi16(ascii, zero)) ^ 0xFFu;
+    // low byte 0xC0 | c >> 6, high byte 0x80 | (c & 0x3F)
+    const __m128i two = _mm_or_si128(_mm_or_si128(_mm_srli_epi16(x, 6), _mm_set1_epi16(0x00C0)),
+                                     _mm_slli_epi16(_mm_or_si128(_mm_and_si128(x, _mm_set1_epi16(0x003F)), _mm_set1_epi16(0x0080)), 8));
+    const __m128i v = _mm_or_si128(_mm_and_si128(ascii, x), _mm_andnot_si128(ascii, two));
+    _mm_storeu_si128((__m128i *)d, _mm_shuffle_epi8(v, _mm_loadu_si128((const __m128i *)g_shuf[m])));
+    d += g_len[m];
+  }
+  for (; k < len; k++) d = put_cp(d, p[k]);
+  return d;
+}
+
+// Writes the texts' UTF-8 with ONE zero byte between neighbours to dst (cap >= swt_py_join_bound + 32).  Returns the bytes written;
+// *n_nul = zero code points INSIDE the texts (the separator form needs 0).  -1: the list changed under us / cap too small.
+long long swt_py_join_fill(PyObject *list, uint8_t *dst, long long cap, long long *n_nul) {
+  if (!PyList_Check(list) || !dst || !n_nul) return -1;
+  const Py_ssize_t n = PyList_GET_SIZE(list);
+  uint8_t *d = dst, *const end = dst + cap;
+  const int ssse3 = __builtin_cpu_supports("ssse3");
+  if (ssse3 && !g_shuf_ready) shuf_init();
+  long long nul = 0;
+  for (Py_ssize_t i = 0; i < n; i++) {
+    PyObject *o = PyList_GET_ITEM(list, i);
+    if (!PyUnicode_Check(o) || PyUnicode_READY(o) < 0) { PyErr_Clear(); return -1; }
+    const Py_ssize_t len = PyUnicode_GET_LENGTH(o);
+    const int kind = PyUnicode_KIND(o);
+    const void *data = PyUnicode_DATA(o);
+    if ((long long)(end - d) < (long long)len * (PyUnicode_IS_ASCII(o) ? 1 : kind == 1 ? 2 : kind == 2 ? 3 : 4) + 17) return -1;  // 16 bytes of slack: the vector stores
+    if (i) *d++ = 0;
+    if (PyUnicode_IS_ASCII(o)) {
+      memcpy(d, data, (size_t)len);
+      d += len;
+    } else if (kind == PyUnicode_1BYTE_KIND) {
+      const uint8_t *p = (const uint8_t *)data;
+      for (Py_ssize_t k = 0; k < len; k++) d = put_cp(d, p[k]);
+    } else if (kind == PyUnicode_2BYTE_KIND) {
+      d = ssse3 ? ucs2_ssse3((const uint16_t *)data, len, d) : ucs2_sse2((const uint16_t *)data, len, d);
+    } else {
+      const uint32_t *p = (const uint32_t *)data;
+      for (Py_ssize_t k = 0; k < len; k++) d = put_cp(d, p[k]);
+    }
+  }
+  // a zero byte in UTF-8 is U+0000 and nothing else: what is not a separator came from inside a text
+  {
+    const __m128i zero = _mm_setzero_si128(), one = _mm_set1_epi8(1);
+    __m128i acc = zero;  // two 64-bit sums of the bytes that are zero
+    const uint8_t *q = dst;
+    for (; q + 16 <= d; q += 16)
+      acc = _mm_add_epi64(acc, _mm_sad_epu8(_mm_and_si128(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)q), zero), one), zero));
+    uint64_t part[2];
+    _mm_storeu_si128((__m128i *)part, acc);
+    nul += (long long)(part[0] + part[1]);
+    for (; q < d; q++) nul += *q == 0;
+  }
+  *n_nul = nul - (n ? (long long)(n - 1) : 0);
+  return (long long)(d - dst);
+}

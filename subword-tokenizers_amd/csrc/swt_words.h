@@ -19,5 +19,10 @@ int device_words_from_text(const uint8_t *d_text, uint64_t n_bytes, const uint64
 // swt_lower.hip: U+0000-joined host text -> lowercased text + sentence offsets in the calling thread's device workspace
 int prepare_joined_dev(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint8_t *need_host, const uint8_t **d_text,
                        const uint64_t **d_off, uint64_t *n_bytes_out);
+// The same under the workspace's guard, for an encoder: `consume(ctx, d_text, n_bytes, d_off)` runs on the prepared text unless a
+// sentence needs the host's str.lower() (*consumed says which); the workspace is released if anything fails.
+typedef int (*PreparedConsumer)(void *ctx, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_off);
+int with_prepared_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint8_t *need_host, bool *consumed,
+                         PreparedConsumer consume, void *ctx);
 
 }  // namespace swt

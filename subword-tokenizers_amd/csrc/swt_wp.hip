@@ -16,6 +16,7 @@
 
 #include "swt_dedup.h"
 #include "swt_tile.h"
+#include "swt_words.h"
 
 namespace swt {
 
@@ -774,6 +775,28 @@ int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, c
   return SWT_OK;
 }
 
+// text and offsets on the device -> ids, offsets, statuses and the count in the caller's host arrays
+static int wp_encode_to_host(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_off, uint64_t n_sent,
+                             uint32_t *out_ids, uint64_t out_cap, uint64_t *out_off, uint8_t *status, uint64_t *n_tokens) {
+  int rc;
+  if ((rc = t->out_ids.reserve((n_bytes + 64) * 4))) return rc;
+  if ((rc = t->out_off.reserve((n_sent + 1) * 8))) return rc;
+  if ((rc = t->out_status.reserve(n_sent + 8))) return rc;
+  if ((rc = t->n_tok.reserve(8))) return rc;
+  rc = swt_wp_encode_dev(t, d_text, n_bytes, d_off, n_sent, t->out_ids.as<uint32_t>(), t->out_off.as<uint64_t>(), t->out_status.as<uint8_t>(),
+                         t->n_tok.as<uint64_t>(), nullptr);
+  if (rc) return rc;
+  uint64_t nt = 0;
+  SWT_HIP(hipMemcpy(&nt, t->n_tok.p, 8, hipMemcpyDeviceToHost));
+  *n_tokens = nt;
+  SWT_HIP(hipMemcpy(out_off, t->out_off.p, (n_sent + 1) * 8, hipMemcpyDeviceToHost));
+  if (n_sent) SWT_HIP(hipMemcpy(status, t->out_status.p, n_sent, hipMemcpyDeviceToHost));
+  if (nt > out_cap)
+    return fail(SWT_ERR_CAPACITY, "out_ids too small: need %llu ids, have %llu", (unsigned long long)nt, (unsigned long long)out_cap);
+  if (nt) SWT_HIP(hipMemcpy(out_ids, t->out_ids.p, nt * 4, hipMemcpyDeviceToHost));
+  return SWT_OK;
+}
+
 int swt_wp_encode(swt_wp_trie *t, const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, uint32_t *out_ids,
                   uint64_t out_cap, uint64_t *out_off, uint8_t *status, uint64_t *n_tokens) {
   if (!t || !sent_off || !out_off || !n_tokens || (n_sent && !status)) return fail(SWT_ERR_INVALID, "null argument");
@@ -815,24 +838,27 @@ int swt_wp_encode(swt_wp_trie *t, const uint8_t *text, const uint64_t *sent_off,
   }
   if ((rc = t->in_text.reserve(n_bytes + 64))) return rc;
   if ((rc = t->in_off.reserve((n_sent + 1) * 8))) return rc;
-  if ((rc = t->out_ids.reserve((n_bytes + 64) * 4))) return rc;
-  if ((rc = t->out_off.reserve((n_sent + 1) * 8))) return rc;
-  if ((rc = t->out_status.reserve(n_sent + 8))) return rc;
-  if ((rc = t->n_tok.reserve(8))) return rc;
   if (n_bytes) SWT_HIP(hipMemcpyAsync(t->in_text.p, text, n_bytes, hipMemcpyHostToDevice, 0));
   SWT_HIP(hipMemcpyAsync(t->in_off.p, sent_off, (n_sent + 1) * 8, hipMemcpyHostToDevice, 0));
-  rc = swt_wp_encode_dev(t, t->in_text.as<uint8_t>(), n_bytes, t->in_off.as<uint64_t>(), n_sent, t->out_ids.as<uint32_t>(),
-                         t->out_off.as<uint64_t>(), t->out_status.as<uint8_t>(), t->n_tok.as<uint64_t>(), nullptr);
+  return wp_encode_to_host(t, t->in_text.as<uint8_t>(), n_bytes, t->in_off.as<uint64_t>(), n_sent, out_ids, out_cap, out_off, status, n_tokens);
+}
+
+// list[str] joined with U+0000 -> ids, the prepared text staying on the device (see swt_bpe_encode_joined).
+// *n_tokens = UINT64_MAX on return: a sentence needs the host's str.lower() and nothing was encoded.
+int swt_wp_encode_joined(swt_wp_trie *t, const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint32_t *out_ids, uint64_t out_cap,
+                         uint64_t *out_off, uint8_t *status, uint64_t *n_tokens, uint8_t *need_host) {
+  if (!t || !out_off || !n_tokens || (n_sent && (!need_host || !status)) || (n_joined && !joined)) return fail(SWT_ERR_INVALID, "null argument");
+  int rc = wp_upload(t);
   if (rc) return rc;
-  uint64_t nt = 0;
-  SWT_HIP(hipMemcpy(&nt, t->n_tok.p, 8, hipMemcpyDeviceToHost));
-  *n_tokens = nt;
-  SWT_HIP(hipMemcpy(out_off, t->out_off.p, (n_sent + 1) * 8, hipMemcpyDeviceToHost));
-  if (n_sent) SWT_HIP(hipMemcpy(status, t->out_status.p, n_sent, hipMemcpyDeviceToHost));
-  if (nt > out_cap)
-    return fail(SWT_ERR_CAPACITY, "out_ids too small: need %llu ids, have %llu", (unsigned long long)nt, (unsigned long long)out_cap);
-  if (nt) SWT_HIP(hipMemcpy(out_ids, t->out_ids.p, nt * 4, hipMemcpyDeviceToHost));
-  return SWT_OK;
+  *n_tokens = UINT64_MAX;
+  struct Ctx { swt_wp_trie *t; uint64_t n_sent; uint32_t *out_ids; uint64_t out_cap; uint64_t *out_off; uint8_t *status; uint64_t *n_tokens; };
+  Ctx c{t, n_sent, out_ids, out_cap, out_off, status, n_tokens};
+  bool consumed = false;
+  return with_prepared_joined(joined, n_joined, n_sent, need_host, &consumed,
+      [](void *p, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_off) {
+        Ctx *c = static_cast<Ctx *>(p);
+        return wp_encode_to_host(c->t, d_text, n_bytes, d_off, c->n_sent, c->out_ids, c->out_cap, c->out_off, c->status, c->n_tokens);
+      }, &c);
 }
 
 }  // extern "C"

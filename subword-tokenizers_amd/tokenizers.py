@@ -138,13 +138,18 @@ class NaiveBPE(SubwordTokenizer):
 
     # -- bpe.py:50-112: the merge loop, on the device
     def train(self, corpus: List[str], max_vocab: int = 30_000) -> None:
-        if not isinstance(corpus, list) or not all(isinstance(example, str) for example in corpus):
+        if not isinstance(corpus, list):
+            raise TypeError("Corpus must be a list of strings.")
+        joined = None
+        if len(corpus) > 64:
+            joined = N.join_texts(corpus, "Corpus must be a list of strings.")  # checks the items on its way through them
+        elif not all(isinstance(example, str) for example in corpus):
             raise TypeError("Corpus must be a list of strings.")
         if not isinstance(max_vocab, int):
             raise TypeError("Maximum vocabulary size must be an integer.")
         self.reset()
         text = off = None
-        trainer = N.BpeTrainer.from_texts(corpus)  # bpe.py:70-81 (lower, split, Counter, symbolise), the text staying on the device
+        trainer = N.BpeTrainer.from_texts(corpus, joined)  # bpe.py:70-81 (lower, split, Counter, symbolise), the text staying on the device
         if trainer is None:
             text, off = N.pack_and_lower(corpus)
             trainer = N.BpeTrainer.from_text(text, off)
@@ -292,10 +297,20 @@ class FastBPE(NaiveBPE):
     # -- batch entry points (not in the reference)
     def encode_ids_batch(self, texts: List[str]) -> Tuple[np.ndarray, np.ndarray]:
         """texts -> (token ids uint32, sentence offsets uint64[n+1]); ids as defined in include/swt.h."""
-        if not isinstance(texts, list) or not all(isinstance(t, str) for t in texts):
+        if not isinstance(texts, list):
             raise TypeError("Text must be a string.")
         table = self._ensure_table()
-        text, off = N.pack_and_lower(texts)  # utils.py:27 lower(), on the device (SURVEY.md 8f-2)
+        if len(texts) > 64:
+            # strings -> joined bytes -> ids: the device splits, lowercases (utils.py:27; SURVEY.md 8f-2) and encodes, the
+            # prepared text never comes back.  Texts with U+0000 inside, or that only str.lower() lowercases, go the long way.
+            joined, n_nul = N.join_texts(texts)  # TypeError for an item that is no str
+            if n_nul == 0 and joined.size + 1 != len(texts):
+                got = table.encode_joined(joined, len(texts))
+                if got is not None:
+                    return got
+        elif not all(isinstance(t, str) for t in texts):
+            raise TypeError("Text must be a string.")
+        text, off = N.pack_and_lower(texts)
         return table.encode(text, off)
 
     def tokenize_batch(self, texts: List[str]) -> List[List[str]]:
@@ -592,10 +607,20 @@ class FastWP(NaiveWP):
     # -- batch entry points (not in the reference)
     def encode_ids_batch(self, texts: List[str]):
         """texts -> (ids uint32, offsets uint64[n+1], status uint8[n]); see include/swt.h for ids and status."""
-        if not isinstance(texts, list) or not all(isinstance(t, str) for t in texts):
+        if not isinstance(texts, list):
+            raise TypeError("Text to tokenize must be a string.")
+        if len(texts) <= 64 and not all(isinstance(t, str) for t in texts):
             raise TypeError("Text to tokenize must be a string.")
         if self._trie is None:
+            if not all(isinstance(t, str) for t in texts):
+                raise TypeError("Text to tokenize must be a string.")
             raise AttributeError("'FastWP' object has no attribute 'vocab_trie'")  # as the reference before load/train
+        if len(texts) > 64:
+            joined, n_nul = N.join_texts(texts, "Text to tokenize must be a string.")  # as FastBPE.encode_ids_batch
+            if n_nul == 0 and joined.size + 1 != len(texts):
+                got = self._trie.encode_joined(joined, len(texts))
+                if got is not None:
+                    return got
         text, off = N.pack_and_lower(texts)  # wordpiece.py:248 lower(), on the device; the " " is implicit
         return self._trie.encode(text, off)
 

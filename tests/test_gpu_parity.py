@@ -276,6 +276,61 @@ def test_bpe_duplicate_and_unreachable_merges(swt, oracle, dev):
         assert tok.tokenize(w) == orc.tokenize(w), w
 
 
+def test_joined_entry_points_and_their_fallbacks(swt, dev, bpe, bpe_orc, wp, wp_orc, corpora):
+    """encode_ids_batch on more than 64 texts: strings -> join_texts -> swt_bpe_encode_joined / swt_wp_encode_joined (the
+    prepared text stays on the device); texts that hold U+0000, texts only str.lower() lowercases and all-empty batches take
+    the long way (pack_and_lower -> swt_*_encode) -- same ids either way"""
+    base = corpora["pan"][:150]
+    batches = [
+        base,
+        [t.upper() for t in base],
+        base[:70] + ["a\x00b c"] + base[70:],                    # U+0000 inside a text
+        base[:30] + ["İstanbul ΣΟΦΟΣ STRAẞE"] + base[30:],         # need_host: the device flags the sentence
+        [""] * 100,
+        ["", "x"] * 60,
+        ["\ud800 lone", "\U0001F600 emoji"] + base[:80] + ["中文 字", "é"],
+        ["ł" + "a" * 7, "a" * 7 + "ł", "a" * 8 + "ł", "ł" * 8] * 20,
+    ]
+    for texts in batches:
+        same_bpe(bpe, bpe_orc, texts)
+        same_wp(wp, wp_orc, texts)
+    # the entry points themselves: ids when the device can lowercase everything, None when a sentence needs the host
+    joined, n_nul = dev.join_texts(base)
+    assert n_nul == 0
+    ids, off = bpe._table.encode_joined(joined, len(base))
+    oids, ooff = bpe_orc.tokenize_batch_ids(base)
+    assert np.array_equal(ids, oids) and np.array_equal(off, ooff)
+    joined, _ = dev.join_texts(base[:30] + ["İ"] + base[30:])
+    assert bpe._table.encode_joined(joined, len(base) + 1) is None
+    assert wp._trie.encode_joined(joined, len(base) + 1) is None
+    with pytest.raises(TypeError):
+        bpe.encode_ids_batch(base + [3])
+    with pytest.raises(TypeError):
+        wp.encode_ids_batch(base + [b"x"])
+    # a wrong sentence count is refused, not mis-split
+    with pytest.raises(dev.SwtError):
+        bpe._table.encode_joined(dev.join_texts(base)[0], len(base) + 5)
+
+
+def test_bpe_twin_runs_across_register_sets(swt, oracle, dev):
+    """runs of one symbol ("aaaa...": bpe.py:225-235 merges them left to right, non-overlapping) that start anywhere in the
+    list of a chunk, longer than a wave and across the 64-entry sets of the register rounds"""
+    merges = [("a", "a"), ("aa", "aa"), ("b", "b"), ("a", "b"), ("aaaa", "aa"), ("bb", "b"), ("c", "a"), ("aa", "a")]
+    tok = swt.FastBPE()
+    tok.merges_list = list(merges)
+    tok._build_table()
+    orc = oracle.OracleBPE(merges)
+    texts = []
+    for n in range(1, 190, 3):
+        texts.append("ba " * (n % 7) + "a" * n + " " + "a" * max(1, 150 - n) + "b" * (n % 4))
+        texts.append("ca" * (n % 11) + " " + "b" * n + "a" * (n // 2) + " c" + "a" * (n % 67))
+    texts += ["a" * 63 + " " + "a" * 64 + " " + "a" * 65, "ab " * 20 + "a" * 127, "b" * 3 + " " + "a" * 128 + " " + "a" * 129,
+              "a" * 250, "aaa " * 60, "a" * 191 + " " + "a" * 192 + " " + "a" * 193]
+    same_bpe(tok, orc, texts)
+    for t in texts[:40]:
+        same_bpe(tok, orc, [t])
+
+
 def test_bpe_wide_table_unpacked_path(swt, oracle, dev, bpe, corpora):
     """more than 65,534 merges: the kernel variant whose cached pair value is the bare rank (merged_of_rank[] path)"""
     extra = [(chr(0xE000 + 2 * i), chr(0xE001 + 2 * i)) for i in range(3000)]          # private-use pairs, never in text

@@ -274,3 +274,44 @@ def test_pack_helpers(native):
     assert off.tolist() == [0, 2, 2, 8, 11] and buf.size == 11
     blob, off = native.pack_utf32(["ab", "", "ż"])
     assert off.tolist() == [0, 2, 2, 3] and blob.tolist() == [97, 98, 0x17C]
+
+
+def test_join_texts_is_join_plus_encode(native):
+    """csrc/swt_pyhost.c (one pass over the strings' PEP 393 data) against "\\0".join(texts).encode("utf-8", "surrogatepass"),
+    every string kind, lone surrogates, U+0000 inside texts, and the Python form it stands in for"""
+    import random
+
+    def want(ts):
+        return "\x00".join(ts).encode("utf-8", "surrogatepass"), sum(t.count("\x00") for t in ts)
+
+    assert native.pyhost() is not None, "swt_pyhost.c did not build here (gcc and Python.h are part of the image)"
+    rng = random.Random(11)
+    alphabets = ["abc xyz\x00żłé中\U0001F600\ud800ÿ\x7f\x80߿ࠀ￿\U00010000", "abcdefgh ijklmnoł", "abc", "é\xff a", "\U0001F600a"]
+    cases = [[], [""], ["", ""], ["a"], ["\x00"], ["ł" + "a" * 7, "a" * 7 + "ł", "a" * 8 + "ł" + "\x00" * 9, "ł" * 8, "中" * 17, "a" * 1000]]
+    for trial in range(600):
+        a = alphabets[trial % len(alphabets)]
+        cases.append(["".join(rng.choice(a) for _ in range(rng.randrange(0, 70))) for _ in range(rng.randrange(0, 40))])
+    for ts in cases:
+        joined, n_nul = native.join_texts(ts)
+        data, nul = want(ts)
+        assert joined.tobytes() == data and n_nul == nul, ts
+    saved = native._pyhost
+    try:
+        native._pyhost = False  # the str.join + str.encode form
+        for ts in cases[:60]:
+            joined, n_nul = native.join_texts(ts)
+            data, nul = want(ts)
+            assert joined.tobytes() == data and n_nul == nul, ts
+        with pytest.raises(TypeError, match="Text must be a string"):
+            native.join_texts(["a", 3])
+    finally:
+        native._pyhost = saved
+    with pytest.raises(TypeError, match="Text must be a string"):
+        native.join_texts(["a", b"b", "c"])
+    with pytest.raises(TypeError, match="corpus"):
+        native.join_texts(("a", "b"), "corpus")
+
+    class S(str):
+        pass
+
+    assert native.join_texts([S("ab"), "c"])[0].tobytes() == b"ab\x00c"
