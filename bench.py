@@ -215,9 +215,17 @@ def encode_corpus_bench(args, torch, dist, rank, N, bpe, sents, merges, name, cp
     e2e_s = time.perf_counter() - t1
     if not (np.array_equal(e_ids, ids) and np.array_equal(e_off, offs)):
         raise SystemExit("PARITY FAILURE: encode_ids_batch differs from the device-resident call (%s)" % name)
+    # ... and all the way to the reference's output shape, List[List[str]] (bpe.py:245-249 per text)
+    t1 = time.perf_counter()
+    toks = bpe.tokenize_batch(sents)
+    tb_s = time.perf_counter() - t1
+    probe = len(sents) // 2
+    if len(toks) != len(sents) or toks[probe] != bpe.decode_ids(e_ids[int(e_off[probe]):int(e_off[probe + 1])]):
+        raise SystemExit("PARITY FAILURE: tokenize_batch differs from encode_ids_batch + decode_ids (%s)" % name)
+    del toks
     res["detail"] = {"words": n_words, "distinct_words": n_distinct, "distinct_word_ratio": round(n_distinct / max(n_words, 1), 4),
                      "dedup_call_us": round(per_call_s * 1e6, 2), "no_dedup_ms": round(nd_ms / max(nd_calls, 1), 4),
-                     "end_to_end_mb_s": round(n_bytes / 1e6 / e2e_s, 1),
+                     "end_to_end_mb_s": round(n_bytes / 1e6 / e2e_s, 1), "tokenize_batch_mb_s": round(n_bytes / 1e6 / tb_s, 1),
                      "end_to_end_note": "FastBPE.encode_ids_batch(list[str]) -> ids, second call of this size: strings -> joined UTF-8 (csrc/swt_pyhost.c), H2D, device split/lower + encode (swt_bpe_encode_joined), ids D2H"}
     return res
 

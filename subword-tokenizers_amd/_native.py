@@ -200,6 +200,12 @@ def pyhost():
                 dll.swt_py_join_bound.restype = C.c_longlong
                 dll.swt_py_join_fill.argtypes = [C.py_object, C.c_void_p, C.c_longlong, C.POINTER(C.c_longlong)]
                 dll.swt_py_join_fill.restype = C.c_longlong
+                dll.swt_py_nested.argtypes = [C.py_object, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong]
+                dll.swt_py_nested.restype = C.py_object
+                dll.swt_py_distinct.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p]
+                dll.swt_py_distinct.restype = C.c_longlong
+                dll.swt_py_nested_via.argtypes = [C.py_object, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong]
+                dll.swt_py_nested_via.restype = C.py_object
             except OSError:
                 dll = False
         _pyhost = dll
@@ -225,6 +231,43 @@ def join_texts(texts, error="Text must be a string."):
         raise TypeError(error)
     data = "\x00".join(texts).encode("utf-8", "surrogatepass")
     return np.frombuffer(data, dtype=np.uint8), data.count(0) - max(len(texts) - 1, 0)
+
+
+def nested_lists(table, inv, off):
+    """[[table[inv[k]] for k in range(off[s], off[s + 1])] for s in range(len(off) - 1)]: token strings per sentence, the
+    reference's output shape, from a list of strings, int32 indices into it and uint64 sentence offsets"""
+    inv = np.ascontiguousarray(inv, dtype=np.int32)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    n_sent = int(off.size - 1)
+    h = pyhost()
+    if h is not None:
+        return h.swt_py_nested(table, inv.ctypes.data, int(inv.size), off.ctypes.data, n_sent)
+    if inv.size and (int(inv.min()) < 0 or int(inv.max()) >= len(table)):
+        raise IndexError("token index outside the table")
+    arr = np.empty(len(table), dtype=object)
+    arr[:] = table
+    toks = arr[inv].tolist()
+    return [toks[int(off[i]):int(off[i + 1])] for i in range(n_sent)]
+
+
+def nested_lists_by_key(key, cap, spell, off):
+    """The same for tokens named by sparse keys in [0, cap): spell(k) is called once per DISTINCT key (in order of first
+    appearance) and every sentence gets references to those strings.  key: uint32 array."""
+    key = np.ascontiguousarray(key, dtype=np.uint32)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    h = pyhost()
+    if h is None:
+        if key.size and int(key.max()) >= cap:
+            raise IndexError("token outside the table")
+        uniq, inv = np.unique(key, return_inverse=True)
+        return nested_lists([spell(int(k)) for k in uniq.tolist()], inv, off)
+    pos = np.full(cap, -1, dtype=np.int32)
+    uniq = np.empty(min(cap, max(int(key.size), 1)), dtype=np.uint32)
+    n = h.swt_py_distinct(key.ctypes.data, int(key.size), pos.ctypes.data, cap, uniq.ctypes.data)
+    if n < 0:
+        raise IndexError("token outside the table")
+    table = [spell(k) for k in uniq[:n].tolist()]
+    return h.swt_py_nested_via(table, key.ctypes.data, int(key.size), pos.ctypes.data, cap, off.ctypes.data, int(off.size - 1))
 
 
 def pack_and_lower(texts):

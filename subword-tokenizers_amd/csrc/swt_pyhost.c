@@ -154,3 +154,114 @@ long long swt_py_join_fill(PyObject *list, uint8_t *dst, long long cap, long lon
   *n_nul = nul - (n ? (long long)(n - 1) : 0);
   return (long long)(d - dst);
 }
+
+// ids -> the reference's output shape, List[List[str]]: sentence s gets [table[inv[k]] for k in off[s]..off[s+1]) (new lists, the
+// strings shared).  Returns a new reference, or NULL with an exception set (index out of range, offsets not ascending).
+static PyObject *nested_body(PyObject *table, const int32_t *inv, long long n_inv, const uint64_t *off, long long n_sent) {
+  if (!PyList_Check(table) || n_sent < 0 || n_inv < 0 || (n_sent && !off) || (n_inv && !inv)) {
+    PyErr_SetString(PyExc_ValueError, "swt_py_nested: bad argument");
+    return NULL;
+  }
+  const Py_ssize_t n_tab = PyList_GET_SIZE(table);
+  PyObject *outer = PyList_New((Py_ssize_t)n_sent);
+  if (!outer) return NULL;
+  for (long long s = 0; s < n_sent; s++) {
+    const uint64_t a = off[s], b = off[s + 1];
+    if (a > b || b > (uint64_t)n_inv) {
+      Py_DECREF(outer);
+      PyErr_SetString(PyExc_ValueError, "swt_py_nested: offsets must ascend within the ids");
+      return NULL;
+    }
+    PyObject *inner = PyList_New((Py_ssize_t)(b - a));
+    if (!inner) { Py_DECREF(outer); return NULL; }
+    PyList_SET_ITEM(outer, (Py_ssize_t)s, inner);
+    for (uint64_t k = a; k < b; k++) {
+      const int32_t t = inv[k];
+      if (t < 0 || t >= n_tab) {
+        Py_DECREF(outer);  // the unset slots of `inner` are NULL: list_dealloc copes with them
+        PyErr_SetString(PyExc_IndexError, "swt_py_nested: token index outside the table");
+        return NULL;
+      }
+      PyObject *o = PyList_GET_ITEM(table, t);
+      Py_INCREF(o);
+      PyList_SET_ITEM(inner, (Py_ssize_t)(k - a), o);
+    }
+  }
+  return outer;
+}
+
+// The distinct values of key[0..n) in order of first appearance: pos[key] (all -1 on entry, cap entries) becomes the value's
+// rank, uniq[rank] the value.  Returns how many, -1 for a key outside [0, cap).
+long long swt_py_distinct(const uint32_t *key, long long n, int32_t *pos, long long cap, uint32_t *uniq) {
+  long long cnt = 0;
+  for (long long k = 0; k < n; k++) {
+    const uint32_t v = key[k];
+    if ((long long)v >= cap) return -1;
+    if (pos[v] < 0) {
+      pos[v] = (int32_t)cnt;
+      uniq[cnt++] = v;
+    }
+  }
+  return cnt;
+}
+
+// swt_py_nested with the indices looked up on the way: sentence s gets [table[pos[key[k]]] for k in off[s]..off[s+1])
+static PyObject *nested_via_body(PyObject *table, const uint32_t *key, long long n_key, const int32_t *pos, long long cap,
+                                 const uint64_t *off, long long n_sent) {
+  if (!PyList_Check(table) || n_sent < 0 || n_key < 0 || (n_sent && !off) || (n_key && (!key || !pos))) {
+    PyErr_SetString(PyExc_ValueError, "swt_py_nested_via: bad argument");
+    return NULL;
+  }
+  const Py_ssize_t n_tab = PyList_GET_SIZE(table);
+  PyObject *outer = PyList_New((Py_ssize_t)n_sent);
+  if (!outer) return NULL;
+  for (long long s = 0; s < n_sent; s++) {
+    const uint64_t a = off[s], b = off[s + 1];
+    if (a > b || b > (uint64_t)n_key) {
+      Py_DECREF(outer);
+      PyErr_SetString(PyExc_ValueError, "swt_py_nested_via: offsets must ascend within the ids");
+      return NULL;
+    }
+    PyObject *inner = PyList_New((Py_ssize_t)(b - a));
+    if (!inner) { Py_DECREF(outer); return NULL; }
+    PyList_SET_ITEM(outer, (Py_ssize_t)s, inner);
+    for (uint64_t k = a; k < b; k++) {
+      const uint32_t v = key[k];
+      const int32_t t = (long long)v < cap ? pos[v] : -1;
+      if (t < 0 || t >= n_tab) {
+        Py_DECREF(outer);
+        PyErr_SetString(PyExc_IndexError, "swt_py_nested_via: token outside the table");
+        return NULL;
+      }
+      PyObject *o = PyList_GET_ITEM(table, t);
+      Py_INCREF(o);
+      PyList_SET_ITEM(inner, (Py_ssize_t)(k - a), o);
+    }
+  }
+  return outer;
+}
+
+// The cyclic collector runs every few hundred container allocations and finds nothing to do among lists of strings; with
+// 85,000 new lists it was half of the time.  It is switched off while the lists are built (they stay tracked).
+#if PY_VERSION_HEX >= 0x030A0000
+#define SWT_GC_OFF() const int gc_was_on = PyGC_Disable()
+#define SWT_GC_BACK() do { if (gc_was_on) PyGC_Enable(); } while (0)
+#else
+#define SWT_GC_OFF() do { } while (0)
+#define SWT_GC_BACK() do { } while (0)
+#endif
+
+PyObject *swt_py_nested(PyObject *table, const int32_t *inv, long long n_inv, const uint64_t *off, long long n_sent) {
+  SWT_GC_OFF();
+  PyObject *r = nested_body(table, inv, n_inv, off, n_sent);
+  SWT_GC_BACK();
+  return r;
+}
+
+PyObject *swt_py_nested_via(PyObject *table, const uint32_t *key, long long n_key, const int32_t *pos, long long cap,
+                            const uint64_t *off, long long n_sent) {
+  SWT_GC_OFF();
+  PyObject *r = nested_via_body(table, key, n_key, pos, cap, off, n_sent);
+  SWT_GC_BACK();
+  return r;
+}

@@ -315,3 +315,52 @@ def test_join_texts_is_join_plus_encode(native):
         pass
 
     assert native.join_texts([S("ab"), "c"])[0].tobytes() == b"ab\x00c"
+
+
+def test_nested_lists_both_forms(native):
+    """ids -> List[List[str]] (the reference's output shape): csrc/swt_pyhost.c against the numpy form and a plain comprehension"""
+    rng = np.random.default_rng(3)
+    table = ["t%d" % i for i in range(300)]
+    inv = rng.integers(0, 300, size=5000).astype(np.int32)
+    cuts = np.sort(rng.integers(0, 5001, size=400))
+    off = np.concatenate([[0], cuts, [5000]]).astype(np.uint64)
+    want = [[table[int(t)] for t in inv[int(off[s]):int(off[s + 1])]] for s in range(off.size - 1)]
+    assert native.nested_lists(table, inv, off) == want
+    saved = native._pyhost
+    try:
+        native._pyhost = False
+        assert native.nested_lists(table, inv, off) == want
+        with pytest.raises(IndexError):
+            native.nested_lists(table, np.array([300], dtype=np.int32), np.array([0, 1], dtype=np.uint64))
+    finally:
+        native._pyhost = saved
+    with pytest.raises(IndexError):
+        native.nested_lists(table, np.array([1, 300], dtype=np.int32), np.array([0, 2], dtype=np.uint64))
+    with pytest.raises(IndexError):
+        native.nested_lists(table, np.array([-1], dtype=np.int32), np.array([0, 1], dtype=np.uint64))
+    with pytest.raises(ValueError):
+        native.nested_lists(table, np.array([1, 2], dtype=np.int32), np.array([0, 3], dtype=np.uint64))
+    assert native.nested_lists(table, np.zeros(0, np.int32), np.zeros(1, np.uint64)) == []
+    assert native.nested_lists(table, np.array([5], np.int32), np.array([0, 0, 1, 1], np.uint64)) == [[], ["t5"], []]
+
+
+def test_nested_lists_by_key_both_forms(native):
+    rng = np.random.default_rng(4)
+    key = rng.choice(np.array([3, 7, 2_000_001, 12, 999_999, 0], dtype=np.uint32), size=3000)
+    off = np.concatenate([[0], np.sort(rng.integers(0, 3001, size=50)), [3000]]).astype(np.uint64)
+    calls = []
+    spell = lambda k: (calls.append(k), "k%d" % k)[1]
+    want = [["k%d" % int(t) for t in key[int(off[s]):int(off[s + 1])]] for s in range(off.size - 1)]
+    assert native.nested_lists_by_key(key, 2_000_002, spell, off) == want
+    assert sorted(calls) == sorted(set(key.tolist())) and calls[0] == int(key[0])  # once per distinct key, first seen first
+    saved = native._pyhost
+    try:
+        native._pyhost = False
+        assert native.nested_lists_by_key(key, 2_000_002, spell, off) == want
+        with pytest.raises(IndexError):
+            native.nested_lists_by_key(key, 2_000_001, spell, off)
+    finally:
+        native._pyhost = saved
+    with pytest.raises(IndexError):
+        native.nested_lists_by_key(key, 2_000_001, spell, off)
+    assert native.nested_lists_by_key(np.zeros(0, np.uint32), 10, spell, np.zeros(1, np.uint64)) == []
