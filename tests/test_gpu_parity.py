@@ -331,6 +331,41 @@ def test_bpe_twin_runs_across_register_sets(swt, oracle, dev):
         same_bpe(tok, orc, [t])
 
 
+def test_bpe_random_tables_fuzz(swt, oracle, dev):
+    """random merge tables over tiny alphabets (so that words are long chains of mergeable pairs, twin runs and overlapping
+    candidates) x random texts, through the tile kernel, the single-launch form and the dedup pipeline"""
+    rng = np.random.default_rng(2024)
+    for trial in range(24):
+        alpha = ["ab", "abc", "abcd", "aąb", "ab\u4e2d"][trial % 5]
+        symbols = list(alpha)
+        merges = []
+        for _ in range(int(rng.integers(3, 40))):
+            l, r = symbols[int(rng.integers(len(symbols)))], symbols[int(rng.integers(len(symbols)))]
+            if len(l + r) > 24:
+                continue
+            merges.append((l, r))
+            symbols.append(l + r)
+        if trial % 4 == 0 and merges:
+            merges.append(merges[0])  # a duplicate: the last rank wins (bpe.py:200)
+        tok = swt.FastBPE()
+        tok.merges_list = list(merges)
+        tok._build_table()
+        orc = oracle.OracleBPE(merges)
+        texts = []
+        for _ in range(120):
+            n_words = int(rng.integers(0, 12))
+            words = ["".join(alpha[int(c)] for c in rng.integers(0, len(alpha), size=int(rng.integers(1, 60 if trial % 3 else 200))))
+                     for _ in range(n_words)]
+            texts.append((" " if rng.random() < 0.2 else "") + " ".join(words) + ("." if rng.random() < 0.3 else ""))
+        same_bpe(tok, orc, texts)
+        for t in texts[:12]:
+            same_bpe(tok, orc, [t])
+            assert tok.encode_word(t.replace(" ", "")[:150] or "a") == orc.encode_word(t.replace(" ", "")[:150] or "a")
+        with dedup(dev, dev.DEDUP_ALWAYS, tok):
+            same_bpe(tok, orc, texts)
+        tok._table.close()
+
+
 def test_bpe_wide_table_unpacked_path(swt, oracle, dev, bpe, corpora):
     """more than 65,534 merges: the kernel variant whose cached pair value is the bare rank (merged_of_rank[] path)"""
     extra = [(chr(0xE000 + 2 * i), chr(0xE001 + 2 * i)) for i in range(3000)]          # private-use pairs, never in text
