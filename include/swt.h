@@ -76,6 +76,9 @@ int swt_profile_read(double *ms_total, uint64_t *n_launches);
  * another UTF-8 length or of several code points, or U+03A3 whose lowercase depends on its neighbours): the caller
  * lowercases THAT sentence on the host.  swt_lower_of: the table itself (0xFFFFFFFF = host only), for tests. */
 uint32_t swt_lower_of(uint32_t cp);
+/* The Unicode database the lowercase and class tables were generated from ("13.0.0"): a host whose own str.lower() follows
+ * another version must lowercase every batch itself (swt_*_encode on its own text), or small and large batches disagree. */
+const char *swt_unidata_version(void);
 int swt_utf8_lower(uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, uint8_t *need_host);
 /* The same for a host that only knows its sentences' lengths in CODE POINTS (Python: "".join(texts).encode() and len(str)
  * are cheap, every string's byte length is not): text = well-formed UTF-8 of all sentences joined, cp_off[n_sent + 1] =

@@ -57,6 +57,7 @@ SIGNATURES = {
     "swt_wp_encode_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "swt_lower_of": (C.c_uint32, [C.c_uint32]),
+    "swt_unidata_version": (C.c_char_p, []),
     "swt_utf8_lower": (C.c_int, [u8p, u64p, C.c_uint64, u8p]),
     "swt_utf8_prepare": (C.c_int, [u8p, C.c_uint64, u64p, C.c_uint64, u64p, u8p]),
     "swt_utf8_prepare_joined": (C.c_int, [u8p, C.c_uint64, C.c_uint64, u8p, u64p, u8p]),
@@ -184,6 +185,19 @@ def lower_of(cp):
     return int(lib().swt_lower_of(cp))
 
 
+_lower_ok = None
+
+
+def device_lower_ok():
+    """The device's lowercase table speaks for this interpreter's str.lower(): both follow the same Unicode database.  If not,
+    every batch is lowercased on the host, so that a text tokenizes the same whatever the size of the batch it comes in."""
+    global _lower_ok
+    if _lower_ok is None:
+        import unicodedata
+        _lower_ok = lib().swt_unidata_version().decode() == unicodedata.unidata_version
+    return _lower_ok
+
+
 _pyhost = None
 
 
@@ -276,7 +290,7 @@ def pack_and_lower(texts):
     hold U+0000 themselves go by their code-point lengths, swt_utf8_prepare); the few sentences the device flags are lowercased
     here and spliced in."""
     n = len(texts)
-    if n <= 64 and sum(map(len, texts)) <= 16384:
+    if (n <= 64 and sum(map(len, texts)) <= 16384) or not device_lower_ok():
         # the reference-style call (one sentence, or a few): a device round trip costs more than str.lower() here
         return pack_utf8([t.lower() for t in texts])
     off = np.zeros(n + 1, dtype=np.uint64)
@@ -489,7 +503,7 @@ class BpeTrainer:
         not lend themselves to it (few of them, a U+0000 inside, a code point only the host lowercases): the caller then goes
         pack_and_lower -> from_text.  joined: join_texts(texts), if the caller has it already."""
         n = len(texts)
-        if n <= 64:
+        if n <= 64 or not device_lower_ok():
             return None
         joined, n_nul = joined if joined is not None else join_texts(texts, "Corpus must be a list of strings.")
         if joined.size + 1 == n or n_nul:

@@ -277,6 +277,8 @@ extern "C" {
 
 uint32_t swt_lower_of(uint32_t cp) { return cp < kNumCodePoints ? host_lower_table()[cp] : cp; }
 
+const char *swt_unidata_version(void) { return SWT_UNIDATA_VERSION; }
+
 int swt_utf8_lower_dev(uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off, uint64_t n_sent, uint8_t *d_need_host,
                        void *stream) {
   if (!d_sent_off || (n_bytes && !d_text) || (n_sent && !d_need_host)) return fail(SWT_ERR_INVALID, "null argument");

@@ -303,7 +303,7 @@ class FastBPE(NaiveBPE):
             # strings -> joined bytes -> ids: the device splits, lowercases (utils.py:27) and encodes, the
             # prepared text never comes back.  Texts with U+0000 inside, or that only str.lower() lowercases, go the long way.
             joined, n_nul = N.join_texts(texts)  # TypeError for an item that is no str
-            if n_nul == 0 and joined.size + 1 != len(texts):
+            if n_nul == 0 and joined.size + 1 != len(texts) and N.device_lower_ok():
                 got = table.encode_joined(joined, len(texts))
                 if got is not None:
                     return got
@@ -622,7 +622,7 @@ class FastWP(NaiveWP):
             raise AttributeError("'FastWP' object has no attribute 'vocab_trie'")  # as the reference before load/train
         if len(texts) > 64:
             joined, n_nul = N.join_texts(texts, "Text to tokenize must be a string.")  # as FastBPE.encode_ids_batch
-            if n_nul == 0 and joined.size + 1 != len(texts):
+            if n_nul == 0 and joined.size + 1 != len(texts) and N.device_lower_ok():
                 got = self._trie.encode_joined(joined, len(texts))
                 if got is not None:
                     return got

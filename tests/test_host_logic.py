@@ -364,3 +364,19 @@ def test_nested_lists_by_key_both_forms(native):
     with pytest.raises(IndexError):
         native.nested_lists_by_key(key, 2_000_001, spell, off)
     assert native.nested_lists_by_key(np.zeros(0, np.uint32), 10, spell, np.zeros(1, np.uint64)) == []
+
+
+def test_unicode_database_mismatch_lowercases_on_the_host(native, monkeypatch):
+    """the device's lowercase / class tables carry the Unicode version they were generated from; an interpreter on another
+    version lowercases every batch itself (pack_and_lower needs no device then), whatever its size"""
+    import unicodedata
+
+    assert native.lib().swt_unidata_version().decode() == unicodedata.unidata_version  # this image: generated here
+    assert native.device_lower_ok()
+    monkeypatch.setattr(native, "_lower_ok", False)
+    texts = ["Zażółć GĘŚLĄ jaźń %d" % i for i in range(100)] + ["İstanbul ΣΟΦΟΣ", ""]
+    buf, off = native.pack_and_lower(texts)  # no GPU in this test: the device path would raise NoDeviceError
+    want = [t.lower().encode("utf-8") for t in texts]
+    assert buf.tobytes() == b"".join(want)
+    assert off.tolist() == np.concatenate([[0], np.cumsum([len(w) for w in want])]).tolist()
+    assert native.BpeTrainer.from_texts(texts) is None
