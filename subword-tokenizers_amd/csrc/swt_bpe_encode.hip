@@ -873,6 +873,32 @@ int swt_bpe_encode(swt_bpe_table *t, const uint8_t *text, const uint64_t *sent_o
     if (sent_off[s] > sent_off[s + 1])
       return fail(SWT_ERR_INVALID, "sentence offsets must be non-decreasing (at %llu)", (unsigned long long)s);
   if (n_bytes && !text) return fail(SWT_ERR_INVALID, "null text");
+  if (n_bytes <= kDirectBytes && n_sent <= kDirectSents && n_sent > 0) {
+    // tokenize(text) on one sentence (bpe.py:245): the single workgroup of the direct form reads the text and the offsets from
+    // pinned host memory and writes the count, the offsets and the ids there -- one launch and one synchronisation, no copy
+    // call at all.  Measured: 43.1 -> 40.7 us per call from Python; a launch + hipStreamSynchronize is 11 us here, spinning on
+    // a host word instead would save 4.5 of them (tools/micro/sync_probe.hip), the rest is the kernel's own latency chain
+    // (~10 merge rounds, one L2 probe each) and ctypes.
+    const size_t off_bytes = ((n_sent + 1) * 8 + 15) & ~(size_t)15, text_bytes = (n_bytes + 64 + 15) & ~(size_t)15;
+    const size_t out_at = off_bytes + text_bytes;
+    if ((rc = t->pin.reserve(out_at + 16 + off_bytes + (n_bytes + 64) * 4))) return rc;
+    uint8_t *h = t->pin.as<uint8_t>();
+    memcpy(h, sent_off, (n_sent + 1) * 8);
+    if (n_bytes) memcpy(h + off_bytes, text, n_bytes);
+    memset(h + off_bytes + n_bytes, ' ', 64);
+    uint8_t *o = h + out_at;
+    rc = swt_bpe_encode_dev(t, h + off_bytes, n_bytes, reinterpret_cast<const uint64_t *>(h), n_sent, reinterpret_cast<uint32_t *>(o + 16 + off_bytes),
+                            reinterpret_cast<uint64_t *>(o + 16), reinterpret_cast<uint64_t *>(o), flags, nullptr);
+    if (rc) return rc;
+    SWT_HIP(hipStreamSynchronize(0));
+    const uint64_t nt = *reinterpret_cast<const volatile uint64_t *>(o);
+    *n_tokens = nt;
+    memcpy(out_off, o + 16, (n_sent + 1) * 8);
+    if (nt > out_cap)
+      return fail(SWT_ERR_CAPACITY, "out_ids too small: need %llu ids, have %llu", (unsigned long long)nt, (unsigned long long)out_cap);
+    if (nt) memcpy(out_ids, o + 16 + off_bytes, nt * 4);
+    return SWT_OK;
+  }
   if (n_bytes <= kSmallCallBytes && n_sent <= kSmallCallSents) {
     // The reference-style call (one sentence, or a few): five small copies and their synchronisations cost more than the
     // kernels.  Offsets + text go up in ONE copy from pinned memory, token count + offsets + ids come back in ONE.

@@ -808,6 +808,31 @@ int swt_wp_encode(swt_wp_trie *t, const uint8_t *text, const uint64_t *sent_off,
     if (sent_off[s] > sent_off[s + 1])
       return fail(SWT_ERR_INVALID, "sentence offsets must be non-decreasing (at %llu)", (unsigned long long)s);
   if (n_bytes && !text) return fail(SWT_ERR_INVALID, "null text");
+  if (n_bytes <= kWpDirectBytes && n_sent <= kWpDirectSents && n_sent > 0) {
+    // tokenize(text) on one sentence (wordpiece.py:233): the kernels read the text and the offsets from pinned host memory and
+    // write the count, the offsets, the statuses and the ids there -- no copy call at all (see swt_bpe_encode)
+    const size_t off_bytes = ((n_sent + 1) * 8 + 15) & ~(size_t)15, st_bytes = (n_sent + 15) & ~(size_t)15;
+    const size_t text_bytes = (n_bytes + 64 + 15) & ~(size_t)15, out_at = off_bytes + text_bytes;
+    if ((rc = t->pin.reserve(out_at + 16 + off_bytes + st_bytes + (n_bytes + 64) * 4))) return rc;
+    uint8_t *h = t->pin.as<uint8_t>();
+    memcpy(h, sent_off, (n_sent + 1) * 8);
+    if (n_bytes) memcpy(h + off_bytes, text, n_bytes);
+    memset(h + off_bytes + n_bytes, ' ', 64);
+    uint8_t *o = h + out_at;
+    rc = swt_wp_encode_dev(t, h + off_bytes, n_bytes, reinterpret_cast<const uint64_t *>(h), n_sent,
+                           reinterpret_cast<uint32_t *>(o + 16 + off_bytes + st_bytes), reinterpret_cast<uint64_t *>(o + 16), o + 16 + off_bytes,
+                           reinterpret_cast<uint64_t *>(o), nullptr);
+    if (rc) return rc;
+    SWT_HIP(hipStreamSynchronize(0));
+    const uint64_t nt = *reinterpret_cast<const volatile uint64_t *>(o);
+    *n_tokens = nt;
+    memcpy(out_off, o + 16, (n_sent + 1) * 8);
+    if (n_sent) memcpy(status, o + 16 + off_bytes, n_sent);
+    if (nt > out_cap)
+      return fail(SWT_ERR_CAPACITY, "out_ids too small: need %llu ids, have %llu", (unsigned long long)nt, (unsigned long long)out_cap);
+    if (nt) memcpy(out_ids, o + 16 + off_bytes + st_bytes, nt * 4);
+    return SWT_OK;
+  }
   if (n_bytes <= kSmallCallBytes && n_sent <= kSmallCallSents) {
     // the reference-style call (one sentence, or a few): one copy up (offsets + text), one copy down (count, offsets, statuses, ids)
     const size_t off_bytes = ((n_sent + 1) * 8 + 15) & ~(size_t)15, st_bytes = (n_sent + 15) & ~(size_t)15;
