@@ -119,6 +119,7 @@ class NaiveBPE(SubwordTokenizer):
         self.vocab: set = set()
         self._trainer: Optional[N.BpeTrainer] = None
         self._train_syms: Optional[_SymbolTable] = None
+        self._train_ids = None  # (left, right, merged) ids of merges_list as the device named them, when no replay was needed
         self._corpus_cache = None
 
     # -- bpe.py:25-48
@@ -158,6 +159,7 @@ class NaiveBPE(SubwordTokenizer):
         applied: List[Tuple[int, int, int]] = []  # (left, right, merged) ids in order, for the collision replay
         done = set()
         exhausted = False
+        runs, clean = [], True  # the id arrays of every device run, as long as no string collision forced a replay
         while len(self.vocab) < max_vocab and not exhausted:  # bpe.py:88
             # The device runs `want` iterations of bpe.py:90-111 back to back; it names the merged symbol of step i
             # SYM_BASE + (strings so far) + i, which is right as long as every merged string is new (bpe.py:103).
@@ -166,6 +168,7 @@ class NaiveBPE(SubwordTokenizer):
             lefts, rights, counts = trainer.run(want, first)
             if len(lefts) < want:
                 exhausted = True  # bpe.py:98-99: no pair left
+            runs.append((lefts, rights, first))
             # (plain Python ints and local names: this loop runs once per merge, beside a device that needs ~15 us for one)
             strings, intern, base = syms.strings, syms.intern, N.SYM_BASE
             vocab_add, merges_append, applied_append, done_add = self.vocab.add, self.merges_list.append, applied.append, done.add
@@ -183,6 +186,7 @@ class NaiveBPE(SubwordTokenizer):
                 if merged != first + i:
                     # two different merges spelled the same string (never observed).  The device
                     # continued with a fresh id; rebuild the state with the right one and carry on from here.
+                    clean = False
                     trainer.close()
                     if text is None:
                         text, off = N.pack_and_lower(corpus)
@@ -192,6 +196,10 @@ class NaiveBPE(SubwordTokenizer):
                     exhausted = False
                     break
         self._trainer, self._train_syms, self._corpus_cache = trainer, syms, None
+        if clean:
+            self._train_ids = (np.concatenate([l for l, _, _ in runs]) if runs else np.zeros(0, np.uint32),
+                               np.concatenate([r for _, r, _ in runs]) if runs else np.zeros(0, np.uint32),
+                               np.concatenate([f + np.arange(len(l), dtype=np.uint32) for l, _, f in runs]) if runs else np.zeros(0, np.uint32))
 
     @property
     def corpus_as_symbols(self) -> List[Tuple[List[str], int]]:
@@ -231,6 +239,7 @@ class NaiveBPE(SubwordTokenizer):
         if self._trainer is not None:
             self._trainer.close()
         self._trainer, self._train_syms, self._corpus_cache = None, None, None
+        self._train_ids = None
 
     # -- bpe.py:167-189
     def save_resources(self, path: str) -> None:
@@ -258,16 +267,16 @@ class FastBPE(NaiveBPE):
         # bpe.py:200 / :257
         self._bpe_ranks = {pair: i for i, pair in enumerate(self.merges_list)}
         syms = _SymbolTable()
-        n = len(self.merges_list)
-        ids = np.zeros((3, max(n, 1)), dtype=np.uint32)
-        for i, (l, r) in enumerate(self.merges_list):
-            ids[0, i] = syms.intern(l)
-            ids[1, i] = syms.intern(r)
-            ids[2, i] = syms.intern(l + r)
+        intern = syms.intern
+        ids = [x for l, r in self.merges_list for x in (intern(l), intern(r), intern(l + r))]
+        ids = np.array(ids, dtype=np.uint32).reshape(-1, 3)
+        self._set_table(syms, ids[:, 0], ids[:, 1], ids[:, 2])
+
+    def _set_table(self, syms, left, right, merged) -> None:
         if self._table is not None:
             self._table.close()
         self._syms = syms
-        self._table = N.BpeTable(ids[0, :n], ids[1, :n], ids[2, :n])
+        self._table = N.BpeTable(left, right, merged)
 
     def _ensure_table(self) -> N.BpeTable:
         # like _bpe_ranks, the table only changes in train()/load_resources() (bpe.py:200,257)
@@ -277,7 +286,16 @@ class FastBPE(NaiveBPE):
 
     def train(self, corpus: List[str], max_vocab: int = 30_000) -> None:
         super().train(corpus, max_vocab)
-        self._build_table()
+        if self._train_ids is None or len(self._train_ids[0]) != len(self.merges_list):
+            self._build_table()
+            return
+        # the device named the symbols exactly as _build_table would (a merged string gets the next id the first time it is
+        # spelled, and in training every merge spells a new one): its ids go to the rank table as they are
+        self._bpe_ranks = {pair: i for i, pair in enumerate(self.merges_list)}
+        syms = _SymbolTable()
+        syms.strings = list(self._train_syms.strings)
+        syms.index = dict(self._train_syms.index)
+        self._set_table(syms, *self._train_ids)
 
     def _pairs(self, seq: List[str]) -> set:
         return {(seq[i], seq[i + 1]) for i in range(len(seq) - 1)}

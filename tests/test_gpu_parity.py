@@ -598,6 +598,15 @@ def test_train_5k_config1(swt, dev, golden, corpora):
     # corpus_as_symbols (bpe.py:23): the final segmentation of every unique word with its frequency
     cas = tok.corpus_as_symbols
     assert len(cas) == 22971 and sum(f for _, f in cas) == 80161
+    # train() hands the device's own symbol ids to the rank table; a table built from the merges alone names them the same
+    assert tok._train_ids is not None and len(tok._train_ids[0]) == 922
+    tok2 = swt.FastBPE()
+    tok2.merges_list = list(tok.merges_list)
+    tok2._build_table()
+    assert tok2._syms.strings == tok._syms.strings and tok2._bpe_ranks == tok._bpe_ranks
+    a, ao = tok.encode_ids_batch(corpora["t5k"][:500])
+    b, bo = tok2.encode_ids_batch(corpora["t5k"][:500])
+    assert np.array_equal(a, b) and np.array_equal(ao, bo)
 
 
 def test_train_state_matches_oracle_stepwise(swt, oracle, dev, corpora):
