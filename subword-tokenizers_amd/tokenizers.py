@@ -156,8 +156,10 @@ class NaiveBPE(SubwordTokenizer):
             trainer = N.BpeTrainer.from_text(text, off)
         syms = _SymbolTable()
         self.vocab.update(chr(int(c)) for c in trainer.base_symbols())  # bpe.py:75
-        applied: List[Tuple[int, int, int]] = []  # (left, right, merged) ids in order, for the collision replay
-        done = set()
+        applied_l: List[int] = []  # (left, right, merged) ids of every merge so far, for the collision replay
+        applied_r: List[int] = []
+        applied_m: List[int] = []
+        done = set()  # left << 32 | right of every merge so far
         exhausted = False
         runs, clean = [], True  # the id arrays of every device run, as long as no string collision forced a replay
         while len(self.vocab) < max_vocab and not exhausted:  # bpe.py:88
@@ -169,32 +171,42 @@ class NaiveBPE(SubwordTokenizer):
             if len(lefts) < want:
                 exhausted = True  # bpe.py:98-99: no pair left
             runs.append((lefts, rights, first))
-            # (plain Python ints and local names: this loop runs once per merge, beside a device that needs ~15 us for one)
+            # (plain Python ints and local names: this loop runs once per merge, beside a device that needs ~10 us for one;
+            # what can be done for the whole run at once -- the replay record, the "never twice" check -- is done after it)
             strings, intern, base = syms.strings, syms.intern, N.SYM_BASE
-            vocab_add, merges_append, applied_append, done_add = self.vocab.add, self.merges_list.append, applied.append, done.add
-            for i, (left, right) in enumerate(zip(lefts.tolist(), rights.tolist())):
-                if (left, right) in done:  # symbols only ever merge: a merged pair cannot come back
-                    raise RuntimeError("pair histogram inconsistent: %r selected twice" % ((left, right),))
-                done_add((left, right))
+            vocab_add, merges_append = self.vocab.add, self.merges_list.append
+            ll, rl = lefts.tolist(), rights.tolist()
+            taken, collided = len(ll), None
+            for i, (left, right) in enumerate(zip(ll, rl)):
                 ls = chr(left) if left < base else strings[left - base]   # _SymbolTable.string
                 rs = chr(right) if right < base else strings[right - base]
                 joined = ls + rs
                 merged = intern(joined)
                 vocab_add(joined)  # bpe.py:103
                 merges_append((ls, rs))  # bpe.py:104
-                applied_append((left, right, merged))
                 if merged != first + i:
-                    # two different merges spelled the same string (never observed).  The device
-                    # continued with a fresh id; rebuild the state with the right one and carry on from here.
-                    clean = False
-                    trainer.close()
-                    if text is None:
-                        text, off = N.pack_and_lower(corpus)
-                    trainer = N.BpeTrainer.from_text(text, off)
-                    for l_, r_, m_ in applied:
-                        trainer.apply(l_, r_, m_)
-                    exhausted = False
+                    taken, collided = i + 1, merged
                     break
+            keys = ((lefts[:taken].astype(np.uint64) << np.uint64(32)) | rights[:taken].astype(np.uint64)).tolist()
+            fresh = set(keys)
+            if len(fresh) != len(keys) or not done.isdisjoint(fresh):  # symbols only ever merge: a merged pair cannot come back
+                raise RuntimeError("pair histogram inconsistent: a pair was selected twice")
+            done |= fresh
+            applied_l.extend(ll[:taken])
+            applied_r.extend(rl[:taken])
+            applied_m.extend(range(first, first + taken))
+            if collided is not None:
+                # two different merges spelled the same string (never observed).  The device
+                # continued with a fresh id; rebuild the state with the right one and carry on from here.
+                applied_m[-1] = collided
+                clean = False
+                trainer.close()
+                if text is None:
+                    text, off = N.pack_and_lower(corpus)
+                trainer = N.BpeTrainer.from_text(text, off)
+                for l_, r_, m_ in zip(applied_l, applied_r, applied_m):
+                    trainer.apply(l_, r_, m_)
+                exhausted = False
         self._trainer, self._train_syms, self._corpus_cache = trainer, syms, None
         if clean:
             self._train_ids = (np.concatenate([l for l, _, _ in runs]) if runs else np.zeros(0, np.uint32),
