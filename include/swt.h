@@ -229,6 +229,8 @@ int swt_bpe_train_create_joined(const uint8_t *joined, uint64_t n_joined, uint64
 #define SWT_WP_MERGED_BASE 0x220000u
 int swt_wp_train_create_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent,
                              swt_bpe_trainer **out);
+/* ... and from the joined texts, as swt_bpe_train_create_joined (NULL handle + SWT_OK: a sentence needs the host's lower()). */
+int swt_wp_train_create_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint8_t *need_host, swt_bpe_trainer **out);
 /* From an already deduplicated word list (symbol ids, CSR offsets, frequencies). */
 int swt_bpe_train_create_words(const uint32_t *syms, const uint64_t *word_off, const uint32_t *freq,
                                uint64_t n_words, swt_bpe_trainer **out);

@@ -67,6 +67,7 @@ SIGNATURES = {
     "swt_bpe_train_create_text": (C.c_int, [u8p, u64p, C.c_uint64, vpp]),
     "swt_bpe_train_create_joined": (C.c_int, [u8p, C.c_uint64, C.c_uint64, u8p, vpp]),
     "swt_wp_train_create_text": (C.c_int, [u8p, u64p, C.c_uint64, vpp]),
+    "swt_wp_train_create_joined": (C.c_int, [u8p, C.c_uint64, C.c_uint64, u8p, vpp]),
     "swt_bpe_train_create_words": (C.c_int, [u32p, u64p, u32p, C.c_uint64, vpp]),
     "swt_bpe_train_destroy": (None, [C.c_void_p]),
     "swt_bpe_train_set_pos_base": (C.c_int, [C.c_void_p, C.c_uint64]),
@@ -498,7 +499,7 @@ class BpeTrainer:
         return cls(h)
 
     @classmethod
-    def from_texts(cls, texts, joined=None):
+    def from_texts(cls, texts, joined=None, wordpiece=False):
         """list[str] -> trainer, the prepared text never leaving the device (swt_bpe_train_create_joined); None when the texts do
         not lend themselves to it (few of them, a U+0000 inside, a code point only the host lowercases): the caller then goes
         pack_and_lower -> from_text.  joined: join_texts(texts), if the caller has it already."""
@@ -510,7 +511,8 @@ class BpeTrainer:
             return None
         need = np.zeros(n, dtype=np.uint8)
         h = C.c_void_p()
-        check(lib().swt_bpe_train_create_joined(ptr(joined, u8p), int(joined.size), n, ptr(need, u8p), C.byref(h)))
+        create = lib().swt_wp_train_create_joined if wordpiece else lib().swt_bpe_train_create_joined
+        check(create(ptr(joined, u8p), int(joined.size), n, ptr(need, u8p), C.byref(h)))
         return cls(h) if h.value else None
 
     @classmethod

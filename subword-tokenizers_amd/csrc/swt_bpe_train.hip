@@ -2399,10 +2399,9 @@ int swt_bpe_train_create_text(const uint8_t *text, const uint64_t *sent_off, uin
 
 // wordpiece.py:44-63 on the device: the same split and Counter, then [word[0]] + ["##" + c ...] and the symbol frequencies.
 // The handle is used with the swt_bpe_train_* calls; `count` outputs carry the winning score's bit pattern.
-int swt_wp_train_create_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, swt_bpe_trainer **out) {
-  swt_bpe_trainer *t = nullptr;
-  int rc = words_from_text(text, sent_off, n_sent, &t);
-  if (rc) return rc;
+// everything after the word census: '##' symbols, histogram and index, symbol frequencies, the initial vocabulary.  Owns t.
+static int wp_finish_create(swt_bpe_trainer *t, swt_bpe_trainer **out) {
+  int rc;
   auto bail = [&](int code) { swt_bpe_train_destroy(t); return code; };
   t->id_base = kWpMergedBase;
   if (t->n_words)
@@ -2434,6 +2433,31 @@ int swt_wp_train_create_text(const uint8_t *text, const uint64_t *sent_off, uint
   t->n_base = h[1];
   *out = t;
   return SWT_OK;
+}
+
+int swt_wp_train_create_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, swt_bpe_trainer **out) {
+  swt_bpe_trainer *t = nullptr;
+  int rc = words_from_text(text, sent_off, n_sent, &t);
+  if (rc) return rc;
+  return wp_finish_create(t, out);
+}
+
+// the WordPiece trainer from the joined texts: see swt_bpe_train_create_joined
+int swt_wp_train_create_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint8_t *need_host, swt_bpe_trainer **out) {
+  if (!out || (n_sent && !need_host) || (n_joined && !joined)) return fail(SWT_ERR_INVALID, "null argument");
+  *out = nullptr;
+  const uint8_t *d_text = nullptr;
+  const uint64_t *d_off = nullptr;
+  uint64_t n_bytes = 0;
+  int rc = prepare_joined_dev(joined, n_joined, n_sent, need_host, &d_text, &d_off, &n_bytes);
+  if (rc) return rc;
+  for (uint64_t s2 = 0; s2 < n_sent; s2++)
+    if (need_host[s2]) return SWT_OK;
+  DeviceWords dw;
+  if ((rc = device_words_from_text(d_text, n_bytes, d_off, n_sent, &dw))) return rc;
+  auto *t = new swt_bpe_trainer();
+  if ((rc = trainer_adopt(t, dw))) { swt_bpe_train_destroy(t); return rc; }
+  return wp_finish_create(t, out);
 }
 
 void swt_bpe_train_destroy(swt_bpe_trainer *t) {

@@ -417,13 +417,22 @@ class NaiveWP(SubwordTokenizer):
 
     # -- wordpiece.py:29-103: the merge loop, on the device
     def train(self, corpus, max_vocab: int = 30_000):
-        if not isinstance(corpus, list) or not all(isinstance(example, str) for example in corpus):
+        if not isinstance(corpus, list):
+            raise TypeError("corpus must be a list of strings.")
+        joined = None
+        if len(corpus) > 64:
+            joined = N.join_texts(corpus, "corpus must be a list of strings.")  # checks the items on its way
+        elif not all(isinstance(example, str) for example in corpus):
             raise TypeError("corpus must be a list of strings.")
         if not isinstance(max_vocab, int):
             raise TypeError("max_vocab must be an int.")
         self.reset()
-        text, off = N.pack_and_lower(corpus)
-        trainer = N.BpeTrainer.from_text_wordpiece(text, off)  # wordpiece.py:44-58 (split, Counter, '##' symbols)
+        text = off = None
+        # wordpiece.py:44-58 (lower, split, Counter, '##' symbols), the text staying on the device where it can
+        trainer = N.BpeTrainer.from_texts(corpus, joined, wordpiece=True)
+        if trainer is None:
+            text, off = N.pack_and_lower(corpus)
+            trainer = N.BpeTrainer.from_text_wordpiece(text, off)
         syms = _WpSymbols()
         self.vocab |= {syms.string(int(c)) for c in trainer.base_symbols()}  # wordpiece.py:62-63
         applied: List[Tuple[int, int, int]] = []
@@ -450,6 +459,8 @@ class NaiveWP(SubwordTokenizer):
                     # two different merges spelled the same string: the device went on with a fresh id; rebuild the state
                     # with the shared one and carry on from here
                     trainer.close()
+                    if text is None:
+                        text, off = N.pack_and_lower(corpus)
                     trainer = N.BpeTrainer.from_text_wordpiece(text, off)
                     for l_, r_, m_ in applied:
                         trainer.apply(l_, r_, m_)
