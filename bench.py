@@ -334,6 +334,37 @@ def train_bench(args, torch, dist, rank, world, N, sents, max_vocab, name, repea
                                        "full recount per merge; its cost per merge falls slowly with N_t)" % cpu_sample}}
 
 
+EMIT = None  # main() installs the function that formats a result as THE JSON line and writes it (rank 0)
+
+
+def train_bench_guarded(out_so_far, args, torch, dist, rank, world, N, sents, max_vocab, name, limit_s=240.0):
+    """train_bench for the headline line.  At world > 1 the sharded runner makes RCCL calls of its own on every rank: a rank
+    that fails or hangs there would take the encode half of the line with it (the other ranks wait in a collective for ever).
+    So the block runs under a watchdog: if it raises on this rank or does not finish in limit_s, rank 0 writes the line with
+    train = {"error": ...} and every rank leaves at once (os._exit: no collective is entered again)."""
+    if world == 1:
+        return train_bench(args, torch, dist, rank, world, N, sents, max_vocab, name)
+    import threading
+
+    def leave(why):
+        sys.stderr.write("bench: sharded training on rank %d: %s -- the line goes out without the train block\n" % (rank, why))
+        sys.stderr.flush()
+        if rank == 0:
+            EMIT(dict(out_so_far, train={"error": why, "parallelism": "corpus-sharded x%d" % world}))
+        os._exit(0)
+
+    timer = threading.Timer(limit_s, leave, args=("not finished after %.0f s" % limit_s,))
+    timer.daemon = True
+    timer.start()
+    try:
+        train = train_bench(args, torch, dist, rank, world, N, sents, max_vocab, name)
+    except BaseException as e:  # incl. SystemExit of a parity failure: say so in the line instead of hanging the other ranks
+        timer.cancel()
+        leave("%s: %s" % (type(e).__name__, e))
+    timer.cancel()
+    return train
+
+
 def bench_headline(args, torch, dist, rank, world, local):
     """Both halves of BASELINE.json's metric: configs[1] FastBPE encode (value) + FastBPE.train s/1k-merges ("train")."""
     from subword_tokenizers_amd import _native as N
@@ -350,7 +381,6 @@ def bench_headline(args, torch, dist, rank, world, local):
     # encode: every rank has its own shard-shaped corpus; training: ONE corpus, which the sharded runner cuts into the ranks'
     # sentence ranges (train_sharded) -- so every rank must hold the same sentences, rank 0's
     train_sents = corpora[1][1] if rank == 0 else synth.s85k_open()
-    train = train_bench(args, torch, dist, rank, world, N, train_sents, args.max_vocab or 8000, "S85k-open")
     head, other = sorted(runs, key=lambda r: r["mb_s"])
     out = {
         "metric": "FastBPE encode MB/s (value; tokens bit-exact) + BPE train s/1k-merges (train.s_per_1k_merges)",
@@ -364,8 +394,8 @@ def bench_headline(args, torch, dist, rank, world, local):
         "other_corpus": {"corpus": other["corpus"], "value": round(other["mb_s"], 1), "unit": "MB/s", "ms_per_step": round(other["ms_per_step"], 4),
                          "bytes_per_gpu": other["n_bytes"], "tokens_per_gpu": other["n_tok"], "roofline": other["roofline"],
                          "cpu_baseline": other["cpu"]},
-        "train": train,
     }
+    out["train"] = train_bench_guarded(out, args, torch, dist, rank, world, N, train_sents, args.max_vocab or 8000, "S85k-open")
     return out
 
 
@@ -745,14 +775,20 @@ def main():
     torch, dist, rank, world, local = dist_setup(args.gpus)
     fn = {"headline": bench_headline, "bpe_encode": bench_bpe_encode, "wp_encode": bench_wp_encode, "bpe_train": bench_bpe_train,
           "wp_train": bench_wp_train, "bpe_train_1g": bench_bpe_train_words, "mixed_encode": bench_mixed_encode}[args.workload]
-    res = fn(args, torch, dist, rank, world, local)
-    line = {"metric": res.pop("metric"), "value": res.pop("value"), "unit": res.pop("unit"), "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"),
-            "higher_is_better": res.pop("higher_is_better", True), "scaling": res.pop("scaling", "weak"), "vs_baseline": None,
-            "dtype": res.pop("dtype"), "data": "synthetic", "config": res.pop("config")}
-    line.update(res)
-    if rank == 0:
+    def emit(res):
+        res = dict(res)
+        line = {"metric": res.pop("metric"), "value": res.pop("value"), "unit": res.pop("unit"), "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"),
+                "higher_is_better": res.pop("higher_is_better", True), "scaling": res.pop("scaling", "weak"), "vs_baseline": None,
+                "dtype": res.pop("dtype"), "data": "synthetic", "config": res.pop("config")}
+        line.update(res)
         print(json.dumps(line), file=real_stdout, flush=True)
+
+    global EMIT
+    EMIT = emit
+    res = fn(args, torch, dist, rank, world, local)
+    if rank == 0:
+        emit(res)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -5,6 +5,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -380,3 +381,45 @@ def test_unicode_database_mismatch_lowercases_on_the_host(native, monkeypatch):
     assert buf.tobytes() == b"".join(want)
     assert off.tolist() == np.concatenate([[0], np.cumsum([len(w) for w in want])]).tolist()
     assert native.BpeTrainer.from_texts(texts) is None
+
+
+def test_bench_watchdog_emits_the_line_without_the_train_block(monkeypatch):
+    """bench.py at world > 1: if the sharded training block raises (or hangs) on a rank, rank 0 still writes the JSON line, with
+    train = {"error": ...}, and every rank leaves without entering another collective"""
+    import time
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class Left(BaseException):
+        pass
+
+    emitted = []
+    monkeypatch.setattr(bench, "EMIT", emitted.append)
+    monkeypatch.setattr(bench.os, "_exit", lambda code: (_ for _ in ()).throw(Left(code)))
+    out = {"metric": "m", "value": 1.0}
+
+    def boom(*a, **k):
+        raise SystemExit("PARITY FAILURE: made up")
+
+    monkeypatch.setattr(bench, "train_bench", boom)
+    with pytest.raises(Left):
+        bench.train_bench_guarded(out, None, None, None, 0, 2, None, [], 8000, "x")
+    assert len(emitted) == 1 and "PARITY FAILURE" in emitted[0]["train"]["error"] and emitted[0]["value"] == 1.0
+    emitted.clear()
+    with pytest.raises(Left):  # another rank: nothing to print, it just leaves
+        bench.train_bench_guarded(out, None, None, None, 1, 2, None, [], 8000, "x")
+    assert emitted == []
+    # a block that hangs: the timer fires in its own thread, writes the line and leaves (here: raises inside that thread)
+    fired = []
+    monkeypatch.setattr(bench.os, "_exit", lambda code: fired.append(code))
+    monkeypatch.setattr(bench, "train_bench", lambda *a, **k: time.sleep(0.6) or {"ok": True})
+    got = bench.train_bench_guarded(out, None, None, None, 0, 2, None, [], 8000, "x", limit_s=0.2)
+    assert fired == [0] and len(emitted) == 1 and "not finished" in emitted[0]["train"]["error"]
+    # and the ordinary case: the block's result, no line, nobody leaves
+    emitted.clear(); fired.clear()
+    monkeypatch.setattr(bench, "train_bench", lambda *a, **k: {"ok": True})
+    assert bench.train_bench_guarded(out, None, None, None, 0, 2, None, [], 8000, "x") == {"ok": True}
+    assert bench.train_bench_guarded(out, None, None, None, 0, 1, None, [], 8000, "x") == {"ok": True}
+    assert emitted == [] and fired == []
