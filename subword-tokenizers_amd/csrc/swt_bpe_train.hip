@@ -222,42 +222,84 @@ __device__ __forceinline__ uint32_t k0_find(const K0Index &K, unsigned long long
   }
 }
 
-// pass 0: occurrences per key; pass 1: fill the lists (start[] holds each list's base by then).  One lane per word, eight
-// pairs at a time: their probes go out together, then their atomics (a lane that walked its word pair by pair paid two
-// dependent round trips per symbol).
+// pass 0: occurrences per key; pass 1: fill the lists (start[] holds each list's base by then).  One lane per word, four
+// pairs per lane and trip.  The pairs of natural text are Zipfian: a lane-per-occurrence atomicAdd on fill[] serialised on the
+// hot keys (1.26 ms per pass on S85k-open, against 0.1-0.3 ms for hist_build_kernel, which visits the same pairs).  So, like
+// there, a wave stages its trip's keys in an LDS table (512 slots, linear probing): the LDS atomic gives every occurrence its
+// rank among the wave's occurrences of that key, ONE global atomicAdd per distinct key reserves the run, and the lanes write
+// their words at run + rank.  A key that finds no LDS slot in eight probes goes to the global table directly.
+constexpr int kK0Slots = 512, kK0Fan = 4;
 __global__ __launch_bounds__(kTrainThreads) void k0_pass_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
                                                                 uint64_t n_words, K0Index K, int pass) {
+  __shared__ unsigned long long lk[kTrainThreads / 64][kK0Slots];
+  __shared__ uint32_t lc[kTrainThreads / 64][kK0Slots];   // occurrences in this trip
+  __shared__ uint32_t lb[kTrainThreads / 64][kK0Slots];   // pass 1: where the wave's run of this key starts in K.words
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = lane; i < kK0Slots; i += 64) { lk[wave][i] = kEmptyKey; lc[wave][i] = 0; }
   const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= n_words) return;
-  const uint64_t b0 = woff[w], b1 = woff[w + 1];
-  if (b1 - b0 < 2) return;
-  for (uint64_t base = b0; base + 1 < b1; base += 8) {
-    uint32_t s9[9];
+  uint64_t b0 = 0, b1 = 0;
+  if (w < n_words) { b0 = woff[w]; b1 = woff[w + 1]; }
+  __syncthreads();
+  for (uint64_t base = b0;; base += kK0Fan) {
+    const bool more = base + 1 < b1;
+    if (!__syncthreads_or(more)) break;  // every wave of the workgroup makes the same number of trips (the barriers below)
+    unsigned long long key[kK0Fan];
+    int slot[kK0Fan];
+    uint32_t rank[kK0Fan];
+    uint32_t s5[kK0Fan + 1];
 #pragma unroll
-    for (int u = 0; u < 9; u++) s9[u] = base + u < b1 ? sym[base + u] : kHole;
-    unsigned long long key[8], seen[8];
-    uint32_t h[8], got[8];
+    for (int u = 0; u <= kK0Fan; u++) s5[u] = more && base + u < b1 ? sym[base + u] : kHole;
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      key[u] = base + u + 1 < b1 ? pair_key(s9[u], s9[u + 1]) : kEmptyKey;
-      h[u] = hash_slot(key[u], K.bits);
-      seen[u] = key[u] != kEmptyKey ? K.keys[h[u]] : kEmptyKey;
+    for (int u = 0; u < kK0Fan; u++) {
+      key[u] = more && base + u + 1 < b1 ? pair_key(s5[u], s5[u + 1]) : kEmptyKey;
+      slot[u] = -1;
+      rank[u] = 0;
+      if (key[u] == kEmptyKey) continue;
+      uint32_t h = (uint32_t)((key[u] * 0x9E3779B97F4A7C15ull) >> 55);  // 9 bits
+      for (int probe = 0; probe < 8; probe++) {
+        unsigned long long k = lk[wave][h];
+        if (k == kEmptyKey) {
+          k = atomicCAS(&lk[wave][h], kEmptyKey, key[u]);
+          if (k == kEmptyKey) k = key[u];
+        }
+        if (k == key[u]) {
+          slot[u] = (int)h;
+          rank[u] = atomicAdd(&lc[wave][h], 1u);
+          break;
+        }
+        h = (h + 1) & (kK0Slots - 1);
+      }
     }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      if (key[u] == kEmptyKey) { h[u] = 0xFFFFFFFFu; continue; }
-      if (seen[u] != key[u]) h[u] = seen[u] == kEmptyKey ? 0xFFFFFFFFu : k0_find(K, key[u]);  // not at its home slot: walk on
+    __syncthreads();
+    // one lane per staged key: its slot in the index, one global atomic for the wave's occurrences
+    for (int i = lane; i < kK0Slots; i += 64) {
+      const unsigned long long k = lk[wave][i];
+      if (k == kEmptyKey) continue;
+      const uint32_t h = k0_find(K, k);
+      uint32_t at = 0xFFFFFFFFu;
+      if (h != 0xFFFFFFFFu) {
+        const uint32_t got = atomicAdd(&K.fill[h], lc[wave][i]);
+        if (pass == 1) at = K.start[h] + got;
+      }
+      lb[wave][i] = at;
     }
+    __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 8; u++) got[u] = h[u] != 0xFFFFFFFFu ? atomicAdd(&K.fill[h[u]], 1u) : 0u;
-    if (pass == 1) {
-      uint32_t at[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) at[u] = h[u] != 0xFFFFFFFFu ? K.start[h[u]] : 0u;
-#pragma unroll
-      for (int u = 0; u < 8; u++)
-        if (h[u] != 0xFFFFFFFFu) K.words[(uint64_t)at[u] + got[u]] = (uint32_t)w;
+    for (int u = 0; u < kK0Fan; u++) {
+      if (key[u] == kEmptyKey) continue;
+      if (slot[u] >= 0) {
+        if (pass == 1 && lb[wave][slot[u]] != 0xFFFFFFFFu) K.words[(uint64_t)lb[wave][slot[u]] + rank[u]] = (uint32_t)w;
+      } else {  // the wave's table was crowded: straight to the global one
+        const uint32_t h = k0_find(K, key[u]);
+        if (h != 0xFFFFFFFFu) {
+          const uint32_t got = atomicAdd(&K.fill[h], 1u);
+          if (pass == 1) K.words[(uint64_t)K.start[h] + got] = (uint32_t)w;
+        }
+      }
     }
+    __syncthreads();
+    for (int i = lane; i < kK0Slots; i += 64) { lk[wave][i] = kEmptyKey; lc[wave][i] = 0; }
+    __syncthreads();
   }
 }
 
