@@ -217,6 +217,9 @@ def pyhost():
                 dll.swt_py_join_fill.restype = C.c_longlong
                 dll.swt_py_nested.argtypes = [C.py_object, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong]
                 dll.swt_py_nested.restype = C.py_object
+                dll.swt_py_bpe_merge_strings.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_uint32, C.c_uint32, C.py_object, C.py_object,
+                                                         C.py_object, C.py_object, C.POINTER(C.c_uint32)]
+                dll.swt_py_bpe_merge_strings.restype = C.c_longlong
                 dll.swt_py_distinct.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p]
                 dll.swt_py_distinct.restype = C.c_longlong
                 dll.swt_py_nested_via.argtypes = [C.py_object, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong]

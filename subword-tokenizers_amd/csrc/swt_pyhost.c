@@ -265,3 +265,56 @@ PyObject *swt_py_nested_via(PyObject *table, const uint32_t *key, long long n_ke
   SWT_GC_BACK();
   return r;
 }
+
+// The per-merge bookkeeping of NaiveBPE.train (bpe.py:102-104) for a whole device run: for merge i of n,
+//   ls, rs = spelling of left[i], right[i] (a code point below `base`, else strings[id - base]); joined = ls + rs;
+//   merged = _SymbolTable.intern(joined)   (index: str -> k, strings: k -> str, id = base + k; a one-code-point string is its ord);
+//   vocab.add(joined); merges.append((ls, rs));
+// and it stops behind the first merge whose id is not first + i (two merges spelled the same string: the caller replays).
+// Returns that merge's index (its id in *collided) or -1 when every id was the expected one; -2 with an exception set on error.
+long long swt_py_bpe_merge_strings(const uint32_t *left, const uint32_t *right, long long n, uint32_t base, uint32_t first,
+                                   PyObject *strings, PyObject *index, PyObject *vocab, PyObject *merges, uint32_t *collided) {
+  if (!PyList_Check(strings) || !PyDict_Check(index) || !PySet_Check(vocab) || !PyList_Check(merges) || n < 0 || (n && (!left || !right))) {
+    PyErr_SetString(PyExc_TypeError, "swt_py_bpe_merge_strings: bad argument");
+    return -2;
+  }
+  for (long long i = 0; i < n; i++) {
+    PyObject *sp[2] = {NULL, NULL};
+    const uint32_t id[2] = {left[i], right[i]};
+    for (int s = 0; s < 2; s++) {
+      if (id[s] < base) sp[s] = PyUnicode_FromOrdinal((int)id[s]);
+      else if ((Py_ssize_t)(id[s] - base) < PyList_GET_SIZE(strings)) { sp[s] = PyList_GET_ITEM(strings, id[s] - base); Py_INCREF(sp[s]); }
+      else PyErr_SetString(PyExc_IndexError, "swt_py_bpe_merge_strings: symbol id without a string");
+      if (!sp[s]) { Py_XDECREF(sp[0]); return -2; }
+    }
+    PyObject *joined = PyUnicode_Concat(sp[0], sp[1]);
+    PyObject *pair = joined ? PyTuple_Pack(2, sp[0], sp[1]) : NULL;
+    Py_DECREF(sp[0]);
+    Py_DECREF(sp[1]);
+    if (!joined || !pair) { Py_XDECREF(joined); Py_XDECREF(pair); return -2; }
+    long long merged;
+    if (PyUnicode_GET_LENGTH(joined) == 1) merged = (long long)PyUnicode_READ_CHAR(joined, 0);
+    else {
+      PyObject *k = PyDict_GetItemWithError(index, joined);  // borrowed
+      if (k) merged = (long long)base + PyLong_AsLongLong(k);
+      else {
+        if (PyErr_Occurred()) { Py_DECREF(joined); Py_DECREF(pair); return -2; }
+        const Py_ssize_t at = PyList_GET_SIZE(strings);
+        PyObject *v = PyLong_FromSsize_t(at);
+        const int bad = !v || PyDict_SetItem(index, joined, v) < 0 || PyList_Append(strings, joined) < 0;
+        Py_XDECREF(v);
+        if (bad) { Py_DECREF(joined); Py_DECREF(pair); return -2; }
+        merged = (long long)base + at;
+      }
+    }
+    const int bad = PySet_Add(vocab, joined) < 0 || PyList_Append(merges, pair) < 0;
+    Py_DECREF(joined);
+    Py_DECREF(pair);
+    if (bad) return -2;
+    if (merged != (long long)first + i) {
+      if (collided) *collided = (uint32_t)merged;
+      return i;
+    }
+  }
+  return -1;
+}

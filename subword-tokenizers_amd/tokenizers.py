@@ -19,6 +19,8 @@ import os
 from collections import Counter
 from typing import Dict, List, Optional, Tuple
 
+import ctypes as C
+
 import numpy as np
 
 from . import _native as N
@@ -109,6 +111,9 @@ class _SymbolTable:
         return chr(sid) if sid < N.SYM_BASE else self.strings[sid - N.SYM_BASE]
 
 
+_PLAIN_INTERN = _SymbolTable.intern  # (a test swaps intern() for another to force the collision replay: then the Python loop runs)
+
+
 class NaiveBPE(SubwordTokenizer):
     """Byte-Pair Encoding (bpe.py:9-189).  `train` runs on the device; `encode_word`/`tokenize` keep the
     reference's didactic O(merges x length) loop in Python (out of the GPU scope)."""
@@ -177,7 +182,15 @@ class NaiveBPE(SubwordTokenizer):
             vocab_add, merges_append = self.vocab.add, self.merges_list.append
             ll, rl = lefts.tolist(), rights.tolist()
             taken, collided = len(ll), None
-            for i, (left, right) in enumerate(zip(ll, rl)):
+            host = N.pyhost() if _SymbolTable.intern is _PLAIN_INTERN and "intern" not in vars(syms) else None
+            if host is not None:  # the same loop in C (csrc/swt_pyhost.c), unless someone has put another intern() in place
+                la, ra = np.ascontiguousarray(lefts, dtype=np.uint32), np.ascontiguousarray(rights, dtype=np.uint32)
+                hit = C.c_uint32()
+                at = host.swt_py_bpe_merge_strings(la.ctypes.data, ra.ctypes.data, len(ll), base, first, strings, syms.index, self.vocab,
+                                                   self.merges_list, C.byref(hit))
+                if at >= 0:
+                    taken, collided = at + 1, int(hit.value)
+            for i, (left, right) in enumerate(zip(ll, rl) if host is None else ()):
                 ls = chr(left) if left < base else strings[left - base]   # _SymbolTable.string
                 rs = chr(right) if right < base else strings[right - base]
                 joined = ls + rs

@@ -423,3 +423,59 @@ def test_bench_watchdog_emits_the_line_without_the_train_block(monkeypatch):
     assert bench.train_bench_guarded(out, None, None, None, 0, 2, None, [], 8000, "x") == {"ok": True}
     assert bench.train_bench_guarded(out, None, None, None, 0, 1, None, [], 8000, "x") == {"ok": True}
     assert emitted == [] and fired == []
+
+
+def test_merge_strings_helper_is_the_python_loop(native):
+    """csrc/swt_pyhost.c swt_py_bpe_merge_strings against the per-merge loop of NaiveBPE.train it stands in for (bpe.py:102-104):
+    same strings / index / vocab / merges afterwards, same stop at the first merge whose id is not the expected one"""
+    import ctypes as C
+    import random
+
+    from subword_tokenizers_amd.tokenizers import _SymbolTable
+
+    host = native.pyhost()
+    assert host is not None
+    base = native.SYM_BASE
+    rng = random.Random(9)
+
+    def python_loop(lefts, rights, first, syms, vocab, merges):
+        for i, (left, right) in enumerate(zip(lefts, rights)):
+            ls, rs = syms.string(left), syms.string(right)
+            joined = ls + rs
+            merged = syms.intern(joined)
+            vocab.add(joined)
+            merges.append((ls, rs))
+            if merged != first + i:
+                return i, merged
+        return -1, None
+
+    for trial in range(200):
+        alphabet = [ord(c) for c in "abł中\U0001F600\ud800"][: rng.randrange(1, 7)]
+        seed_strings = []
+        for _ in range(rng.randrange(0, 6)):
+            seed_strings.append("".join(chr(rng.choice(alphabet)) for _ in range(rng.randrange(2, 5))))
+        seed_strings = list(dict.fromkeys(seed_strings))
+        states = []
+        for which in range(2):
+            syms = _SymbolTable()
+            for s_ in seed_strings:
+                syms.intern(s_)
+            states.append((syms, set("xyz"), [("x", "y")]))
+        n = rng.randrange(0, 40)
+        first = base + len(seed_strings)
+        lefts, rights = [], []
+        for i in range(n):  # ids that exist by the time merge i is reached if no collision happens (else the loop stops anyway)
+            pool = alphabet + [base + k for k in range(len(seed_strings) + i)]
+            lefts.append(rng.choice(pool)); rights.append(rng.choice(pool))
+        want = python_loop(lefts, rights, first, *states[0])
+        la, ra = np.array(lefts, dtype=np.uint32), np.array(rights, dtype=np.uint32)
+        hit = C.c_uint32()
+        syms, vocab, merges = states[1]
+        at = host.swt_py_bpe_merge_strings(la.ctypes.data, ra.ctypes.data, n, base, first, syms.strings, syms.index, vocab, merges, C.byref(hit))
+        got = (at, hit.value if at >= 0 else None)
+        assert got == want, (trial, got, want)
+        assert syms.strings == states[0][0].strings and syms.index == states[0][0].index
+        assert vocab == states[0][1] and merges == states[0][2]
+    with pytest.raises(IndexError):
+        la = np.array([base + 99], dtype=np.uint32)
+        host.swt_py_bpe_merge_strings(la.ctypes.data, la.ctypes.data, 1, base, base, [], {}, set(), [], C.byref(C.c_uint32()))
