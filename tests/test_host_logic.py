@@ -479,3 +479,26 @@ def test_merge_strings_helper_is_the_python_loop(native):
     with pytest.raises(IndexError):
         la = np.array([base + 99], dtype=np.uint32)
         host.swt_py_bpe_merge_strings(la.ctypes.data, la.ctypes.data, 1, base, base, [], {}, set(), [], C.byref(C.c_uint32()))
+
+
+def test_decode_ids_large_outputs_equal_the_per_id_spelling(swt, native, ref_dir):
+    """FastBPE.decode_ids above 4,096 ids (distinct ids found by a presence map, spelled once, references handed out) against the
+    plain per-id form, with and without csrc/swt_pyhost.c; no device needed: the rank table is built on the host"""
+    tok = swt.FastBPE()
+    tok.load_resources(os.path.join(ref_dir, "resources/pretrained/FastBPE"))
+    st = tok._syms
+    rng = np.random.default_rng(12)
+    pool = np.concatenate([np.arange(97, 123), [0x142, 0x4E2D, 0x1F600], native.SYM_BASE + rng.integers(0, len(st.strings), size=3000)]).astype(np.uint32)
+    ids = pool[rng.integers(0, pool.size, size=20000)]
+    ids[rng.random(ids.size) < 0.6] |= np.uint32(native.BPE_CONT)
+    want = [("##" + st.string(int(t))) if int(t) & native.BPE_CONT else st.string(int(t)) for t in ids]
+    assert tok.decode_ids(ids[:100]) == want[:100]
+    assert tok.decode_ids(ids) == want
+    saved = native._pyhost
+    try:
+        native._pyhost = False
+        assert tok.decode_ids(ids) == want
+    finally:
+        native._pyhost = saved
+    with pytest.raises(IndexError):
+        tok.decode_ids(np.full(5000, native.SYM_BASE + len(st.strings), dtype=np.uint32))
