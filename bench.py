@@ -341,7 +341,8 @@ def train_bench_guarded(out_so_far, args, torch, dist, rank, world, N, sents, ma
     """train_bench for the headline line.  At world > 1 the sharded runner makes RCCL calls of its own on every rank: a rank
     that fails or hangs there would take the encode half of the line with it (the other ranks wait in a collective for ever).
     So the block runs under a watchdog: if it raises on this rank or does not finish in limit_s, rank 0 writes the line with
-    train = {"error": ...} and every rank leaves at once (os._exit: no collective is entered again)."""
+    train = {"error": ...} and every rank leaves at once (os._exit: no collective is entered again) -- with exit code 3:
+    a training leg that failed, hung or broke parity is a FAILED run, whatever else the line holds."""
     if world == 1:
         return train_bench(args, torch, dist, rank, world, N, sents, max_vocab, name)
     import threading
@@ -351,7 +352,7 @@ def train_bench_guarded(out_so_far, args, torch, dist, rank, world, N, sents, ma
         sys.stderr.flush()
         if rank == 0:
             EMIT(dict(out_so_far, train={"error": why, "parallelism": "corpus-sharded x%d" % world}))
-        os._exit(0)
+        os._exit(3)
 
     timer = threading.Timer(limit_s, leave, args=("not finished after %.0f s" % limit_s,))
     timer.daemon = True

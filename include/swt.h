@@ -44,7 +44,9 @@ extern "C" {
 #define SWT_ERR_CAPACITY (-3)     /* caller buffer too small; the needed size is reported */
 #define SWT_ERR_HIP (-4)          /* a HIP call failed */
 #define SWT_ERR_UNSUPPORTED (-5)
-#define SWT_ERR_STATE (-6)        /* call out of order */
+#define SWT_ERR_STATE (-6)        /* call out of order, or an internal capacity check failed (the handle is unusable) */
+#define SWT_ERR_NOMEM (-7)        /* host memory exhausted (std::bad_alloc / std::length_error inside the library) */
+#define SWT_ERR_INTERNAL (-8)     /* any other C++ exception stopped at the ABI boundary */
 
 #define SWT_SYM_BASE 0x110000u
 #define SWT_BPE_CONT 0x80000000u
@@ -56,6 +58,10 @@ extern "C" {
 
 const char *swt_last_error(void);
 int swt_version(void);
+/* The contract above, testable without a GPU: raises a C++ exception of the given kind inside the library (1 std::bad_alloc,
+ * 2 std::length_error, 3 std::runtime_error, 4 a non-std object) and returns what the ABI's exception barrier made of it
+ * (SWT_ERR_NOMEM, SWT_ERR_NOMEM, SWT_ERR_INTERNAL, SWT_ERR_INTERNAL; swt_last_error() names the exception).  0: SWT_OK. */
+int swt_abi_selftest(int kind);
 /* Selects the HIP device for this process (one process per GPU).  Fails loudly without a GPU. */
 int swt_init(int device_ordinal);
 int swt_device_count(void);

@@ -17,7 +17,7 @@ BPE_CONT = 0x80000000
 BPE_RAW_WORDS = 1
 BPE_NO_DEDUP = 2
 WP_OK, WP_NONTERMINATING, WP_INDEXERROR = 0, 1, 2
-ERR_NO_DEVICE, ERR_INVALID, ERR_CAPACITY, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = -1, -2, -3, -4, -5, -6
+ERR_NO_DEVICE, ERR_INVALID, ERR_CAPACITY, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE, ERR_NOMEM, ERR_INTERNAL = -1, -2, -3, -4, -5, -6, -7, -8
 CLS_BERT_WS, CLS_BERT_PUNCT, CLS_PY_SPACE, CLS_PY_ALNUM = 1, 2, 4, 8
 NO_POS = 0xFFFFFFFFFFFFFFFF
 
@@ -32,6 +32,7 @@ vpp = C.POINTER(C.c_void_p)
 SIGNATURES = {
     "swt_last_error": (C.c_char_p, []),
     "swt_version": (C.c_int, []),
+    "swt_abi_selftest": (C.c_int, [C.c_int]),
     "swt_init": (C.c_int, [C.c_int]),
     "swt_device_count": (C.c_int, []),
     "swt_device_info": (C.c_int, [C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),

@@ -662,15 +662,15 @@ static void launch_encode_kernel_as(swt_bpe_table *t, uint64_t n_tiles, const Ti
 extern "C" {
 
 // diagnostics (not part of include/swt.h): resident workgroups per CU the runtime grants the encode kernel
-int swt_debug_occupancy(int which) {
+int swt_debug_occupancy(int which) try {
   int n = -1;
   hipError_t e = which ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<false, kBpeCap, 0>, 64, 0)
                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<true, kBpeCap, 0>, 64, 0);
   return e == hipSuccess ? n : -(int)e;
-}
+} SWT_API_CATCH
 
 int swt_bpe_table_create(const uint32_t *left, const uint32_t *right, const uint32_t *merged, uint32_t n_merges,
-                         swt_bpe_table **out) {
+                         swt_bpe_table **out) try {
   if (!out || (n_merges && (!left || !right || !merged))) return fail(SWT_ERR_INVALID, "null argument");
   uint32_t bits = 4;
   while ((1ull << bits) < 2ull * n_merges + 2) bits++;
@@ -704,9 +704,9 @@ int swt_bpe_table_create(const uint32_t *left, const uint32_t *right, const uint
       if (sl.key != kEmptyKey) sl.rank = (sl.rank << 16) | (sl.merged - SWT_SYM_BASE);
   *out = t;
   return SWT_OK;
-}
+} SWT_API_CATCH
 
-int swt_bpe_table_set_option(swt_bpe_table *t, int option, int value) {
+int swt_bpe_table_set_option(swt_bpe_table *t, int option, int value) try {
   if (!t) return fail(SWT_ERR_INVALID, "null table");
   switch (option) {
     case SWT_OPT_DEDUP:
@@ -723,9 +723,9 @@ int swt_bpe_table_set_option(swt_bpe_table *t, int option, int value) {
       return SWT_OK;
   }
   return fail(SWT_ERR_INVALID, "no such option");
-}
+} SWT_API_CATCH
 
-void swt_bpe_table_destroy(swt_bpe_table *t) {
+void swt_bpe_table_destroy(swt_bpe_table *t) try {
   if (!t) return;
   if (t->d_slots) (void)hipFree(t->d_slots);
   if (t->d_merged) (void)hipFree(t->d_merged);
@@ -737,7 +737,7 @@ void swt_bpe_table_destroy(swt_bpe_table *t) {
   t->small_out.release();
   for (DevBuf *b : {&t->in_text, &t->in_off, &t->out_ids, &t->out_off, &t->n_tok}) b->release();
   delete t;
-}
+} SWT_API_CATCH_VOID
 
 // the direct path: every word occurrence goes through the merge rounds
 // cap = staged bytes per chunk (LDS footprint ~ 20 B per byte): 512 for running text, less for the unique-word pass
@@ -817,7 +817,7 @@ static int bpe_encode_dedup(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_
 
 int swt_bpe_encode_dev(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off,
                        uint64_t n_sent, uint32_t *d_out_ids, uint64_t *d_out_off, uint64_t *d_n_tokens, uint32_t flags,
-                       void *stream) {
+                       void *stream) try {
   if (!t || !d_sent_off || !d_out_off || !d_n_tokens || (n_bytes && (!d_text || !d_out_ids)))
     return fail(SWT_ERR_INVALID, "null argument");
   int rc = bpe_upload(t);
@@ -840,7 +840,7 @@ int swt_bpe_encode_dev(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes
   }
   // raw-word mode: no classes, so nothing splits and nothing is dropped
   return bpe_encode_direct(t, t->ws, d_text, n_bytes, d_sent_off, n_sent, d_out_ids, d_out_off, d_n_tokens, raw ? nullptr : d_cls, st);
-}
+} SWT_API_CATCH
 
 // text and offsets on the device -> ids, offsets and the count in the caller's host arrays
 static int bpe_encode_to_host(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_off, uint64_t n_sent,
@@ -863,7 +863,7 @@ static int bpe_encode_to_host(swt_bpe_table *t, const uint8_t *d_text, uint64_t 
 }
 
 int swt_bpe_encode(swt_bpe_table *t, const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, uint32_t *out_ids,
-                   uint64_t out_cap, uint64_t *out_off, uint64_t *n_tokens, uint32_t flags) {
+                   uint64_t out_cap, uint64_t *out_off, uint64_t *n_tokens, uint32_t flags) try {
   if (!t || !sent_off || !out_off || !n_tokens) return fail(SWT_ERR_INVALID, "null argument");
   int rc = bpe_upload(t);
   if (rc) return rc;
@@ -932,13 +932,13 @@ int swt_bpe_encode(swt_bpe_table *t, const uint8_t *text, const uint64_t *sent_o
   if (n_bytes) SWT_HIP(hipMemcpyAsync(t->in_text.p, text, n_bytes, hipMemcpyHostToDevice, 0));
   SWT_HIP(hipMemcpyAsync(t->in_off.p, sent_off, (n_sent + 1) * 8, hipMemcpyHostToDevice, 0));
   return bpe_encode_to_host(t, t->in_text.as<uint8_t>(), n_bytes, t->in_off.as<uint64_t>(), n_sent, out_ids, out_cap, out_off, n_tokens, flags);
-}
+} SWT_API_CATCH
 
 // list[str] joined with U+0000 -> ids without the prepared text ever coming back to the host (swt_utf8_prepare_joined +
 // swt_bpe_encode in one call).  *n_tokens = UINT64_MAX on return: a sentence needs the host's str.lower() (need_host says
 // which) and nothing was encoded.
 int swt_bpe_encode_joined(swt_bpe_table *t, const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint32_t *out_ids, uint64_t out_cap,
-                          uint64_t *out_off, uint64_t *n_tokens, uint8_t *need_host, uint32_t flags) {
+                          uint64_t *out_off, uint64_t *n_tokens, uint8_t *need_host, uint32_t flags) try {
   if (!t || !out_off || !n_tokens || (n_sent && !need_host) || (n_joined && !joined)) return fail(SWT_ERR_INVALID, "null argument");
   int rc = bpe_upload(t);
   if (rc) return rc;
@@ -951,6 +951,6 @@ int swt_bpe_encode_joined(swt_bpe_table *t, const uint8_t *joined, uint64_t n_jo
         Ctx *c = static_cast<Ctx *>(p);
         return bpe_encode_to_host(c->t, d_text, n_bytes, d_off, c->n_sent, c->out_ids, c->out_cap, c->out_off, c->n_tokens, c->flags);
       }, &c);
-}
+} SWT_API_CATCH
 
 }  // extern "C"

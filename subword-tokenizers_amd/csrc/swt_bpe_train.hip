@@ -94,10 +94,13 @@ __device__ __forceinline__ unsigned long long pair_value(unsigned long long key,
 
 // ---- pair table --------------------------------------------------------------------------------------------------------
 // Insert-or-find; returns the slot.  Keys are never removed (a rehash drops the dead ones).
+// The host keeps the load factor below 1/2 (ensure_room), so a probe sequence is short; should that bound ever be wrong, a
+// full table must not become a hang: after one whole turn the insert gives up, raises kFlagTableFull (the host turns it into
+// SWT_ERR_STATE at its next look) and hands back the home slot -- a valid index, so nothing faults; the counts are void.
 __device__ __forceinline__ uint32_t table_slot(const PairTable &T, unsigned long long key, TrainState *st) {
   const uint32_t mask = (uint32_t)((1ull << T.bits) - 1ull);
   uint32_t h = hash_slot(key, T.bits);
-  for (;;) {
+  for (uint32_t turn = 0; turn <= mask; turn++) {
     unsigned long long k = __hip_atomic_load(&T.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (k == kEmptyKey) {
       k = atomicCAS(&T.keys[h], kEmptyKey, key);
@@ -109,6 +112,8 @@ __device__ __forceinline__ uint32_t table_slot(const PairTable &T, unsigned long
     if (k == key) return h;
     h = (h + 1) & mask;
   }
+  atomicOr(&st->flags, kFlagTableFull);
+  return hash_slot(key, T.bits);
 }
 
 __device__ __forceinline__ void cand_push(const TrainCtx &C, uint32_t slot) {
@@ -152,12 +157,13 @@ __device__ __forceinline__ void table_add(const TrainCtx &C, unsigned long long 
 __device__ __forceinline__ long long table_get(const PairTable &T, unsigned long long key) {
   const uint32_t mask = (uint32_t)((1ull << T.bits) - 1ull);
   uint32_t h = hash_slot(key, T.bits);
-  for (;;) {
+  for (uint32_t turn = 0; turn <= mask; turn++) {
     const unsigned long long k = T.keys[h];
     if (k == key) return T.cnt[h];
     if (k == kEmptyKey) return 0;
     h = (h + 1) & mask;
   }
+  return 0;  // a full table without the key (see table_slot)
 }
 
 __global__ void table_clear_kernel(unsigned long long *keys, long long *cnt, uint64_t cap) {
@@ -214,12 +220,13 @@ __global__ __launch_bounds__(kTrainThreads) void hist_build_kernel(const uint32_
 __device__ __forceinline__ uint32_t k0_find(const K0Index &K, unsigned long long key) {
   const uint32_t mask = (uint32_t)((1ull << K.bits) - 1ull);
   uint32_t h = hash_slot(key, K.bits);
-  for (;;) {
+  for (uint32_t turn = 0; turn <= mask; turn++) {
     const unsigned long long k = K.keys[h];
     if (k == key) return h;
     if (k == kEmptyKey) return 0xFFFFFFFFu;
     h = (h + 1) & mask;
   }
+  return 0xFFFFFFFFu;
 }
 
 // pass 0: occurrences per key; pass 1: fill the lists (start[] holds each list's base by then).  One lane per word, four
@@ -1983,6 +1990,35 @@ int swt_bpe_trainer::sync_state() {
   return SWT_OK;
 }
 
+int swt_bpe_trainer::ready() const {
+  if (broken) return fail(SWT_ERR_STATE, "the trainer failed a capacity check earlier and cannot go on");
+  if (!hist_ready || !T.keys || !T.cnt || !T.bits || !d_st || !d_steplog || !d_parts || !d_cmd)
+    return fail(SWT_ERR_STATE, "the trainer has no pair histogram (the handle was not completely built)");
+  if (n_words && (!K.keys || !K.words || !d_idx_tag || !d_idx_word || !d_wstamp || !d_wkey || !d_seg_start || !d_seg_of))
+    return fail(SWT_ERR_STATE, "the trainer has no inverted index (the handle was not completely built)");
+  if (n_words && (!d_sym || !d_woff || !d_freq)) return fail(SWT_ERR_STATE, "the trainer has no symbol stream");
+  return SWT_OK;
+}
+
+// What the kernels rely on without checking, looked at whenever the host has the state anyway (h_st is fresh):
+//   the pair table is at most half full (table_slot's probe sequences end; ensure_room's bound held);
+//   no insert gave up (kFlagTableFull);
+//   the candidate list, the index log and the step numbers are inside what was allocated (the device drops what does not
+//   fit and says so in flags -- kFlagReplan, kFlagIndexBroken -- so these two only bound what the HOST sized).
+int swt_bpe_trainer::check_state() {
+  const uint64_t cap = 1ull << T.bits;
+  const char *what = nullptr;
+  if (h_st.flags & kFlagTableFull) what = "an insert found the pair table full";
+  else if (2 * h_st.n_used > cap) what = "the pair table is more than half full (the head-room bound of a round trip was wrong)";
+  else if (h_st.n_syms > n_syms0) what = "more live symbols than the stream has slots";
+  else if ((uint64_t)step_no + 2 > seg_start_cap) what = "more steps than index segments were allocated for";
+  if (!what) return SWT_OK;
+  broken = true;
+  return fail(SWT_ERR_STATE, "trainer capacity check failed: %s (keys %llu of %llu slots, candidates %llu, index entries %llu of %llu, step %u)", what,
+              (unsigned long long)h_st.n_used, (unsigned long long)cap, (unsigned long long)h_st.n_cand,
+              (unsigned long long)h_st.idx_cursor, (unsigned long long)idx_cap, step_no);
+}
+
 // per-slot arrays of the sharded mode follow the table's size (called between exchanges: pend[] is all zero then)
 static int sharded_arrays(swt_bpe_trainer *t) {
   if (!t->sharded) return SWT_OK;
@@ -2348,7 +2384,7 @@ void swt_bpe_trainer::enqueue_apply() {
 
 #ifdef SWT_STAMPS
 // diagnostic builds only (not in include/swt.h): read = 0 resets the stamps, 1 copies spans (4 * 16384) then phases (3 * 16), then g_why (32)
-extern "C" int swt_debug_stamps(int read, unsigned long long *out) {
+extern "C" int swt_debug_stamps(int read, unsigned long long *out) try {
   if (!read) {
     static unsigned long long init[4][kSpanSteps];
     for (uint32_t i = 0; i < kSpanSteps; i++) { init[0][i] = ~0ull; init[1][i] = 0; init[2][i] = ~0ull; init[3][i] = 0; }
@@ -2367,13 +2403,13 @@ extern "C" int swt_debug_stamps(int read, unsigned long long *out) {
   if (hipMemcpyFromSymbol(out + 4 * kSpanSteps + 48, HIP_SYMBOL(g_why), sizeof(unsigned long long) * 32) != hipSuccess) return -4;
   if (hipMemcpyFromSymbol(out + 4 * kSpanSteps + 80, HIP_SYMBOL(g_kstep), sizeof(unsigned int) * kSpanSteps) != hipSuccess) return -4;
   return hipMemcpyFromSymbol(out + 4 * kSpanSteps + 80 + kSpanSteps / 2, HIP_SYMBOL(g_pmax), sizeof g_pmax) == hipSuccess ? 0 : -4;
-}
+} SWT_API_CATCH
 #endif
 
 extern "C" {
 
 int swt_bpe_train_create_words(const uint32_t *syms, const uint64_t *word_off, const uint32_t *freq, uint64_t n_words,
-                               swt_bpe_trainer **out) {
+                               swt_bpe_trainer **out) try {
   if (!out || !word_off || (n_words && (!freq || (word_off[n_words] && !syms)))) return fail(SWT_ERR_INVALID, "null argument");
   if (word_off[0] != 0) return fail(SWT_ERR_INVALID, "word_off[0] must be 0");
   auto *t = new swt_bpe_trainer();
@@ -2381,7 +2417,7 @@ int swt_bpe_train_create_words(const uint32_t *syms, const uint64_t *word_off, c
   if (rc) { swt_bpe_train_destroy(t); return rc; }
   *out = t;
   return SWT_OK;
-}
+} SWT_API_CATCH
 
 static int words_from_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, swt_bpe_trainer **out) {
   if (!out || !sent_off || (n_sent && sent_off[n_sent] && !text)) return fail(SWT_ERR_INVALID, "null argument");
@@ -2406,38 +2442,27 @@ static int words_from_text(const uint8_t *text, const uint64_t *sent_off, uint64
   return SWT_OK;
 }
 
+static int trainer_from_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint8_t *need_host, bool wordpiece,
+                               swt_bpe_trainer **out);
+
 // The same from the texts joined with U+0000 (swt_utf8_prepare_joined's input): offsets, lowercase and the word census without
 // the prepared text travelling to the host and back.  need_host[s] = 1: sentence s holds a code point only the host lowercases;
 // then *out stays NULL and the caller takes the host-array way.
-int swt_bpe_train_create_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint8_t *need_host, swt_bpe_trainer **out) {
+int swt_bpe_train_create_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint8_t *need_host, swt_bpe_trainer **out) try {
   if (!out || (n_sent && !need_host) || (n_joined && !joined)) return fail(SWT_ERR_INVALID, "null argument");
   *out = nullptr;
-  const uint8_t *d_text = nullptr;
-  const uint64_t *d_off = nullptr;
-  uint64_t n_bytes = 0;
-  int rc = prepare_joined_dev(joined, n_joined, n_sent, need_host, &d_text, &d_off, &n_bytes);
-  if (rc) return rc;
-  for (uint64_t s2 = 0; s2 < n_sent; s2++)
-    if (need_host[s2]) return SWT_OK;
-  DeviceWords dw;
-  if ((rc = device_words_from_text(d_text, n_bytes, d_off, n_sent, &dw))) return rc;
-  auto *t = new swt_bpe_trainer();
-  rc = trainer_adopt(t, dw);
-  if (!rc) rc = finish_create(t);  // histogram, index
-  if (rc) { swt_bpe_train_destroy(t); return rc; }
-  *out = t;
-  return SWT_OK;
-}
+  return trainer_from_joined(joined, n_joined, n_sent, need_host, false, out);
+} SWT_API_CATCH
 
 // bpe.py:70-81 on the device (swt_words.hip): split (utils.py:27), Counter(words) in first-occurrence order, symbolise.
-int swt_bpe_train_create_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, swt_bpe_trainer **out) {
+int swt_bpe_train_create_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, swt_bpe_trainer **out) try {
   swt_bpe_trainer *t = nullptr;
   int rc = words_from_text(text, sent_off, n_sent, &t);
   if (rc) return rc;
   if ((rc = finish_create(t))) { swt_bpe_train_destroy(t); return rc; }
   *out = t;
   return SWT_OK;
-}
+} SWT_API_CATCH
 
 // wordpiece.py:44-63 on the device: the same split and Counter, then [word[0]] + ["##" + c ...] and the symbol frequencies.
 // The handle is used with the swt_bpe_train_* calls; `count` outputs carry the winning score's bit pattern.
@@ -2477,32 +2502,45 @@ static int wp_finish_create(swt_bpe_trainer *t, swt_bpe_trainer **out) {
   return SWT_OK;
 }
 
-int swt_wp_train_create_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, swt_bpe_trainer **out) {
+// Both trainers from the joined texts.  The prepared text lives in the calling thread's prepare workspace only while the word
+// census reads it (with_prepared_joined: the workspace's guard releases it on every error path and above its keep limit --
+// a 1 GiB corpus does not stay pinned in the thread); the trainer owns copies of nothing but the census' own arrays.
+// A handle leaves this function only after finish_create (histogram + index): swt_bpe_trainer::ready() refuses any other.
+static int trainer_from_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint8_t *need_host, bool wordpiece,
+                               swt_bpe_trainer **out) {
+  struct Ctx { uint64_t n_sent; DeviceWords dw; } c{n_sent, {}};
+  bool consumed = false;
+  int rc = with_prepared_joined(joined, n_joined, n_sent, need_host, &consumed,
+      [](void *p, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_off) {
+        Ctx *c = static_cast<Ctx *>(p);
+        return device_words_from_text(d_text, n_bytes, d_off, c->n_sent, &c->dw);
+      }, &c);
+  auto drop = [&]() { for (void *q : {(void *)c.dw.d_sym, (void *)c.dw.d_woff, (void *)c.dw.d_freq}) if (q) (void)hipFree(q); };
+  if (rc) { drop(); return rc; }
+  if (!consumed) return SWT_OK;  // a sentence needs the host's str.lower(): *out stays NULL
+  auto *t = new swt_bpe_trainer();
+  if ((rc = trainer_adopt(t, c.dw))) { drop(); swt_bpe_train_destroy(t); return rc; }
+  if (wordpiece) return wp_finish_create(t, out);
+  if ((rc = finish_create(t))) { swt_bpe_train_destroy(t); return rc; }  // histogram, index
+  *out = t;
+  return SWT_OK;
+}
+
+int swt_wp_train_create_text(const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, swt_bpe_trainer **out) try {
   swt_bpe_trainer *t = nullptr;
   int rc = words_from_text(text, sent_off, n_sent, &t);
   if (rc) return rc;
   return wp_finish_create(t, out);
-}
+} SWT_API_CATCH
 
 // the WordPiece trainer from the joined texts: see swt_bpe_train_create_joined
-int swt_wp_train_create_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint8_t *need_host, swt_bpe_trainer **out) {
+int swt_wp_train_create_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint8_t *need_host, swt_bpe_trainer **out) try {
   if (!out || (n_sent && !need_host) || (n_joined && !joined)) return fail(SWT_ERR_INVALID, "null argument");
   *out = nullptr;
-  const uint8_t *d_text = nullptr;
-  const uint64_t *d_off = nullptr;
-  uint64_t n_bytes = 0;
-  int rc = prepare_joined_dev(joined, n_joined, n_sent, need_host, &d_text, &d_off, &n_bytes);
-  if (rc) return rc;
-  for (uint64_t s2 = 0; s2 < n_sent; s2++)
-    if (need_host[s2]) return SWT_OK;
-  DeviceWords dw;
-  if ((rc = device_words_from_text(d_text, n_bytes, d_off, n_sent, &dw))) return rc;
-  auto *t = new swt_bpe_trainer();
-  if ((rc = trainer_adopt(t, dw))) { swt_bpe_train_destroy(t); return rc; }
-  return wp_finish_create(t, out);
-}
+  return trainer_from_joined(joined, n_joined, n_sent, need_host, true, out);
+} SWT_API_CATCH
 
-void swt_bpe_train_destroy(swt_bpe_trainer *t) {
+void swt_bpe_train_destroy(swt_bpe_trainer *t) try {
   if (!t) return;
   (void)hipStreamSynchronize(t->stream);
   for (void *p : {(void *)t->d_sym, (void *)t->d_woff, (void *)t->d_freq, (void *)t->d_st, (void *)t->d_parts, (void *)t->d_cmd,
@@ -2515,16 +2553,17 @@ void swt_bpe_train_destroy(swt_bpe_trainer *t) {
   table_free(t->T);
   t->tmp.release();
   delete t;
-}
+} SWT_API_CATCH_VOID
 
-int swt_bpe_train_set_pos_base(swt_bpe_trainer *t, uint64_t pos_base) {
+int swt_bpe_train_set_pos_base(swt_bpe_trainer *t, uint64_t pos_base) try {
   if (!t) return fail(SWT_ERR_INVALID, "null trainer");
   t->pos_base = pos_base;
   return SWT_OK;
-}
+} SWT_API_CATCH
 
-int swt_bpe_train_info(const swt_bpe_trainer *t, uint64_t *n_words, uint64_t *n_symbols, uint32_t *n_base_symbols, uint64_t *n_pairs) {
+int swt_bpe_train_info(const swt_bpe_trainer *t, uint64_t *n_words, uint64_t *n_symbols, uint32_t *n_base_symbols, uint64_t *n_pairs) try {
   if (!t) return fail(SWT_ERR_INVALID, "null trainer");
+  if (!t->d_st) return fail(SWT_ERR_STATE, "the trainer has no device state");
   TrainState r;
   SWT_HIP(hipMemcpy(&r, t->d_st, sizeof r, hipMemcpyDeviceToHost));
   if (n_words) *n_words = t->n_words;
@@ -2532,19 +2571,20 @@ int swt_bpe_train_info(const swt_bpe_trainer *t, uint64_t *n_words, uint64_t *n_
   if (n_base_symbols) *n_base_symbols = t->n_base;
   if (n_pairs) *n_pairs = r.n_used;
   return SWT_OK;
-}
+} SWT_API_CATCH
 
-int swt_bpe_train_stats(const swt_bpe_trainer *t, uint64_t *out, uint32_t n) {
+int swt_bpe_train_stats(const swt_bpe_trainer *t, uint64_t *out, uint32_t n) try {
   if (!t || !out) return fail(SWT_ERR_INVALID, "null argument");
+  if (!t->d_st || !t->T.bits) return fail(SWT_ERR_STATE, "the trainer has no device state");
   TrainState r;
   SWT_HIP(hipMemcpy(&r, t->d_st, sizeof r, hipMemcpyDeviceToHost));
   const uint64_t v[10] = {t->n_replans, t->theta, r.n_cand, r.idx_cursor, (uint64_t)(1ull << t->T.bits), r.flags, t->step_no, r.n_used,
                           r.ent_scanned, r.tie_words};
   for (uint32_t i = 0; i < n && i < 10; i++) out[i] = v[i];
   return SWT_OK;
-}
+} SWT_API_CATCH
 
-int swt_bpe_train_trace(const swt_bpe_trainer *t, uint64_t *rows, uint64_t cap_rows, uint64_t *n_rows) {
+int swt_bpe_train_trace(const swt_bpe_trainer *t, uint64_t *rows, uint64_t cap_rows, uint64_t *n_rows) try {
   if (!t || !n_rows) return fail(SWT_ERR_INVALID, "null argument");
   *n_rows = t->trace.size();
   for (uint64_t i = 0; rows && i < t->trace.size() && i < cap_rows; i++) {
@@ -2554,26 +2594,27 @@ int swt_bpe_train_trace(const swt_bpe_trainer *t, uint64_t *rows, uint64_t cap_r
     rows[4 * i + 3] = t->trace[i].n_syms;
   }
   return SWT_OK;
-}
+} SWT_API_CATCH
 
-int swt_bpe_train_base_symbols(const swt_bpe_trainer *t, uint32_t *out, uint32_t cap) {
+int swt_bpe_train_base_symbols(const swt_bpe_trainer *t, uint32_t *out, uint32_t cap) try {
   if (!t) return fail(SWT_ERR_INVALID, "null trainer");
   if (cap < t->n_base) return fail(SWT_ERR_CAPACITY, "need room for %u symbols", t->n_base);
   std::copy(t->base_syms.begin(), t->base_syms.end(), out);
   return SWT_OK;
-}
+} SWT_API_CATCH
 
 int swt_bpe_train_best(swt_bpe_trainer *t, uint32_t *left, uint32_t *right, uint64_t *count, uint64_t *n_tied,
-                       uint64_t *first_pos) {
+                       uint64_t *first_pos) try {
   if (!t || !left || !right || !count) return fail(SWT_ERR_INVALID, "null argument");
   int rc = ensure_device();
   if (rc) return rc;
+  if ((rc = t->ready())) return rc;
   for (int attempt = 0;; attempt++) {
     if (!t->cand_valid && (rc = t->replan())) return rc;
     t->enqueue_argmax();
     hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(64), 0, t->stream, t->d_sym, t->d_woff, t->ctx(), t->d_parts, t->n_parts,
                        (StepCmd *)nullptr, (StepLog *)nullptr, 0u, 0u);
-    if ((rc = t->sync_state())) return rc;
+    if ((rc = t->sync_state()) || (rc = t->check_state())) return rc;
     if (!(t->h_st.flags & kFlagReplan)) break;
     if (attempt > 64) return fail(SWT_ERR_STATE, "the candidate list cannot be rebuilt");
     t->cand_valid = false;  // the list ran dry or overflowed: new theta, again
@@ -2594,13 +2635,14 @@ int swt_bpe_train_best(swt_bpe_trainer *t, uint32_t *left, uint32_t *right, uint
   *right = (uint32_t)key;
   if (first_pos) *first_pos = pos;
   return SWT_OK;
-}
+} SWT_API_CATCH
 
-int swt_bpe_train_apply(swt_bpe_trainer *t, uint32_t left, uint32_t right, uint32_t merged) {
+int swt_bpe_train_apply(swt_bpe_trainer *t, uint32_t left, uint32_t right, uint32_t merged) try {
   if (!t) return fail(SWT_ERR_INVALID, "null trainer");
   int rc = ensure_device();
   if (rc) return rc;
   if (t->sharded) return fail(SWT_ERR_STATE, "a sharded trainer is stepped by swt_bpe_train_run_sharded");
+  if ((rc = t->ready())) return rc;
   if (merged == kHole) return fail(SWT_ERR_INVALID, "symbol id 0xFFFFFFFF is reserved");
   if (t->d_sfreq && (left >= kWpSymCap || right >= kWpSymCap || merged >= kWpSymCap))
     return fail(SWT_ERR_UNSUPPORTED, "WordPiece symbol id beyond %llu", (unsigned long long)kWpSymCap);
@@ -2617,12 +2659,12 @@ int swt_bpe_train_apply(swt_bpe_trainer *t, uint32_t left, uint32_t right, uint3
   t->h_st.n_used += occ;
   t->n_applied++;
   return SWT_OK;
-}
+} SWT_API_CATCH
 
 // Up to max_steps iterations of {argmax, tie-break, decide, apply} enqueued back to back: the pair of step i stays on the
 // device (decide_kernel -> apply_kernel), only the log comes back.  Step i merges into symbol first_merged + i.
 int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_merged, uint32_t *left, uint32_t *right,
-                      uint64_t *count, uint32_t *n_done) {
+                      uint64_t *count, uint32_t *n_done) try {
   if (!t || !left || !right || !count || !n_done) return fail(SWT_ERR_INVALID, "null argument");
   if (t->sharded) return fail(SWT_ERR_STATE, "swt_bpe_train_run is for unsharded training (see swt_bpe_train_run_sharded)");
   if (t->d_sfreq && (uint64_t)first_merged + max_steps > kWpSymCap)
@@ -2631,6 +2673,7 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
   int rc = ensure_device();
   if (rc) return rc;
   *n_done = 0;
+  if ((rc = t->ready())) return rc;
   std::vector<StepLog> hlog(kMaxRunSteps);
   uint32_t done = 0;
   bool exhausted = false;
@@ -2709,8 +2752,9 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
     }
     prof_end(t->stream);
     SWT_HIP(hipGetLastError());
+    if (cap > kMaxRunSteps) return fail(SWT_ERR_STATE, "a round trip was sized beyond the step log (%u rows)", cap);
     SWT_HIP(hipMemcpyAsync(hlog.data(), t->d_steplog, cap * sizeof(StepLog), hipMemcpyDeviceToHost, t->stream));
-    if ((rc = t->sync_state())) return rc;
+    if ((rc = t->sync_state()) || (rc = t->check_state())) return rc;
     uint32_t good = 0;
     unsigned long long stop = 0;  // why the device stopped before `cap`: 0 (it did not), 2 no pair left, 3 re-plan
     if (fast) {
@@ -2758,10 +2802,11 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
   }
   *n_done = done;
   return SWT_OK;
-}
+} SWT_API_CATCH
 
-int swt_bpe_train_export(swt_bpe_trainer *t, uint32_t *syms, uint64_t syms_cap, uint64_t *word_off, uint32_t *freq) {
+int swt_bpe_train_export(swt_bpe_trainer *t, uint32_t *syms, uint64_t syms_cap, uint64_t *word_off, uint32_t *freq) try {
   if (!t || !word_off) return fail(SWT_ERR_INVALID, "null argument");
+  if (!t->d_st || (t->n_words && (!t->d_sym || !t->d_woff))) return fail(SWT_ERR_STATE, "the trainer has no symbol stream");
   SWT_HIP(hipStreamSynchronize(t->stream));
   std::vector<uint32_t> all(t->extent + 1);
   std::vector<uint64_t> woff(t->n_words + 1);
@@ -2779,11 +2824,12 @@ int swt_bpe_train_export(swt_bpe_trainer *t, uint32_t *syms, uint64_t syms_cap, 
   word_off[t->n_words] = o;
   if (freq && t->n_words) SWT_HIP(hipMemcpy(freq, t->d_freq, t->n_words * 4, hipMemcpyDeviceToHost));
   return SWT_OK;
-}
+} SWT_API_CATCH
 
-int swt_bpe_train_histogram(swt_bpe_trainer *t, uint64_t *keys, uint64_t *counts, uint64_t cap, uint64_t *n) {
+int swt_bpe_train_histogram(swt_bpe_trainer *t, uint64_t *keys, uint64_t *counts, uint64_t cap, uint64_t *n) try {
   if (!t || !n) return fail(SWT_ERR_INVALID, "null argument");
   int rc;
+  if ((rc = t->ready())) return rc;
   if ((rc = t->tmp.reserve(cap * 16 + 32))) return rc;
   unsigned long long *d_n = t->tmp.as<unsigned long long>();
   DeltaRec *d_r = reinterpret_cast<DeltaRec *>(d_n + 2);
@@ -2801,7 +2847,7 @@ int swt_bpe_train_histogram(swt_bpe_trainer *t, uint64_t *keys, uint64_t *counts
     for (uint64_t i = 0; i < got; i++) { keys[i] = h[i].key; counts[i] = (uint64_t)h[i].delta; }
   }
   return SWT_OK;
-}
+} SWT_API_CATCH
 
 }  // extern "C"
 

@@ -25,6 +25,14 @@ int fail(int code, const char *fmt, ...);
       return ::swt::fail(SWT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
   } while (0)
 
+// The exception barrier of the C ABI (include/swt.h: "nothing throws, aborts"): every extern "C" entry point is a
+// function-try-block that ends in SWT_API_CATCH, so a std::bad_alloc / std::length_error from a host-side container (or
+// anything else) becomes SWT_ERR_NOMEM / SWT_ERR_INTERNAL + swt_last_error() instead of std::terminate -> SIGABRT.
+// api_exception() must be called inside a catch block (it rethrows to classify).
+int api_exception() noexcept;
+#define SWT_API_CATCH catch (...) { return ::swt::api_exception(); }
+#define SWT_API_CATCH_VOID catch (...) { (void)::swt::api_exception(); }
+
 int ensure_device();  // SWT_OK when a device is selected (selects 0 on first use)
 int device_cus();
 

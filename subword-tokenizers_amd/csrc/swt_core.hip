@@ -1,5 +1,7 @@
 // swt_core.hip -- process-level state of libswt_hip.so: error text, device selection, class tables.
 #include <mutex>
+#include <new>
+#include <stdexcept>
 
 #include "swt_common.h"
 #include "unicode_classes.inc"
@@ -8,13 +10,18 @@ namespace swt {
 
 static thread_local std::string g_err;
 
+// (the assignment may allocate: an error path must not throw on its own)
+static void keep_error(const char *text) noexcept {
+  try { g_err = text; } catch (...) { }
+}
+
 void set_error(const char *fmt, ...) {
   char buf[1024];
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
-  g_err = buf;
+  keep_error(buf);
 }
 
 int fail(int code, const char *fmt, ...) {
@@ -23,8 +30,22 @@ int fail(int code, const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
-  g_err = buf;
+  keep_error(buf);
   return code;
+}
+
+int api_exception() noexcept {
+  try {
+    throw;
+  } catch (const std::bad_alloc &) {
+    return fail(SWT_ERR_NOMEM, "out of host memory (std::bad_alloc) inside libswt_hip");
+  } catch (const std::length_error &e) {
+    return fail(SWT_ERR_NOMEM, "a host container was asked for an impossible size (std::length_error: %s)", e.what());
+  } catch (const std::exception &e) {
+    return fail(SWT_ERR_INTERNAL, "C++ exception stopped at the ABI boundary: %s", e.what());
+  } catch (...) {
+    return fail(SWT_ERR_INTERNAL, "unknown C++ exception stopped at the ABI boundary");
+  }
 }
 
 static int g_device = -1;
@@ -157,22 +178,33 @@ extern "C" {
 
 const char *swt_last_error(void) { return swt::g_err.c_str(); }
 
-int swt_version(void) { return 1; }
+int swt_version(void) { return 2; }
 
-int swt_device_count(void) {
+int swt_abi_selftest(int kind) try {
+  switch (kind) {
+    case 0: return SWT_OK;
+    case 1: throw std::bad_alloc();
+    case 2: { std::vector<uint64_t> v; v.resize(v.max_size() + 1); return (int)v.size(); }
+    case 3: throw std::runtime_error("swt_abi_selftest");
+    case 4: throw 42;
+    default: return swt::fail(SWT_ERR_INVALID, "no such self test");
+  }
+} SWT_API_CATCH
+
+int swt_device_count(void) try {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
-}
+} SWT_API_CATCH
 
-int swt_init(int device_ordinal) {
+int swt_init(int device_ordinal) try {
   std::lock_guard<std::mutex> lk(swt::g_mu);
   if (swt::g_device >= 0 && swt::g_device != device_ordinal && swt::g_cls_dev)
     return swt::fail(SWT_ERR_STATE, "device %d already selected for this process", swt::g_device);
   return swt::select_device(device_ordinal);
-}
+} SWT_API_CATCH
 
-int swt_device_info(int *n_cu, char *name, size_t name_cap) {
+int swt_device_info(int *n_cu, char *name, size_t name_cap) try {
   int rc = swt::ensure_device();
   if (rc) return rc;
   hipDeviceProp_t prop;
@@ -182,7 +214,7 @@ int swt_device_info(int *n_cu, char *name, size_t name_cap) {
     snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
   }
   return SWT_OK;
-}
+} SWT_API_CATCH
 
 #ifdef SWT_ABLATION
 int swt_ablation_knob(int which, int value) {  // not declared in include/swt.h: ablation builds only
@@ -192,12 +224,12 @@ int swt_ablation_knob(int which, int value) {  // not declared in include/swt.h:
 }
 #endif
 
-int swt_profile_enable(int on) {
+int swt_profile_enable(int on) try {
   swt::g_prof_on = on;
   return SWT_OK;
-}
+} SWT_API_CATCH
 
-int swt_profile_read(double *ms_total, uint64_t *n_launches) {
+int swt_profile_read(double *ms_total, uint64_t *n_launches) try {
   double ms = 0;
   uint64_t n = 0;
   for (auto &ev : swt::g_prof_pending) {
@@ -212,8 +244,8 @@ int swt_profile_read(double *ms_total, uint64_t *n_launches) {
   if (ms_total) *ms_total = ms;
   if (n_launches) *n_launches = n;
   return SWT_OK;
-}
+} SWT_API_CATCH
 
-unsigned swt_class_of(uint32_t cp) { return cp < swt::kNumCodePoints ? swt::host_class_table()[cp] : 0u; }
+unsigned swt_class_of(uint32_t cp) try { return cp < swt::kNumCodePoints ? swt::host_class_table()[cp] : 0u; } catch (...) { (void)::swt::api_exception(); return 0; }
 
 }  // extern "C"

@@ -112,8 +112,11 @@ int check_group(swt_dist *d, swt_bpe_trainer **tr, uint32_t n_local) {
   if (d->local ? n_local != (uint32_t)d->world : n_local != 1)
     return fail(SWT_ERR_INVALID, "%s communicator of %d ranks needs %d local trainer(s), got %u", d->local ? "a loop-back" : "an RCCL", d->world,
                 d->local ? d->world : 1, n_local);
-  for (uint32_t i = 0; i < n_local; i++)
+  for (uint32_t i = 0; i < n_local; i++) {
     if (!tr[i]) return fail(SWT_ERR_INVALID, "null trainer");
+    int rc = tr[i]->ready();  // a handle without histogram / index never reaches a kernel
+    if (rc) return rc;
+  }
   return SWT_OK;
 }
 
@@ -123,7 +126,7 @@ int rank_of(const swt_dist *d, uint32_t i) { return d->local ? (int)i : d->rank;
 
 extern "C" {
 
-int swt_dist_unique_id(uint8_t *out128) {
+int swt_dist_unique_id(uint8_t *out128) try {
   if (!out128) return fail(SWT_ERR_INVALID, "null argument");
   int rc = ensure_device();
   if (rc) return rc;
@@ -133,9 +136,9 @@ int swt_dist_unique_id(uint8_t *out128) {
   static_assert(sizeof id == 128, "ncclUniqueId is 128 bytes");
   memcpy(out128, &id, 128);
   return SWT_OK;
-}
+} SWT_API_CATCH
 
-int swt_dist_init(int rank, int world, const uint8_t *unique_id128, swt_dist **out) {
+int swt_dist_init(int rank, int world, const uint8_t *unique_id128, swt_dist **out) try {
   if (!out || !unique_id128 || world < 1 || rank < 0 || rank >= world) return fail(SWT_ERR_INVALID, "bad rank / world / id");
   int rc = ensure_device();
   if (rc) return rc;
@@ -152,9 +155,9 @@ int swt_dist_init(int rank, int world, const uint8_t *unique_id128, swt_dist **o
   }
   *out = d;
   return SWT_OK;
-}
+} SWT_API_CATCH
 
-int swt_dist_init_local(int world, swt_dist **out) {
+int swt_dist_init_local(int world, swt_dist **out) try {
   if (!out || world < 1 || world > 64) return fail(SWT_ERR_INVALID, "bad world size");
   int rc = ensure_device();
   if (rc) return rc;
@@ -163,27 +166,27 @@ int swt_dist_init_local(int world, swt_dist **out) {
   d->local = true;
   *out = d;
   return SWT_OK;
-}
+} SWT_API_CATCH
 
-void swt_dist_destroy(swt_dist *d) {
+void swt_dist_destroy(swt_dist *d) try {
   if (!d) return;
   if (d->comm) (void)g_rccl.CommDestroy(d->comm);
   d->stage_send.release();
   d->stage_recv.release();
   delete d;
-}
+} SWT_API_CATCH_VOID
 
-int swt_dist_info(const swt_dist *d, int *rank, int *world, int *is_local) {
+int swt_dist_info(const swt_dist *d, int *rank, int *world, int *is_local) try {
   if (!d) return fail(SWT_ERR_INVALID, "null argument");
   if (rank) *rank = d->rank;
   if (world) *world = d->world;
   if (is_local) *is_local = d->local ? 1 : 0;
   return SWT_OK;
-}
+} SWT_API_CATCH
 
 // Enter sharded mode: the distinct initial symbols of the whole corpus (bpe.py:75 over all shards) and the one-off
 // reduction of the local histograms (every rank adds every other rank's (pair, count) list to its replica).
-int swt_bpe_train_shard_begin(swt_bpe_trainer **tr, uint32_t n_local, swt_dist *d, uint32_t *base_out, uint32_t base_cap, uint32_t *n_base) {
+int swt_bpe_train_shard_begin(swt_bpe_trainer **tr, uint32_t n_local, swt_dist *d, uint32_t *base_out, uint32_t base_cap, uint32_t *n_base) try {
   int rc = check_group(d, tr, n_local);
   if (rc) return rc;
   if (!n_base) return fail(SWT_ERR_INVALID, "null argument");
@@ -261,7 +264,7 @@ int swt_bpe_train_shard_begin(swt_bpe_trainer **tr, uint32_t n_local, swt_dist *
   }
   release();
   return SWT_OK;
-}
+} SWT_API_CATCH
 
 // One failed exchange: the largest block any rank wanted, from the headers every rank received.
 static int exchange_again(swt_dist *d, swt_bpe_trainer **tr, uint32_t n_local) {
@@ -295,7 +298,7 @@ static int exchange_again(swt_dist *d, swt_bpe_trainer **tr, uint32_t n_local) {
 
 // Up to max_steps merges over all shards.  Outputs as swt_bpe_train_run (identical on every rank).
 int swt_bpe_train_run_sharded(swt_bpe_trainer **tr, uint32_t n_local, swt_dist *d, uint32_t max_steps, uint32_t first_merged, uint32_t *left,
-                              uint32_t *right, uint64_t *count, uint32_t *n_done) {
+                              uint32_t *right, uint64_t *count, uint32_t *n_done) try {
   int rc = check_group(d, tr, n_local);
   if (rc) return rc;
   if (!left || !right || !count || !n_done) return fail(SWT_ERR_INVALID, "null argument");
@@ -333,7 +336,7 @@ int swt_bpe_train_run_sharded(swt_bpe_trainer **tr, uint32_t n_local, swt_dist *
     SWT_HIP(hipMemcpyAsync(hlog.data(), tr[0]->d_steplog, k * sizeof(StepLog), hipMemcpyDeviceToHost, tr[0]->stream));
     SWT_HIP(hipMemcpyAsync(&halt, tr[0]->d_halt, 4, hipMemcpyDeviceToHost, tr[0]->stream));
     for (uint32_t i = 0; i < n_local; i++)
-      if ((rc = tr[i]->sync_state())) return rc;
+      if ((rc = tr[i]->sync_state()) || (rc = tr[i]->check_state())) return rc;
     uint32_t good = 0;
     while (good < k && hlog[good].flag == 0) {
       left[done] = hlog[good].l;
@@ -361,6 +364,6 @@ int swt_bpe_train_run_sharded(swt_bpe_trainer **tr, uint32_t n_local, swt_dist *
   }
   *n_done = done;
   return SWT_OK;
-}
+} SWT_API_CATCH
 
 }  // extern "C"

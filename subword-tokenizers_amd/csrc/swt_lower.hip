@@ -166,9 +166,14 @@ __global__ __launch_bounds__(64) void sep_count_kernel(const uint8_t *__restrict
   if (threadIdx.x == 0) blk_cnt[blockIdx.x] = c;
 }
 
+// `out` holds n_bytes - (n_sent - 1) bytes: right when the text holds exactly n_sent - 1 separators.  The host only learns the
+// true count from the scan's total, which it reads AFTER this launch (one synchronisation instead of two), so every write is
+// bounded by what was allocated: with fewer separators than announced the tail of the text is dropped here -- not written
+// past the buffer -- and the host then rejects the call (SWT_ERR_INVALID).
 __global__ __launch_bounds__(64) void sep_split_kernel(const uint8_t *__restrict__ text, uint64_t n_bytes, uint64_t n_sent,
                                                        const uint32_t *__restrict__ blk_local, const unsigned long long *__restrict__ blk_base,
                                                        uint8_t *__restrict__ out, uint64_t *__restrict__ byte_off) {
+  const uint64_t out_cap = n_bytes - (n_sent ? n_sent - 1 : 0);
   const uint64_t b = blockIdx.x, b0 = b * kOffBlock;
   const int lane = threadIdx.x;
   uint64_t z = blk_base[b >> 10] + blk_local[b];  // separators before this block
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(64) void sep_split_kernel(const uint8_t *__restrict
     const unsigned long long M = __ballot(sep);
     const uint64_t mine = z + (uint64_t)__popcll(M & ((1ull << lane) - 1ull));  // separators before this byte
     if (g < n_bytes) {
-      if (!sep) out[g - mine] = c;
+      if (!sep) { if (g - mine < out_cap) out[g - mine] = c; }
       else if (mine + 1 < n_sent) byte_off[mine + 1] = g - mine;  // sentence mine + 1 starts behind this separator
     }
     z += (uint64_t)__popcll(M);
@@ -275,12 +280,12 @@ int with_prepared_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n_se
 
 extern "C" {
 
-uint32_t swt_lower_of(uint32_t cp) { return cp < kNumCodePoints ? host_lower_table()[cp] : cp; }
+uint32_t swt_lower_of(uint32_t cp) try { return cp < kNumCodePoints ? host_lower_table()[cp] : cp; } catch (...) { (void)::swt::api_exception(); return 0; }
 
 const char *swt_unidata_version(void) { return SWT_UNIDATA_VERSION; }
 
 int swt_utf8_lower_dev(uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off, uint64_t n_sent, uint8_t *d_need_host,
-                       void *stream) {
+                       void *stream) try {
   if (!d_sent_off || (n_bytes && !d_text) || (n_sent && !d_need_host)) return fail(SWT_ERR_INVALID, "null argument");
   int rc = ensure_device();
   if (rc) return rc;
@@ -295,7 +300,7 @@ int swt_utf8_lower_dev(uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent
   }
   SWT_HIP(hipGetLastError());
   return SWT_OK;
-}
+} SWT_API_CATCH
 
 // d_byte_off[s] = byte at which the sentence that starts after d_cp_off[s] code points begins (n_sent + 1 entries; well-formed
 // UTF-8: a code point is a byte that is not a continuation byte)
@@ -313,7 +318,7 @@ static int utf8_offsets_dev(const uint8_t *d_text, uint64_t n_bytes, const uint6
   return SWT_OK;
 }
 
-int swt_utf8_prepare(uint8_t *text, uint64_t n_bytes, const uint64_t *cp_off, uint64_t n_sent, uint64_t *byte_off, uint8_t *need_host) {
+int swt_utf8_prepare(uint8_t *text, uint64_t n_bytes, const uint64_t *cp_off, uint64_t n_sent, uint64_t *byte_off, uint8_t *need_host) try {
   if (!cp_off || !byte_off || (n_sent && !need_host) || (n_bytes && !text)) return fail(SWT_ERR_INVALID, "null argument");
   if (cp_off[0] != 0) return fail(SWT_ERR_INVALID, "cp_off[0] must be 0");
   for (uint64_t s = 0; s < n_sent; s++)
@@ -342,9 +347,9 @@ int swt_utf8_prepare(uint8_t *text, uint64_t n_bytes, const uint64_t *cp_off, ui
   }
   guard.ok = rc == SWT_OK;
   return rc;
-}
+} SWT_API_CATCH
 
-int swt_utf8_prepare_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint8_t *text_out, uint64_t *byte_off, uint8_t *need_host) {
+int swt_utf8_prepare_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint8_t *text_out, uint64_t *byte_off, uint8_t *need_host) try {
   if (!byte_off || (n_sent && !need_host) || (n_joined && (!joined || !text_out))) return fail(SWT_ERR_INVALID, "null argument");
   PrepareWs &W = prepare_ws();
   PrepareGuard guard{W};
@@ -356,9 +361,9 @@ int swt_utf8_prepare_joined(const uint8_t *joined, uint64_t n_joined, uint64_t n
   }
   guard.ok = rc == SWT_OK;
   return rc;
-}
+} SWT_API_CATCH
 
-int swt_utf8_lower(uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, uint8_t *need_host) {
+int swt_utf8_lower(uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, uint8_t *need_host) try {
   if (!sent_off || (n_sent && !need_host)) return fail(SWT_ERR_INVALID, "null argument");
   if (sent_off[0] != 0) return fail(SWT_ERR_INVALID, "sent_off[0] must be 0");
   for (uint64_t s = 0; s < n_sent; s++)
@@ -378,6 +383,6 @@ int swt_utf8_lower(uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, uin
   if (!rc && n_sent) SWT_HIP(hipMemcpy(need_host, d_flag.p, n_sent, hipMemcpyDeviceToHost));
   guard.ok = rc == SWT_OK;
   return rc;
-}
+} SWT_API_CATCH
 
 }  // extern "C"

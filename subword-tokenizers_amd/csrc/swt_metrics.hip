@@ -57,7 +57,7 @@ using namespace swt;
 
 extern "C" {
 
-int swt_token_histogram_dev(const uint32_t *d_ids, uint64_t n, uint32_t id_cap, uint64_t *d_counts, uint64_t *d_out_of_range, void *stream) {
+int swt_token_histogram_dev(const uint32_t *d_ids, uint64_t n, uint32_t id_cap, uint64_t *d_counts, uint64_t *d_out_of_range, void *stream) try {
   if ((n && !d_ids) || !d_counts || !d_out_of_range || !id_cap) return fail(SWT_ERR_INVALID, "null argument");
   int rc = ensure_device();
   if (rc) return rc;
@@ -71,9 +71,9 @@ int swt_token_histogram_dev(const uint32_t *d_ids, uint64_t n, uint32_t id_cap, 
                      reinterpret_cast<unsigned long long *>(d_counts), reinterpret_cast<unsigned long long *>(d_out_of_range));
   SWT_HIP(hipGetLastError());
   return SWT_OK;
-}
+} SWT_API_CATCH
 
-int swt_token_histogram(const uint32_t *ids, uint64_t n, uint32_t id_cap, uint64_t *counts, uint64_t *out_of_range) {
+int swt_token_histogram(const uint32_t *ids, uint64_t n, uint32_t id_cap, uint64_t *counts, uint64_t *out_of_range) try {
   if ((n && !ids) || !counts || !out_of_range || !id_cap) return fail(SWT_ERR_INVALID, "null argument");
   int rc = ensure_device();
   if (rc) return rc;
@@ -87,6 +87,6 @@ int swt_token_histogram(const uint32_t *ids, uint64_t n, uint32_t id_cap, uint64
   SWT_HIP(hipMemcpy(out_of_range, d_c, 8, hipMemcpyDeviceToHost));
   SWT_HIP(hipMemcpy(counts, d_c + 1, (size_t)2 * id_cap * 8, hipMemcpyDeviceToHost));
   return SWT_OK;
-}
+} SWT_API_CATCH
 
 }  // extern "C"

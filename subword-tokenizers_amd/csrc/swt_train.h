@@ -32,6 +32,8 @@ constexpr uint32_t kSegBase = 0xFFFFFFFFu;  // seg_of[]: the id names a symbol o
 constexpr uint32_t kFlagIndexBroken = 1u;  // a merged id was reused (or the index log overflowed): applies scan every word
 constexpr uint32_t kFlagBrokenPending = 4u; // fast path: kFlagIndexBroken from the next step on
 constexpr uint32_t kFlagReplan = 2u;       // the candidate list ran dry or overflowed: steps are no-ops until the host re-plans
+constexpr uint32_t kFlagTableFull = 8u;    // an insert found no free slot in a whole turn of the pair table: the host's head-room
+                                           // bound was wrong.  The counts are no longer exact; the host returns SWT_ERR_STATE
 
 struct TrainState {
   unsigned long long max_count;  // result of the last decide: the maximum (count, or WordPiece score bits)
@@ -212,6 +214,13 @@ struct swt_bpe_trainer {
   void enqueue_argmax();
   void enqueue_apply();
   void enqueue_fast_step(uint32_t first_merged, uint32_t limit);
+  // SWT_OK when the handle went through finish_create (histogram, index) and no capacity check has failed since:
+  // every entry point that steps or reads the trainer asks first (a half-built handle used to mean a null pair table
+  // under a kernel: a GPU memory fault, i.e. a process abort)
+  int ready() const;
+  // after a synchronisation: the invariants the device code relies on, from h_st
+  int check_state();
+  bool broken = false;  // check_state failed once: the handle refuses further steps
 };
 
 namespace swt {

@@ -347,11 +347,17 @@ int device_words_from_text(const uint8_t *d_text, uint64_t n_bytes, const uint64
                     (void *)d_vals2, (void *)d_nchar, d_tmp})
       if (p) (void)hipFree(p);
   };
+  auto drop_out = [&]() {  // an error: the caller gets nothing it would have to free
+    for (void *p : {(void *)out->d_sym, (void *)out->d_woff, (void *)out->d_freq})
+      if (p) (void)hipFree(p);
+    out->d_sym = nullptr; out->d_woff = nullptr; out->d_freq = nullptr;
+  };
 #define W_HIP(expr)                                                                                         \
   do {                                                                                                      \
     hipError_t _e = (expr);                                                                                 \
     if (_e != hipSuccess) {                                                                                 \
       cleanup();                                                                                            \
+      drop_out();                                                                                           \
       return fail(SWT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);  \
     }                                                                                                       \
   } while (0)

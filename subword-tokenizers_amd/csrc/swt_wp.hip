@@ -587,7 +587,7 @@ static int wp_upload(swt_wp_trie *t) {
 
 extern "C" {
 
-int swt_wp_trie_create(const uint32_t *vocab_cps, const uint64_t *vocab_off, uint32_t n_vocab, swt_wp_trie **out) {
+int swt_wp_trie_create(const uint32_t *vocab_cps, const uint64_t *vocab_off, uint32_t n_vocab, swt_wp_trie **out) try {
   if (!out || !vocab_off || (n_vocab && vocab_off[n_vocab] && !vocab_cps)) return fail(SWT_ERR_INVALID, "null argument");
   if (n_vocab > 0x7FFFFFF0u) return fail(SWT_ERR_INVALID, "vocabulary too large");
   auto *t = new swt_wp_trie();
@@ -625,9 +625,9 @@ int swt_wp_trie_create(const uint32_t *vocab_cps, const uint64_t *vocab_off, uin
   }
   *out = t;
   return SWT_OK;
-}
+} SWT_API_CATCH
 
-int swt_wp_trie_set_option(swt_wp_trie *t, int option, int value) {
+int swt_wp_trie_set_option(swt_wp_trie *t, int option, int value) try {
   if (!t) return fail(SWT_ERR_INVALID, "null trie");
   switch (option) {
     case SWT_OPT_DEDUP:
@@ -640,9 +640,9 @@ int swt_wp_trie_set_option(swt_wp_trie *t, int option, int value) {
       return SWT_OK;
   }
   return fail(SWT_ERR_INVALID, "no such option");
-}
+} SWT_API_CATCH
 
-void swt_wp_trie_destroy(swt_wp_trie *t) {
+void swt_wp_trie_destroy(swt_wp_trie *t) try {
   if (!t) return;
   if (t->d_edges) (void)hipFree(t->d_edges);
   if (t->d_nodes) (void)hipFree(t->d_nodes);
@@ -655,25 +655,25 @@ void swt_wp_trie_destroy(swt_wp_trie *t) {
   t->small_out.release();
   for (DevBuf *b : {&t->in_text, &t->in_off, &t->out_ids, &t->out_off, &t->out_status, &t->n_tok, &t->u_status}) b->release();
   delete t;
-}
+} SWT_API_CATCH_VOID
 
-int swt_wp_trie_stats(const swt_wp_trie *t, uint32_t *n_nodes, uint32_t *n_edges, uint32_t *n_pops) {
+int swt_wp_trie_stats(const swt_wp_trie *t, uint32_t *n_nodes, uint32_t *n_edges, uint32_t *n_pops) try {
   if (!t) return fail(SWT_ERR_INVALID, "null trie");
   if (n_nodes) *n_nodes = (uint32_t)t->H.ch.size();
   if (n_edges) *n_edges = (uint32_t)t->H.edges.size();
   if (n_pops) *n_pops = (uint32_t)t->h_pops.size();
   return SWT_OK;
-}
+} SWT_API_CATCH
 
-int64_t swt_wp_trie_corner(const swt_wp_trie *t, uint32_t *out, uint64_t cap) {
+int64_t swt_wp_trie_corner(const swt_wp_trie *t, uint32_t *out, uint64_t cap) try {
   if (!t) return -2;
   if (t->H.corner_nonterm) return -1;
   for (size_t k = 0; k < t->H.corner.size() && k < cap; k++) out[k] = t->H.corner[k];
   return (int64_t)t->H.corner.size();
-}
+} SWT_API_CATCH
 
 int swt_wp_trie_node(const swt_wp_trie *t, const uint32_t *path, uint64_t path_len, uint32_t *node_id, int32_t *link,
-                     uint8_t *is_end, uint32_t *pops, uint32_t pops_cap, uint32_t *n_pops) {
+                     uint8_t *is_end, uint32_t *pops, uint32_t pops_cap, uint32_t *n_pops) try {
   if (!t) return fail(SWT_ERR_INVALID, "null trie");
   uint32_t node = t->H.root;
   for (uint64_t i = 0; i < path_len; i++) {
@@ -687,19 +687,19 @@ int swt_wp_trie_node(const swt_wp_trie *t, const uint32_t *path, uint64_t path_l
   if (n_pops) *n_pops = (uint32_t)t->H.pops[node].size();
   for (size_t k = 0; k < t->H.pops[node].size() && k < pops_cap; k++) pops[k] = t->H.pops[node][k];
   return SWT_OK;
-}
+} SWT_API_CATCH
 
-int swt_wp_trie_node_path(const swt_wp_trie *t, uint32_t node_id, uint32_t *out, uint64_t cap, uint64_t *len) {
+int swt_wp_trie_node_path(const swt_wp_trie *t, uint32_t node_id, uint32_t *out, uint64_t cap, uint64_t *len) try {
   if (!t || node_id >= t->H.ch.size()) return fail(SWT_ERR_INVALID, "bad node id");
   std::vector<uint32_t> rev;
   for (int32_t n = (int32_t)node_id; n >= 0 && t->H.parent[n] >= 0; n = t->H.parent[n]) rev.push_back(t->H.ch[n]);
   if (len) *len = rev.size();
   for (size_t k = 0; k < rev.size() && k < cap; k++) out[k] = rev[rev.size() - 1 - k];
   return SWT_OK;
-}
+} SWT_API_CATCH
 
 int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off, uint64_t n_sent,
-                      uint32_t *d_out_ids, uint64_t *d_out_off, uint8_t *d_status, uint64_t *d_n_tokens, void *stream) {
+                      uint32_t *d_out_ids, uint64_t *d_out_off, uint8_t *d_status, uint64_t *d_n_tokens, void *stream) try {
   if (!t || !d_sent_off || !d_out_off || !d_n_tokens || (n_sent && !d_status) || (n_bytes && (!d_text || !d_out_ids)))
     return fail(SWT_ERR_INVALID, "null argument");
   int rc = wp_upload(t);
@@ -773,7 +773,7 @@ int swt_wp_encode_dev(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, c
   prof_end(st, 2);
   SWT_HIP(hipGetLastError());
   return SWT_OK;
-}
+} SWT_API_CATCH
 
 // text and offsets on the device -> ids, offsets, statuses and the count in the caller's host arrays
 static int wp_encode_to_host(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_off, uint64_t n_sent,
@@ -798,7 +798,7 @@ static int wp_encode_to_host(swt_wp_trie *t, const uint8_t *d_text, uint64_t n_b
 }
 
 int swt_wp_encode(swt_wp_trie *t, const uint8_t *text, const uint64_t *sent_off, uint64_t n_sent, uint32_t *out_ids,
-                  uint64_t out_cap, uint64_t *out_off, uint8_t *status, uint64_t *n_tokens) {
+                  uint64_t out_cap, uint64_t *out_off, uint8_t *status, uint64_t *n_tokens) try {
   if (!t || !sent_off || !out_off || !n_tokens || (n_sent && !status)) return fail(SWT_ERR_INVALID, "null argument");
   int rc = wp_upload(t);
   if (rc) return rc;
@@ -866,12 +866,12 @@ int swt_wp_encode(swt_wp_trie *t, const uint8_t *text, const uint64_t *sent_off,
   if (n_bytes) SWT_HIP(hipMemcpyAsync(t->in_text.p, text, n_bytes, hipMemcpyHostToDevice, 0));
   SWT_HIP(hipMemcpyAsync(t->in_off.p, sent_off, (n_sent + 1) * 8, hipMemcpyHostToDevice, 0));
   return wp_encode_to_host(t, t->in_text.as<uint8_t>(), n_bytes, t->in_off.as<uint64_t>(), n_sent, out_ids, out_cap, out_off, status, n_tokens);
-}
+} SWT_API_CATCH
 
 // list[str] joined with U+0000 -> ids, the prepared text staying on the device (see swt_bpe_encode_joined).
 // *n_tokens = UINT64_MAX on return: a sentence needs the host's str.lower() and nothing was encoded.
 int swt_wp_encode_joined(swt_wp_trie *t, const uint8_t *joined, uint64_t n_joined, uint64_t n_sent, uint32_t *out_ids, uint64_t out_cap,
-                         uint64_t *out_off, uint8_t *status, uint64_t *n_tokens, uint8_t *need_host) {
+                         uint64_t *out_off, uint8_t *status, uint64_t *n_tokens, uint8_t *need_host) try {
   if (!t || !out_off || !n_tokens || (n_sent && (!need_host || !status)) || (n_joined && !joined)) return fail(SWT_ERR_INVALID, "null argument");
   int rc = wp_upload(t);
   if (rc) return rc;
@@ -884,6 +884,6 @@ int swt_wp_encode_joined(swt_wp_trie *t, const uint8_t *joined, uint64_t n_joine
         Ctx *c = static_cast<Ctx *>(p);
         return wp_encode_to_host(c->t, d_text, n_bytes, d_off, c->n_sent, c->out_ids, c->out_cap, c->out_off, c->status, c->n_tokens);
       }, &c);
-}
+} SWT_API_CATCH
 
 }  // extern "C"

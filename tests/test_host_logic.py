@@ -29,6 +29,36 @@ def test_library_exports_every_declared_symbol(native):
     assert sorted(native.SIGNATURES) == names
 
 
+def test_abi_exception_barrier(native):
+    """include/swt.h: "nothing throws, aborts".  Every extern "C" entry point is a function-try-block (SWT_API_CATCH): a C++
+    exception raised inside the library comes back as a status + swt_last_error(), never as std::terminate -> SIGABRT (the
+    suspected shape of round 2's abort in swt_bpe_train_run).  swt_abi_selftest throws on purpose, behind the same barrier."""
+    lib = native.lib()
+    assert lib.swt_abi_selftest(0) == 0
+    for kind, code, word in ((1, native.ERR_NOMEM, "bad_alloc"), (2, native.ERR_NOMEM, "length_error"),
+                             (3, native.ERR_INTERNAL, "swt_abi_selftest"), (4, native.ERR_INTERNAL, "unknown")):
+        assert lib.swt_abi_selftest(kind) == code
+        assert word in lib.swt_last_error().decode()
+    with pytest.raises(native.SwtError):
+        native.check(lib.swt_abi_selftest(3))
+
+
+def test_every_entry_point_has_the_exception_barrier():
+    """source check: each function include/swt.h declares is defined as `... swt_x(...) try {` (or is one of the two
+    accessors that cannot throw), so none can be added without its barrier"""
+    srcs = ""
+    cs = os.path.join(ROOT, "subword-tokenizers_amd", "csrc")
+    for f in os.listdir(cs):
+        if f.endswith(".hip"):
+            srcs += open(os.path.join(cs, f), encoding="utf-8").read()
+    for name in declared_functions():
+        if name in ("swt_last_error", "swt_version", "swt_unidata_version"):
+            continue
+        m = re.search(r"^[a-z_0-9 \*]+\b%s\((?:[^;{]|\n)*?\)\s*(try)?\s*\{" % name, srcs, flags=re.M)
+        assert m, "no definition of %s found" % name
+        assert m.group(1) == "try", "%s is defined without the exception barrier" % name
+
+
 def test_no_gpu_means_loud_failure(native, swt, ref_dir):
     if native.device_count() > 0:
         pytest.skip("a GPU is present")
@@ -385,7 +415,8 @@ def test_unicode_database_mismatch_lowercases_on_the_host(native, monkeypatch):
 
 def test_bench_watchdog_emits_the_line_without_the_train_block(monkeypatch):
     """bench.py at world > 1: if the sharded training block raises (or hangs) on a rank, rank 0 still writes the JSON line, with
-    train = {"error": ...}, and every rank leaves without entering another collective"""
+    train = {"error": ...}, and every rank leaves without entering another collective -- with a NON-ZERO exit code: the
+    driver must see a failed training leg as a failed run"""
     import time
 
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -404,8 +435,9 @@ def test_bench_watchdog_emits_the_line_without_the_train_block(monkeypatch):
         raise SystemExit("PARITY FAILURE: made up")
 
     monkeypatch.setattr(bench, "train_bench", boom)
-    with pytest.raises(Left):
+    with pytest.raises(Left) as left:
         bench.train_bench_guarded(out, None, None, None, 0, 2, None, [], 8000, "x")
+    assert left.value.args[0] != 0
     assert len(emitted) == 1 and "PARITY FAILURE" in emitted[0]["train"]["error"] and emitted[0]["value"] == 1.0
     emitted.clear()
     with pytest.raises(Left):  # another rank: nothing to print, it just leaves
@@ -416,7 +448,7 @@ def test_bench_watchdog_emits_the_line_without_the_train_block(monkeypatch):
     monkeypatch.setattr(bench.os, "_exit", lambda code: fired.append(code))
     monkeypatch.setattr(bench, "train_bench", lambda *a, **k: time.sleep(0.6) or {"ok": True})
     got = bench.train_bench_guarded(out, None, None, None, 0, 2, None, [], 8000, "x", limit_s=0.2)
-    assert fired == [0] and len(emitted) == 1 and "not finished" in emitted[0]["train"]["error"]
+    assert fired == [3] and len(emitted) == 1 and "not finished" in emitted[0]["train"]["error"]
     # and the ordinary case: the block's result, no line, nobody leaves
     emitted.clear(); fired.clear()
     monkeypatch.setattr(bench, "train_bench", lambda *a, **k: {"ok": True})
