@@ -396,7 +396,18 @@ def bench_headline(args, torch, dist, rank, world, local):
                          "bytes_per_gpu": other["n_bytes"], "tokens_per_gpu": other["n_tok"], "roofline": other["roofline"],
                          "cpu_baseline": other["cpu"]},
     }
+    # the other half of the north star's encode path, and the mixed shard of configs[4]: blocks of their own beside `train`
+    # (their own timed regions, same bracket: barrier + synchronize on both sides, MAX over ranks)
+    wp = tokenizers.FastWP()
+    wp.vocab = set(synth.v30k())
+    wp._build_trie()
+    out["wp_encode"] = wp_encode_block(args, torch, dist, rank, N, wp, args.sentences or 1000000, max(args.steps // 5, 5), 3)
+    out["mixed_encode"] = mixed_encode_block(args, torch, dist, rank, N, bpe, wp, 625000, max(args.steps // 10, 3), 2)
+    if out.get("cpu_baseline") is not None:
+        out["cpu_baseline"]["reference_python"] = reference_python_baseline("bpe_encode")
     out["train"] = train_bench_guarded(out, args, torch, dist, rank, world, N, train_sents, args.max_vocab or 8000, "S85k-open")
+    if isinstance(out["train"], dict) and out["train"].get("cpu_baseline") is not None:
+        out["train"]["cpu_baseline"]["reference_python"] = reference_python_baseline("train_extrapolated")
     return out
 
 
@@ -426,15 +437,29 @@ def bench_bpe_encode(args, torch, dist, rank, world, local):
     }
 
 
-def bench_wp_encode(args, torch, dist, rank, world, local):
-    from subword_tokenizers_amd import _native as N
-    from subword_tokenizers_amd import synth, tokenizers
+def reference_python_baseline(key):
+    """The reference's OWN Python on the benchmark corpus, measured in the build container by tools/ref_python_baseline.py (the
+    reference cannot travel to the GPU box): a static figure read from profiles/, labelled as such.  None when not recorded."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_reference_python_baseline.json")) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    blk = rec.get(key)
+    if not blk:
+        return None
+    blk = dict(blk)
+    blk["where"] = rec.get("host")
+    blk["static"] = "not measured by this run: read from profiles/r03_reference_python_baseline.json"
+    return blk
 
-    N.init(local)
-    wp = tokenizers.FastWP()
-    wp.vocab = set(synth.v30k())
-    wp._build_trie()
-    n_sent = args.sentences or 1000000
+
+def wp_encode_block(args, torch, dist, rank, N, wp, n_sent, steps, warmup, cpu_sents=200000, with_e2e=True):
+    """configs[2]: K timed steps of the FastWP device path over `n_sent` synthetic sentences resident in HBM; then, outside the
+    timed region, the whole-call and dominant-kernel event timings, the oracle on a bounded subsample (parity + cpu_baseline at
+    1 thread and all host cores) and the end-to-end rate from list[str]."""
+    from subword_tokenizers_amd import synth
+
     text, off = synth.wp_corpus(n_sent, seed=1000000 + rank, vocab=synth.v30k())
     n_bytes = int(text.size)
     d_text, d_off = to_dev(torch, text), to_dev(torch, off.view(np.int64))
@@ -448,7 +473,7 @@ def bench_wp_encode(args, torch, dist, rank, world, local):
         wp._trie.encode_dev(d_text.data_ptr(), n_bytes, d_off.data_ptr(), n_sent, d_out.data_ptr(), d_out_off.data_ptr(),
                             d_status.data_ptr(), d_ntok.data_ptr(), stream)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     barrier_sync(torch, dist)
     n_tok = int(d_ntok.item())
@@ -456,14 +481,21 @@ def bench_wp_encode(args, torch, dist, rank, world, local):
     N.profile_read()
     barrier_sync(torch, dist)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     barrier_sync(torch, dist)
     elapsed = max_over_ranks(torch, dist, time.perf_counter() - t0)
     kernel_ms, launches = N.profile_read()
+    total_bytes = sum_over_ranks(torch, dist, float(n_bytes))
+    res = {"value": round(total_bytes * steps / 1e6 / elapsed, 1), "unit": "MB/s", "ms_per_step": round(elapsed / steps * 1e3, 4), "steps": steps,
+           "workload": "configs[2]: FastWP failure-link trie encode, V30k vocab, %d synthetic sentences (%.1f MB/GPU)" % (n_sent, n_bytes / 1e6),
+           "sentences_per_gpu": n_sent, "bytes_per_gpu": n_bytes, "tokens_per_gpu": n_tok, "roofline": None, "cpu_baseline": None}
+    if args.lean:  # counter passes: only the launches of the timed path
+        N.profile_enable(False)
+        return res
     # outside the timed region: one event pair around ALL kernels of a call (level 2), then around the split + lookup
     # kernel of the dedup path alone (level 3)
-    extra = min(max(args.steps, 1), 10)
+    extra = min(max(steps, 1), 10)
     N.profile_enable(2)
     for _ in range(extra):
         step()
@@ -475,48 +507,83 @@ def bench_wp_encode(args, torch, dist, rank, world, local):
     torch.cuda.synchronize()
     ref_ms, refs = N.profile_read()
     N.profile_enable(False)
-    total_bytes = sum_over_ranks(torch, dist, float(n_bytes))
-    roof = cpu = None
-    if rank == 0:
-        from oracle import oracle as O
+    if rank != 0:
+        return res
+    from oracle import oracle as O
 
-        sub = min(n_sent, 20000)
-        orc = O.OracleWP(wp._tokens)
-        sents = synth.unpack(text, off, 0, sub)
+    sub = min(n_sent, cpu_sents)
+    orc = O.OracleWP(wp._tokens)
+    sents = synth.unpack(text, off, 0, sub)
+    blob, boff = O.pack(sents)  # the corpus is lowercase already; packing is excluded on both sides
+    cap = 4 * blob.size + 64 * sub + 64
+    out = np.zeros(cap, dtype=np.uint32)
+    oo = np.zeros(sub + 1, dtype=np.uint64)
+    ost = np.zeros(sub + 1, dtype=np.uint8)
+    t1 = time.perf_counter()
+    O.lib().orc_wp_tokenize_batch(orc._h, O._p32(blob), O._p64(boff), sub, O._p32(out), cap, O._p64(oo), ost.ctypes.data_as(O._u8p))
+    cpu1_s = time.perf_counter() - t1
+    offs = d_out_off[:sub + 1].cpu().numpy().view(np.uint64)
+    ids = d_out[:int(offs[-1])].cpu().numpy().view(np.uint32)
+    st = d_status[:sub].cpu().numpy()
+    if not (np.array_equal(ids, out[:int(oo[-1])]) and np.array_equal(offs, oo) and np.array_equal(st, ost[:sub])):
+        raise SystemExit("PARITY FAILURE: FastWP device ids differ from the oracle on the benchmark subsample")
+    cores = host_cores()
+    t1 = time.perf_counter()
+    mids, moff, mst = orc.tokenize_packed_mt(blob, boff, cores)
+    cpun_s = time.perf_counter() - t1
+    if not (np.array_equal(ids, mids) and np.array_equal(offs, moff) and np.array_equal(st, mst)):
+        raise SystemExit("PARITY FAILURE: the threaded FastWP oracle differs")
+    # With the word-level dedup the call is a pipeline (plan, wordref, scan, ureg, wp_encode over the unique chunks, urec,
+    # refs-count, scan, refs-write): the roofline line is that of the whole call, the longest kernel (wordref: split + table
+    # lookup of every chunk) is reported beside it.  Without dedup (refs == 0: a vocabulary with whitespace inside tokens)
+    # the dominant kernel is wp_encode_kernel itself.
+    algo = n_bytes + 4.0 * n_tok + 8.0 * (n_sent + 1)
+    per_call_s = call_ms / 1e3 / max(calls, 1)
+    achieved = algo / per_call_s / 1e9
+    dom = ({"name": "wordref_kernel<wp>", "us": round(ref_ms * 1e3 / refs, 2), "launches_timed": int(refs)} if refs else
+           {"name": "wp_encode_kernel", "us": round(kernel_ms * 1e3 / max(launches, 1), 2), "launches_timed": int(launches)})
+    res["roofline"] = check_frac({
+        "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+        "traffic": traffic_from_profile("wp_encode"),
+        "kernel": "whole call (dedup pipeline)" if refs else "whole call (plan, wp_encode, scan, gather)", "kernel_us": round(per_call_s * 1e6, 2),
+        "algorithmic_bytes_per_launch": int(algo), "launches_timed": int(calls), "dominant_kernel": dom,
+        "unique_pass": {"name": "wp_encode_kernel", "us": round(kernel_ms * 1e3 / max(launches, 1), 2)}})
+    sub_bytes = int(off[sub])
+    res["cpu_baseline"] = {
+        "value": round(sub_bytes / 1e6 / cpu1_s, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+        "sample": "first %d sentences (%.1f MB) through oracle/swt_oracle.c orc_wp_tokenize_batch" % (sub, sub_bytes / 1e6),
+        "all_cores": {"value": round(sub_bytes / 1e6 / cpun_s, 3), "unit": "MB/s", "cores": cores,
+                      "sample": "the same sentences, orc_wp_tokenize_batch_mt over %d host threads" % cores},
+        "reference_python": reference_python_baseline("wp_encode")}
+    if with_e2e:
+        all_sents = synth.unpack(text, off)
+        wp.encode_ids_batch(all_sents)  # the first call of a size grows the workspaces
         t1 = time.perf_counter()
-        oids, ooff, ost = orc.tokenize_batch_ids(sents)
-        cpu_s = time.perf_counter() - t1
-        offs = d_out_off[:sub + 1].cpu().numpy().view(np.uint64)
-        ids = d_out[:int(offs[-1])].cpu().numpy().view(np.uint32)
-        st = d_status[:sub].cpu().numpy()
-        if not (np.array_equal(ids, oids) and np.array_equal(offs, ooff) and np.array_equal(st, ost)):
-            raise SystemExit("PARITY FAILURE: device ids differ from the oracle on the benchmark subsample")
-        # With the word-level dedup the call is a pipeline (plan, wordref, scan, ureg, wp_encode over the unique
-        # chunks, urec, refs-count, scan, refs-write): the roofline line is that of the whole call, the longest kernel
-        # (wordref: split + table lookup of every chunk) is reported beside it.  Without dedup (refs == 0: a vocabulary
-        # with whitespace inside tokens) the dominant kernel is wp_encode_kernel itself.
-        algo = n_bytes + 4.0 * n_tok + 8.0 * (n_sent + 1)
-        per_call_s = call_ms / 1e3 / max(calls, 1)
-        achieved = algo / per_call_s / 1e9
-        dom = ({"name": "wordref_kernel<wp>", "us": round(ref_ms * 1e3 / refs, 2), "launches_timed": int(refs)} if refs else
-               {"name": "wp_encode_kernel", "us": round(kernel_ms * 1e3 / max(launches, 1), 2), "launches_timed": int(launches)})
-        roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_from_profile("wp_encode"),
-                "kernel": "whole call (dedup pipeline)" if refs else "whole call (plan, wp_encode, scan, gather)",
-                "kernel_us": round(per_call_s * 1e6, 2),
-                "algorithmic_bytes_per_launch": int(algo), "launches_timed": int(calls), "dominant_kernel": dom,
-                "unique_pass": {"name": "wp_encode_kernel", "us": round(kernel_ms * 1e3 / max(launches, 1), 2)}}
-        sub_bytes = int(off[sub])
-        cpu = {"value": round(sub_bytes / 1e6 / cpu_s, 3), "unit": "MB/s", "cores": 1, "kind": "port",
-               "sample": "first %d sentences (%.1f MB) through oracle/swt_oracle.c orc_wp_tokenize_batch" % (sub, sub_bytes / 1e6)}
+        e_ids, e_off, e_st = wp.encode_ids_batch(all_sents)
+        e2e_s = time.perf_counter() - t1
+        full_off = d_out_off.cpu().numpy().view(np.uint64)
+        if not (np.array_equal(e_off, full_off) and np.array_equal(e_ids, d_out[:n_tok].cpu().numpy().view(np.uint32)) and not e_st.any()):
+            raise SystemExit("PARITY FAILURE: FastWP.encode_ids_batch differs from the device-resident call")
+        res["end_to_end_mb_s"] = round(n_bytes / 1e6 / e2e_s, 1)
+        res["end_to_end_note"] = "FastWP.encode_ids_batch(list[str]) -> ids, second call of this size: strings -> joined UTF-8, H2D, device lower + encode (swt_wp_encode_joined), ids D2H"
+    return res
+
+
+def bench_wp_encode(args, torch, dist, rank, world, local):
+    from subword_tokenizers_amd import _native as N
+    from subword_tokenizers_amd import synth, tokenizers
+
+    N.init(local)
+    wp = tokenizers.FastWP()
+    wp.vocab = set(synth.v30k())
+    wp._build_trie()
+    r = wp_encode_block(args, torch, dist, rank, N, wp, args.sentences or 1000000, args.steps, args.warmup)
     return {
-        "metric": "FastWP encode throughput (input MB/s, tokens bit-exact)", "value": round(total_bytes * args.steps / 1e6 / elapsed, 1),
-        "unit": "MB/s", "ms_per_step": round(elapsed / args.steps * 1e3, 4), "dtype": "u32",
-        "config": {"workload": "configs[2]: FastWP failure-link trie encode, V30k vocab, %d synthetic sentences (%.1f MB/GPU)"
-                               % (n_sent, n_bytes / 1e6),
-                   "sentences_per_gpu": n_sent, "bytes_per_gpu": n_bytes, "tokens_per_gpu": n_tok,
-                   "parallelism": "corpus-sharded x%d, no collective" % world},
-        "roofline": roof, "cpu_baseline": cpu,
+        "metric": "FastWP encode throughput (input MB/s, tokens bit-exact)", "value": r["value"],
+        "unit": "MB/s", "ms_per_step": r["ms_per_step"], "dtype": "u32",
+        "config": {"workload": r["workload"], "sentences_per_gpu": r["sentences_per_gpu"], "bytes_per_gpu": r["bytes_per_gpu"],
+                   "tokens_per_gpu": r["tokens_per_gpu"], "parallelism": "corpus-sharded x%d, no collective" % world},
+        "roofline": r["roofline"], "cpu_baseline": r["cpu_baseline"], "end_to_end_mb_s": r.get("end_to_end_mb_s"),
     }
 
 
@@ -538,20 +605,11 @@ def bench_bpe_train(args, torch, dist, rank, world, local):
             "merge_loop_s": tr["merge_loop_s"]}
 
 
-def bench_mixed_encode(args, torch, dist, rank, world, local):
+def mixed_encode_block(args, torch, dist, rank, N, bpe, wp, n_each, steps, warmup, cpu_sents=100000):
     """BASELINE configs[4] per GPU: 10 M sentences over 8 GPUs = 1.25 M per GPU, half through FastBPE (8,000 merges) and half
     through FastWP (V30k); corpus-sharded, no collective.  One step = one FastBPE call + one FastWP call."""
-    from subword_tokenizers_amd import _native as N
-    from subword_tokenizers_amd import synth, tokenizers
+    from subword_tokenizers_amd import synth
 
-    N.init(local)
-    n_each = args.sentences or 625000
-    bpe = tokenizers.FastBPE()
-    bpe.merges_list = list(synth.pretrained_merges()[:8000])
-    bpe._build_table()
-    wp = tokenizers.FastWP()
-    wp.vocab = set(synth.v30k())
-    wp._build_trie()
     b_sents = synth.sentences(n_each, 10000000 + rank)
     b_text, b_off = N.pack_utf8([s.lower() for s in b_sents])
     w_text, w_off = synth.wp_corpus(n_each, seed=20000000 + rank, vocab=synth.v30k())
@@ -569,58 +627,92 @@ def bench_mixed_encode(args, torch, dist, rank, world, local):
         t, o, out, oo, nt, nb = bufs[1]
         wp._trie.encode_dev(t.data_ptr(), nb, o.data_ptr(), n_each, out.data_ptr(), oo.data_ptr(), d_status.data_ptr(), nt.data_ptr(), stream)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     barrier_sync(torch, dist)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     barrier_sync(torch, dist)
     elapsed = max_over_ranks(torch, dist, time.perf_counter() - t0)
+    n_bytes = bufs[0][5] + bufs[1][5]
+    total_bytes = sum_over_ranks(torch, dist, float(n_bytes))
+    res = {"value": round(total_bytes * steps / 1e6 / elapsed, 1), "unit": "MB/s", "ms_per_step": round(elapsed / steps * 1e3, 4), "steps": steps,
+           "workload": "configs[4] per GPU: %d sentences through FastBPE (8,000 merges, %.1f MB) + %d through FastWP (V30k, %.1f MB)"
+                       % (n_each, bufs[0][5] / 1e6, n_each, bufs[1][5] / 1e6),
+           "sentences_per_gpu": 2 * n_each, "bytes_per_gpu": n_bytes, "roofline": None, "cpu_baseline": None}
+    if args.lean:
+        return res
     N.profile_enable(2)
     N.profile_read()
-    for _ in range(min(max(args.steps, 1), 5)):
+    for _ in range(min(max(steps, 1), 5)):
         step()
     torch.cuda.synchronize()
     call_ms, calls = N.profile_read()
     N.profile_enable(False)
-    n_bytes = bufs[0][5] + bufs[1][5]
-    total_bytes = sum_over_ranks(torch, dist, float(n_bytes))
-    roof = cpu = None
-    if rank == 0:
-        from oracle import oracle as O
+    if rank != 0:
+        return res
+    from oracle import oracle as O
 
-        sub = min(n_each, 10000)
-        borc, worc = O.OracleBPE(bpe.merges_list), O.OracleWP(wp._tokens)
-        t1 = time.perf_counter()
-        bo_ids, bo_off = borc.tokenize_batch_ids(b_sents[:sub])
-        wo_ids, wo_off, wo_st = worc.tokenize_batch_ids(synth.unpack(w_text, w_off, 0, sub))
-        cpu_s = time.perf_counter() - t1
-        for (t, o, out, oo, nt, nb), (ids, off) in zip(bufs, ((bo_ids, bo_off), (wo_ids, wo_off))):
-            offs = oo[:sub + 1].cpu().numpy().view(np.uint64)
-            got = out[:int(offs[-1])].cpu().numpy().view(np.uint32)
-            if not (np.array_equal(got, ids) and np.array_equal(offs, off)):
-                raise SystemExit("PARITY FAILURE: device ids differ from the oracle on the benchmark subsample")
-        if not np.array_equal(d_status[:sub].cpu().numpy(), wo_st):
-            raise SystemExit("PARITY FAILURE: FastWP statuses differ from the oracle")
-        n_tok = int(bufs[0][4].item()) + int(bufs[1][4].item())
-        algo = n_bytes + 4.0 * n_tok + 8.0 * 2 * (n_each + 1)
-        per_step_s = call_ms / 1e3 / max(calls // 2, 1)
-        achieved = algo / per_step_s / 1e9
-        roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None, "kernel": "one FastBPE call + one FastWP call (both dedup pipelines), first kernel .. last kernel of each",
-                "kernel_us": round(per_step_s * 1e6, 2), "algorithmic_bytes_per_launch": int(algo), "launches_timed": int(calls // 2)}
-        sub_bytes = int(b_off[sub]) + int(w_off[sub])
-        cpu = {"value": round(sub_bytes / 1e6 / cpu_s, 3), "unit": "MB/s", "cores": 1, "kind": "port",
-               "sample": "first %d sentences of each half (%.1f MB) through oracle/swt_oracle.c, lower() + packing included" % (sub, sub_bytes / 1e6)}
+    sub = min(n_each, cpu_sents)
+    cores = host_cores()
+    borc, worc = O.OracleBPE(bpe.merges_list), O.OracleWP(wp._tokens)
+    bblob, bboff = O.pack([s.lower() for s in b_sents[:sub]])
+    wblob, wboff = O.pack(synth.unpack(w_text, w_off, 0, sub))
+    t1 = time.perf_counter()
+    bo_ids, bo_off = borc.tokenize_packed_mt(bblob, bboff, 1)
+    wo_ids, wo_off, wo_st = worc.tokenize_packed_mt(wblob, wboff, 1)
+    cpu1_s = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    bm_ids, bm_off = borc.tokenize_packed_mt(bblob, bboff, cores)
+    wm_ids, wm_off, wm_st = worc.tokenize_packed_mt(wblob, wboff, cores)
+    cpun_s = time.perf_counter() - t1
+    if not (np.array_equal(bm_ids, bo_ids) and np.array_equal(wm_ids, wo_ids) and np.array_equal(wm_st, wo_st)):
+        raise SystemExit("PARITY FAILURE: the threaded oracle differs from the one-thread oracle")
+    for (t, o, out, oo, nt, nb), (ids, off) in zip(bufs, ((bo_ids, bo_off), (wo_ids, wo_off))):
+        offs = oo[:sub + 1].cpu().numpy().view(np.uint64)
+        got = out[:int(offs[-1])].cpu().numpy().view(np.uint32)
+        if not (np.array_equal(got, ids) and np.array_equal(offs, off)):
+            raise SystemExit("PARITY FAILURE: device ids differ from the oracle on the benchmark subsample (mixed)")
+    if not np.array_equal(d_status[:sub].cpu().numpy(), wo_st):
+        raise SystemExit("PARITY FAILURE: FastWP statuses differ from the oracle (mixed)")
+    n_tok = int(bufs[0][4].item()) + int(bufs[1][4].item())
+    algo = n_bytes + 4.0 * n_tok + 8.0 * 2 * (n_each + 1)
+    per_step_s = call_ms / 1e3 / max(calls // 2, 1)
+    achieved = algo / per_step_s / 1e9
+    res["tokens_per_gpu"] = n_tok
+    res["roofline"] = check_frac({
+        "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+        "traffic": traffic_from_profile("mixed_encode"),
+        "kernel": "one FastBPE call + one FastWP call (both dedup pipelines), first kernel .. last kernel of each",
+        "kernel_us": round(per_step_s * 1e6, 2), "algorithmic_bytes_per_launch": int(algo), "launches_timed": int(calls // 2)})
+    sub_bytes = int(b_off[sub]) + int(w_off[sub])
+    res["cpu_baseline"] = {
+        "value": round(sub_bytes / 1e6 / cpu1_s, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+        "sample": "first %d sentences of each half (%.1f MB) through oracle/swt_oracle.c (both batch encoders, one thread)" % (sub, sub_bytes / 1e6),
+        "all_cores": {"value": round(sub_bytes / 1e6 / cpun_s, 3), "unit": "MB/s", "cores": cores,
+                      "sample": "the same sentences over %d host threads" % cores}}
+    return res
+
+
+def bench_mixed_encode(args, torch, dist, rank, world, local):
+    from subword_tokenizers_amd import _native as N
+    from subword_tokenizers_amd import synth, tokenizers
+
+    N.init(local)
+    bpe = tokenizers.FastBPE()
+    bpe.merges_list = list(synth.pretrained_merges()[:8000])
+    bpe._build_table()
+    wp = tokenizers.FastWP()
+    wp.vocab = set(synth.v30k())
+    wp._build_trie()
+    r = mixed_encode_block(args, torch, dist, rank, N, bpe, wp, args.sentences or 625000, args.steps, args.warmup)
     return {
         "metric": "mixed FastBPE + FastWP encode throughput (input MB/s, tokens bit-exact)",
-        "value": round(total_bytes * args.steps / 1e6 / elapsed, 1), "unit": "MB/s", "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "dtype": "u32",
-        "config": {"workload": "configs[4] per GPU: %d sentences through FastBPE (8,000 merges, %.1f MB) + %d through FastWP (V30k, %.1f MB)"
-                               % (n_each, bufs[0][5] / 1e6, n_each, bufs[1][5] / 1e6),
-                   "sentences_per_gpu": 2 * n_each, "bytes_per_gpu": n_bytes, "parallelism": "corpus-sharded x%d, no collective" % world},
-        "roofline": roof, "cpu_baseline": cpu,
+        "value": r["value"], "unit": "MB/s", "ms_per_step": r["ms_per_step"], "dtype": "u32",
+        "config": {"workload": r["workload"], "sentences_per_gpu": r["sentences_per_gpu"], "bytes_per_gpu": r["bytes_per_gpu"],
+                   "parallelism": "corpus-sharded x%d, no collective" % world},
+        "roofline": r["roofline"], "cpu_baseline": r["cpu_baseline"],
     }
 
 
@@ -740,7 +832,7 @@ def bench_wp_train(args, torch, dist, rank, world, local):
         "scaling": "strong",
         # rescan: the reference's pair pass + symbol pass + rewrite read/write, per merge
         "roofline": train_roofline(trace, stats, n0, w0, n_final, len(order), per_merge_s, len(order) * len(times),
-                                   16.0 * (n0 + n_final) / 2.0 + 8.0 * w0, whole_table=True),
+                                   16.0 * (n0 + n_final) / 2.0 + 8.0 * w0, whole_table=stats["theta"] == 0),  # theta 1: the list of live pairs
         "cpu_baseline": {"value": round(cpu_s / sample * 1000, 3), "unit": "s/1k-merges", "cores": 1, "kind": "port",
                          "sample": "first %d merges of the same run through oracle/swt_oracle.c (orc_wptrain_new + orc_train_run)" % sample},
         "final_symbols": info["n_symbols"],
@@ -758,7 +850,7 @@ def main():
     ap.add_argument("--types", type=int, default=None, help="bpe_train_1g: word types (default 2,000,000)")
     ap.add_argument("--merges", type=int, default=None, help="bpe_train_1g: merges (default 32,000)")
     ap.add_argument("--parity-merges", type=int, default=None, help="bpe_train_1g: merges compared with the oracle (default 200)")
-    ap.add_argument("--lean", action="store_true", help="bpe_encode: timed steps only (no extra legs, no parity check): for counter passes")
+    ap.add_argument("--lean", action="store_true", help="bpe_encode / wp_encode / mixed_encode: timed steps only (no extra legs, no parity check): for counter passes")
     ap.add_argument("--corpus", default="open", choices=["open", "lex"], help="bpe_train / bpe_encode: S85k-open (default) or S85k-lex")
     args = ap.parse_args()
     defaults = {"headline": (100, 10), "bpe_encode": (200, 20), "wp_encode": (20, 3), "bpe_train": (2, 1), "wp_train": (2, 1), "bpe_train_1g": (1, 0), "mixed_encode": (10, 2)}[args.workload]

@@ -394,7 +394,48 @@ __global__ __launch_bounds__(256) void cand_argmax_kernel(TrainCtx C, ArgPart *_
   arg_publish(m, c, k, parts);
 }
 
-// WordPiece (and the BPE fallback): maximum over the whole table.  The counts are streamed two per load, four loads in
+// WordPiece: maximum SCORE over the list of every live pair (theta = 1), read from its compact mirror.  The score of a pair
+// moves whenever the frequency of one of its symbols does (wordpiece.py:84-87), so no count threshold bounds it -- but the
+// LIST of live pairs is still far shorter than the table it lives in (S85k-lex: ~0.5 M pairs in 4 M slots of 16 B), and its
+// mirror is two dense streams: the argmax went from a 67 MB table scan per merge to ~10 MB.  The entries pushed since the
+// last step (the pairs the last merge created) are gathered from the table here and mirrored on the way -- no count moves
+// while this launch runs -- and decide_kernel moves n_synced up afterwards.
+__global__ __launch_bounds__(256) void wp_list_argmax_kernel(TrainCtx C, ArgPart *__restrict__ parts) {
+  unsigned long long m = 0, c = 0, k = kEmptyKey;
+  unsigned long long n = C.st->n_cand;
+  if (n > C.cand_cap) n = C.cand_cap;
+  const unsigned long long n_synced = C.st->n_synced < n ? C.st->n_synced : n;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
+    long long v[4];
+    unsigned long long key[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {  // four independent streams of loads in flight
+      const uint64_t i = i0 + u * stride;
+      v[u] = 0;
+      key[u] = kEmptyKey;
+      if (i < n_synced) { v[u] = C.ccnt[i]; key[u] = C.ckey[i]; }
+      else if (i < n) {
+        const uint32_t slot = C.cand[i];
+        v[u] = C.T.cnt[slot];
+        key[u] = C.T.keys[slot];
+        C.ccnt[i] = v[u];
+        C.ckey[i] = key[u];
+        C.cidx[slot] = (uint32_t)i;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (v[u] > 0 && key[u] != kEmptyKey) {
+        const unsigned long long val = pair_value(key[u], v[u], C.sfreq);
+        if (val >= m) arg_combine(m, c, k, val, 1ull, key[u]);
+      }
+    }
+  }
+  arg_publish(m, c, k, parts);
+}
+
+// The BPE fallback (and a WordPiece table whose list does not fit): maximum over the whole table.  The counts are streamed two per load, four loads in
 // flight per lane (cap is a power of two >= 1024); a key is only fetched for a count that can still win.
 __global__ __launch_bounds__(256) void argmax_full_kernel(const unsigned long long *__restrict__ keys, const long long *__restrict__ cnt,
                                                           uint64_t cap, ArgPart *__restrict__ parts, const long long *__restrict__ sfreq) {
@@ -531,6 +572,7 @@ __global__ __launch_bounds__(64) void decide_kernel(const uint32_t *__restrict__
   st->res_pos = pos;
   st->best_pos = kEmptyKey;
   if (dry) st->flags |= kFlagReplan;
+  if (C.sfreq && C.theta) st->n_synced = st->n_cand < C.cand_cap ? st->n_cand : C.cand_cap;  // wp_list_argmax_kernel mirrored up to here
   if (!dry && !C.sfreq) {
     if (tied >= 2 && pos != kEmptyKey) { st->plateau = mx; st->cursor_w = (uint32_t)(pos >> 32); }
     else if (st->plateau != mx) { st->plateau = mx; st->cursor_w = 0; }
@@ -2076,22 +2118,35 @@ static int squeeze_stream(swt_bpe_trainer *t) {
 }
 
 // theta from the histogram of the counts, then the list of the slots that pass it
+// (re)allocate the candidate arrays for `want` entries (the fast path's per-candidate arrays only for BPE)
+static int cand_alloc(swt_bpe_trainer *t, uint64_t want) {
+  if (t->d_cand && want <= t->cand_cap) return SWT_OK;
+  SWT_HIP(hipStreamSynchronize(t->stream));
+  for (void *p : {(void *)t->d_cand, (void *)t->d_ccnt, (void *)t->d_ckey, (void *)t->d_gpos, (void *)t->d_gnb_min, (void *)t->d_gnb_max})
+    if (p) (void)hipFree(p);
+  t->d_cand = nullptr; t->d_ccnt = nullptr; t->d_ckey = nullptr; t->d_gpos = nullptr; t->d_gnb_min = nullptr; t->d_gnb_max = nullptr;
+  t->cand_cap = 0;
+  SWT_HIP(hipMalloc((void **)&t->d_cand, (size_t)want * 4));
+  SWT_HIP(hipMalloc((void **)&t->d_ccnt, (size_t)want * 8));
+  SWT_HIP(hipMalloc((void **)&t->d_ckey, (size_t)want * 8));
+  if (!t->d_sfreq) {
+    SWT_HIP(hipMalloc((void **)&t->d_gpos, 2 * (size_t)want * 8));
+    SWT_HIP(hipMalloc((void **)&t->d_gnb_min, 4 * (size_t)want * 4));
+    SWT_HIP(hipMalloc((void **)&t->d_gnb_max, 4 * (size_t)want * 4));
+  }
+  t->cand_cap = want;
+  return SWT_OK;
+}
+
 int swt_bpe_trainer::replan() {
-  if (d_sfreq) { theta = 0; cand_valid = true; return SWT_OK; }  // WordPiece: full-table argmax
   int rc;
-  if (!d_cand) {
-    cand_cap = kCandCap;
-    SWT_HIP(hipMalloc((void **)&d_cand, (size_t)cand_cap * 4));
-    SWT_HIP(hipMalloc((void **)&d_ccnt, (size_t)cand_cap * 8));
-    SWT_HIP(hipMalloc((void **)&d_ckey, (size_t)cand_cap * 8));
+  if (!d_buckets) {
     SWT_HIP(hipMalloc((void **)&d_buckets, 512 * 8));
     SWT_HIP(hipMalloc((void **)&d_tied_idx, 2 * kTieSet * 4));
     SWT_HIP(hipMalloc((void **)&d_tied_key, 2 * kTieSet * 8));
     SWT_HIP(hipMalloc((void **)&d_tied_plan, 2 * kTieSet * sizeof(TiedPlan)));
-    SWT_HIP(hipMalloc((void **)&d_gpos, 2 * (size_t)cand_cap * 8));
-    SWT_HIP(hipMalloc((void **)&d_gnb_min, 4 * (size_t)cand_cap * 4));
-    SWT_HIP(hipMalloc((void **)&d_gnb_max, 4 * (size_t)cand_cap * 4));
   }
+  if (!d_sfreq && (rc = cand_alloc(this, kCandCap))) return rc;
   if (!d_cidx || cidx_bits != T.bits) {  // one place per table slot
     if (d_cidx) (void)hipFree(d_cidx);
     d_cidx = nullptr;
@@ -2105,6 +2160,35 @@ int swt_bpe_trainer::replan() {
   unsigned long long hb[512];
   SWT_HIP(hipMemcpyAsync(hb, d_buckets, sizeof hb, hipMemcpyDeviceToHost, stream));
   if ((rc = sync_state())) return rc;
+  if (d_sfreq) {
+    // WordPiece: every live pair is listed (theta = 1), with room for the pairs the next merges create; a list that would
+    // not fit 2^28 entries falls back to the full-table argmax (theta = 0)
+    unsigned long long live = 0;
+    for (int b = 0; b < 512; b++) live += hb[b];
+    const uint64_t want = 2 * live + 65536;
+    const unsigned int wflags = h_st.flags & ~kFlagReplan;
+    SWT_HIP(hipMemsetAsync(&d_st->n_cand, 0, 8, stream));
+    SWT_HIP(hipMemcpyAsync(&d_st->flags, &wflags, 4, hipMemcpyHostToDevice, stream));
+    if (want > (1ull << 28)) {
+      theta = 0;
+      cand_valid = true;
+      SWT_HIP(hipStreamSynchronize(stream));  // `wflags` is a stack variable
+      return SWT_OK;
+    }
+    if (want > cand_cap || !d_cand) {
+      if ((rc = cand_alloc(this, want + want / 2))) return rc;
+    }
+    theta = 1;
+    cand_built = live;
+    since_replan = 0;
+    cand_valid = true;
+    hipLaunchKernelGGL(cand_build_kernel, dim3(grid_for(cap, 256, 2048)), dim3(256), 0, stream, ctx(), cap);
+    SWT_HIP(hipMemcpyAsync(&d_st->n_synced, &d_st->n_cand, 8, hipMemcpyDeviceToDevice, stream));
+    SWT_HIP(hipMemcpyAsync(&d_st->n_synced_next, &d_st->n_cand, 8, hipMemcpyDeviceToDevice, stream));
+    SWT_HIP(hipStreamSynchronize(stream));
+    n_replans++;
+    return SWT_OK;
+  }
   // from the top: whole buckets while at most kCandTarget pairs pass (the highest non-empty bucket always passes)
   unsigned long long above = 0;
   int lowest = 512;  // lowest bucket taken
@@ -2352,7 +2436,10 @@ static int ensure_room(swt_bpe_trainer *t, uint64_t extra) {
 // argmax -> tie scan (the caller enqueues its decide kernel behind them)
 void swt_bpe_trainer::enqueue_argmax() {
   const TrainCtx C = ctx();
-  if (theta) {
+  if (theta && d_sfreq) {
+    n_parts = kArgParts;
+    hipLaunchKernelGGL(wp_list_argmax_kernel, dim3(kArgParts), dim3(256), 0, stream, C, d_parts);
+  } else if (theta) {
     n_parts = kCandBlocks;
     hipLaunchKernelGGL(cand_argmax_kernel, dim3(kCandBlocks), dim3(256), 0, stream, C, d_parts);
   } else {
@@ -2705,7 +2792,11 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
     if (!t->sharded && t->h_st.n_syms && 2 * t->h_st.n_syms + 64 < extra) extra = 2 * t->h_st.n_syms + 64;
     if ((rc = ensure_room(t, extra))) return rc;
     if ((rc = ensure_steps(t, steps, first_merged + done + cap))) return rc;
-    if (!t->cand_valid || (!t->theta && !t->d_sfreq) || t->h_st.n_cand > kCandHigh) {
+    // BPE re-plans once pushes have grown the (short) list past kCandHigh; WordPiece lists every live pair and re-plans when
+    // three quarters of its room are used (dead entries are dropped on the way; a list that overflows in mid trip says so
+    // on the device -- cand_dry -- and the host comes back here)
+    const bool list_full = t->d_sfreq ? (t->theta && 4 * t->h_st.n_cand > 3 * t->cand_cap) : t->h_st.n_cand > kCandHigh;
+    if (!t->cand_valid || (!t->theta && !t->d_sfreq) || list_full) {
       // a host stop anyway: when three slots in ten are holes, the stream is rewritten without them
       if (maybe_fast && t->h_st.n_syms && t->h_st.n_syms * 10 < t->extent * 7 && (rc = squeeze_stream(t))) return rc;
       if ((rc = t->replan())) return rc;

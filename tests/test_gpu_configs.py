@@ -1,7 +1,16 @@
-"""BASELINE.json's configs at the sizes they are quoted on (`-m gpu`, one MI355X): configs[2] at 1 M sentences, configs[3] at
-2 M word types and as raw text, configs[4]'s per-GPU shard (625 k + 625 k sentences), plus the string-collision replay of the
-training loop.  The oracle covers seeded subsamples / the first merges; the full sizes are held by size-independent properties
-(batch independence, shard concatenation, recount of the final histogram)."""
+"""BASELINE.json's configs at the sizes they are quoted on (`-m gpu`, one MI355X): configs[1] on BOTH stand-ins for train-85k
+(the headline workload of bench.py included: S85k-open, every sentence and every merge), configs[2] at 1 M sentences,
+configs[3] at 2 M word types to 32,000 merges and as 2^30 bytes of raw text, configs[4]'s per-GPU shard (625 k + 625 k
+sentences), plus the string-collision replay of the training loop.  The oracle covers seeded subsamples / the first merges;
+the full sizes are held by size-independent properties (batch independence, shard concatenation, recount of the final
+histogram).
+
+The three long oracle runs (the C restatement recounts every pair per merge: ~100 s for S85k-open -> 8,000, ~20 s for
+S85k-lex, ~60 s for the first 1,000 merges of configs[3]) start in worker threads when the module is set up -- ctypes
+releases the GIL around the C call -- and the tests that need them join them, so the suite pays the longest one once."""
+import concurrent.futures
+import os
+
 import numpy as np
 import pytest
 
@@ -39,6 +48,29 @@ def bpe8k(swt, dev, synth):
     return tok
 
 
+@pytest.fixture(scope="module")
+def oracle_jobs(oracle, synth):
+    """name -> Future of a finished oracle trainer"""
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=3)
+
+    def train_text(sents, vocab):
+        orc = oracle.OracleBPETrainer(sents)
+        orc.run(vocab)
+        return orc
+
+    def train_words(n_merges):
+        sym, off, freq = synth.train_words(2_000_000, 1073741824, total_tokens=2_000_000 * 55)
+        orc = oracle.OracleBPETrainer.from_words(sym, off, freq)
+        orc.run(10 ** 9, n_merges)
+        return orc
+
+    jobs = {"open": pool.submit(train_text, synth.s85k_open(), 8000),
+            "config3": pool.submit(train_words, 1000),
+            "lex": pool.submit(train_text, synth.s85k(), 8000)}
+    yield jobs
+    pool.shutdown(wait=True)
+
+
 def _recount(syms, woff, freq):
     """bpe.py:90-95 over an exported stream, in numpy: {pair key: weighted count}"""
     syms = syms.astype(np.uint64)
@@ -62,15 +94,10 @@ def _same_histogram(tr):
 
 # ------------------------------------------------------------------------------------------------ configs[1], training half
 
-def test_config1_training_to_8000_all_merges(swt, dev, oracle, synth):
-    """configs[1]'s training half at spec on the S85k-lex stand-in: FastBPE.train to vocab 8,000 -- EVERY merge (7,9xx of them, most
-    of them taken several per step from plateaus of tied pairs, with re-plans and stream squeezes in between), the vocabulary
-    and the final symbol stream against the oracle's full recount per merge (bpe.py:88-111)."""
-    sents = synth.s85k()
+def _train_against(swt, sents, orc):
+    """FastBPE.train(sents, 8000): EVERY merge, the vocabulary, the final symbol stream and the incremental histogram"""
     tok = swt.FastBPE()
     tok.train(sents, 8000)
-    orc = oracle.OracleBPETrainer(sents)
-    orc.run(8000)
     want = [tuple(m) for m in orc.merges_list]
     got = [tuple(m) for m in tok.merges_list]
     bad = next((i for i, (a, b) in enumerate(zip(got, want)) if a != b), None)
@@ -84,7 +111,37 @@ def test_config1_training_to_8000_all_merges(swt, dev, oracle, synth):
     st = tok._trainer.stats()
     assert st["flags"] & 1 == 0  # the index was never abandoned
     _same_histogram(tok._trainer)
-    tok.reset()
+    return tok
+
+
+def test_config1_training_to_8000_all_merges(swt, dev, oracle_jobs, synth):
+    """configs[1]'s training half at spec on the S85k-lex stand-in: FastBPE.train to vocab 8,000 -- EVERY merge (7,9xx of them, most
+    of them taken several per step from plateaus of tied pairs, with re-plans and stream squeezes in between), the vocabulary
+    and the final symbol stream against the oracle's full recount per merge (bpe.py:88-111)."""
+    _train_against(swt, synth.s85k(), oracle_jobs["lex"].result()).reset()
+
+
+def test_headline_corpus_encode_all_sentences_three_dedup_modes(bpe8k, dev, oracle, synth):
+    """bench.py's headline workload (configs[1] on S85k-open): ALL 85,000 sentences against the oracle, through
+    the three paths a handle can take -- adaptive (the handle decides from what the last call saw: two calls, so that both of
+    its decisions run), word-level dedup forced, direct -- from device-resident text (what bench.py times) and from list[str]"""
+    sents = synth.s85k_open()
+    assert len(sents) == 85000
+    orc = oracle.OracleBPE(bpe8k.merges_list)
+    blob, boff = oracle.pack([s.lower() for s in sents])
+    want, woff = orc.tokenize_packed_mt(blob, boff, min(os.cpu_count() or 1, 32))
+    text, off = dev.pack_utf8([s.lower() for s in sents])
+    try:
+        for mode in (dev.DEDUP_AUTO, dev.DEDUP_AUTO, dev.DEDUP_ALWAYS, dev.DEDUP_NEVER):
+            bpe8k._table.set_option(dev.OPT_DEDUP, mode)
+            ids, ooff = bpe8k._table.encode(text, off)
+            assert np.array_equal(ooff, woff), mode
+            assert np.array_equal(ids, want), mode
+        bpe8k._table.set_option(dev.OPT_DEDUP, dev.DEDUP_AUTO)
+        ids, ooff = bpe8k.encode_ids_batch(sents)  # strings -> joined bytes -> device lower + split + encode
+        assert np.array_equal(ids, want) and np.array_equal(ooff, woff)
+    finally:
+        bpe8k._table.set_option(dev.OPT_DEDUP, dev.DEDUP_AUTO)
 
 
 # ------------------------------------------------------------------------------------------------ configs[2]
@@ -115,36 +172,44 @@ def test_config2_wp_one_million_sentences(wp30k, oracle, synth):
 
 # ------------------------------------------------------------------------------------------------ configs[3]
 
-def test_config3_two_million_types_first_merges(dev, oracle, synth):
-    """configs[3] at spec, reference formulation (bpe.py:73-81: deduplicated word types with frequencies): 2,000,000 types /
-    110 M tokens (~1 GiB of text).  First 200 merges (pairs AND counts) and the rewritten stream against the oracle's full
-    recount; then 2,000 more merges on the device and the incremental histogram against a recount of the final stream."""
+def test_config3_two_million_types_to_32k_merges(dev, oracle_jobs, synth):
+    """configs[3] at spec, reference formulation (bpe.py:73-81: deduplicated word types with frequencies):
+    2,000,000 types / 110 M tokens (~1 GiB of text) to 32,000 merges.  The first 1,000 merges (pairs AND counts) and the
+    rewritten stream against the oracle's full recount per merge; then on to 32,000 on the device, held by what does not depend
+    on an oracle: counts never grow (bpe.py:90-102), no pair is merged twice, the inverted index was never abandoned, the
+    live-symbol counter equals the exported stream, and the incremental histogram equals a recount of that stream."""
     sym, off, freq = synth.train_words(2_000_000, 1073741824, total_tokens=2_000_000 * 55)
     tr = dev.BpeTrainer.from_words(sym, off, freq)
-    lefts, rights, counts = tr.run(200, dev.SYM_BASE)
-    orc = oracle.OracleBPETrainer.from_words(sym, off, freq)
-    orc.run(10 ** 9, 200)
+    lefts, rights, counts = tr.run(1000, dev.SYM_BASE)
+    orc = oracle_jobs["config3"].result()
     ids, cnt = orc.merge_ids()
-    assert len(lefts) == 200 == len(ids)
+    assert len(lefts) == 1000 == len(ids)
     assert np.array_equal(np.asarray(lefts, dtype=np.uint32), ids[:, 0]) and np.array_equal(np.asarray(rights, dtype=np.uint32), ids[:, 1])
     assert np.array_equal(np.asarray(counts, dtype=np.uint64), cnt)
     got_sym, got_off, got_freq = tr.export()
     want_sym, want_off, want_freq = orc.export()
     assert np.array_equal(got_off, want_off) and np.array_equal(got_sym, want_sym) and np.array_equal(got_freq, want_freq)
-    l2, r2, c2 = tr.run(2000, dev.SYM_BASE + 200)
-    assert len(l2) == 2000
-    assert np.all(np.diff(np.concatenate([counts, c2]).astype(np.int64)) <= 0)  # BPE counts never grow (bpe.py:90-102)
-    assert len({(int(a), int(b)) for a, b in zip(np.concatenate([lefts, l2]), np.concatenate([rights, r2]))}) == 2200
+    l2, r2, c2 = tr.run(31000, dev.SYM_BASE + 1000)
+    assert len(l2) == 31000
+    assert np.all(np.diff(np.concatenate([counts, c2]).astype(np.int64)) <= 0)
+    pairs = (np.concatenate([lefts, l2]).astype(np.uint64) << np.uint64(32)) | np.concatenate([rights, r2]).astype(np.uint64)
+    assert np.unique(pairs).size == 32000
+    st = tr.stats()
+    assert st["flags"] & 1 == 0
+    end_sym, end_off, _ = tr.export()
+    assert tr.info()["n_symbols"] == end_sym.size == int(end_off[-1])
+    # every merge removed at least one symbol, and symbol ids name the merges in order
+    assert int(end_sym.max()) < dev.SYM_BASE + 32000 and end_sym.size <= got_sym.size - 31000
     _same_histogram(tr)
     tr.close()
 
 
-def _raw_text(sym, off, n_tokens, seed, zipf_a=1.05, per_sent=40):
+def _raw_text(sym, off, n_tokens, seed, zipf_a=1.05, per_sent=40, chunk=8_000_000):
     """space-separated Zipf draws over the word types, a sentence boundary every per_sent words: (uint8 text, uint64 offsets,
-    type index of every token)"""
+    type index of every token).  Built in chunks of `chunk` tokens so that 2^30 bytes need a few GB of temporaries, not tens."""
     rng = np.random.default_rng(seed)
     n_types = off.size - 1
-    idx = (rng.zipf(zipf_a, size=n_tokens) - 1) % n_types
+    idx = ((rng.zipf(zipf_a, size=n_tokens) - 1) % n_types).astype(np.int32)
     cp = sym.astype(np.int64)
     # UTF-8 bytes of every type (the alphabet is Latin/Polish: 1 or 2 bytes per code point)
     two = cp >= 0x80
@@ -158,40 +223,61 @@ def _raw_text(sym, off, n_tokens, seed, zipf_a=1.05, per_sent=40):
     tb[boff[:-1][two] + 1] = 0x80 | (cp[two] & 0x3F)
     wb0 = boff[off[:-1].astype(np.int64)]
     wlen = boff[off[1:].astype(np.int64)] - wb0
-    lens = wlen[idx]
-    step = lens + 1
-    dst = np.cumsum(step) - step
-    total = int(step.sum())
+    total = int(wlen[idx].sum()) + n_tokens  # every token is followed by one space
     out = np.full(total, 0x20, dtype=np.uint8)
-    intra = np.arange(int(lens.sum()), dtype=np.int64) - np.repeat(np.cumsum(lens) - lens, lens)
-    out[np.repeat(dst, lens) + intra] = tb[np.repeat(wb0[idx], lens) + intra]
-    starts = dst[::per_sent]
-    soff = np.concatenate([starts, [total]]).astype(np.uint64)
+    starts = []
+    base = 0
+    assert chunk % per_sent == 0
+    wb0 = wb0.astype(np.int32)
+    wlen32 = wlen.astype(np.int32)
+    for c0 in range(0, n_tokens, chunk):  # positions inside a chunk fit 32 bits: half the memory traffic of the index arrays
+        ix = idx[c0:c0 + chunk]
+        lens = wlen32[ix]
+        step = lens + 1
+        dst = np.cumsum(step, dtype=np.int32) - step
+        n_chunk = int(dst[-1]) + int(step[-1])
+        intra = np.arange(int(lens.sum()), dtype=np.int32) - np.repeat(np.cumsum(lens, dtype=np.int32) - lens, lens)
+        out[base:base + n_chunk][np.repeat(dst, lens) + intra] = tb[np.repeat(wb0[ix], lens) + intra]
+        starts.append(dst[::per_sent].astype(np.int64) + base)
+        base += n_chunk
+    assert base == total
+    soff = np.concatenate(starts + [np.array([total], dtype=np.int64)]).astype(np.uint64)
     return out, soff, idx
 
 
 def test_config3_raw_text_stream(dev, oracle, synth):
-    """configs[3] "raw stream" variant: >= 256 MB of text through swt_bpe_train_create_text (device split + Counter, bpe.py:70-81).
-    The unique-word stream must be the types in first-occurrence order with their token counts (known from the generator), and
-    100 merges from it must equal the oracle's on that word list."""
+    """configs[3] "raw stream" variant at spec ("until 2^30 UTF-8 bytes"): one GiB of text through
+    swt_bpe_train_create_text (device split + Counter, bpe.py:70-81).  The unique-word stream must be the types in
+    first-occurrence order with their token counts (known from the generator), and 100 merges from it must equal the oracle's
+    on that word list."""
     sym, off, _ = synth.train_words(400_000, 1073741824, total_tokens=400_000 * 55)
-    text, soff, idx = _raw_text(sym, off, 28_000_000, seed=7)
-    assert text.size >= 256 * 1000 * 1000
+    text, soff, idx = _raw_text(sym, off, 78_000_000, seed=7)
+    assert text.size >= 2 ** 30
     tr = dev.BpeTrainer.from_text(text, soff)
     got_sym, got_off, got_freq = tr.export()
+    del text
     # two types may spell the same word: identity is the STRING (bpe.py:76 Counter(words))
     lens = np.diff(off.astype(np.int64))
+    n_types = off.size - 1
+    seen = np.bincount(idx, minlength=n_types) > 0
     words = {}
-    canon = np.zeros(off.size - 1, dtype=np.int64)
-    for t in np.unique(idx):
+    canon = np.arange(n_types, dtype=np.int64)
+    for t in np.flatnonzero(seen):
         w = sym[int(off[t]):int(off[t + 1])].tobytes()
         canon[t] = words.setdefault(w, t)
     cidx = canon[idx]
-    uniq, first, counts = np.unique(cidx, return_index=True, return_counts=True)
-    order = np.argsort(first, kind="stable")
+    counts = np.bincount(cidx, minlength=n_types)
+    # first occurrence of every type: assigning positions in REVERSE order leaves the earliest one in place
+    first = np.full(n_types, -1, dtype=np.int64)
+    first[cidx[::-1]] = np.arange(cidx.size - 1, -1, -1, dtype=np.int64)
+    uniq = np.flatnonzero(counts)
+    assert np.array_equal(cidx[first[uniq]], uniq)
+    for t in uniq[[0, uniq.size // 2, uniq.size - 1]]:  # (numpy leaves the LAST write of a duplicate index: checked, not assumed)
+        assert first[t] == int(np.argmax(cidx == t))
+    order = np.argsort(first[uniq], kind="stable")
     want_types = uniq[order]
     assert got_freq.size == want_types.size
-    assert np.array_equal(got_freq.astype(np.int64), counts[order])
+    assert np.array_equal(got_freq.astype(np.int64), counts[want_types])
     assert np.array_equal(np.diff(got_off.astype(np.int64)), lens[want_types])
     want_sym = np.concatenate([sym[int(off[t]):int(off[t + 1])] for t in want_types[:5000]])
     assert np.array_equal(got_sym[:want_sym.size], want_sym)
@@ -312,3 +398,21 @@ def test_string_collision_replay_branch(swt, dev, oracle, corpora, monkeypatch, 
     assert tok.corpus_as_symbols == want
     # and its histogram is the recount of that stream
     _same_histogram(tok._trainer)
+
+
+# ------------------------------------------------------------------------------------------------ configs[1], the headline corpus
+# (last in the module: the oracle's recount of S85k-open -> 8,000 is the longest of the three background runs)
+
+def test_headline_corpus_training_every_merge(swt, dev, oracle_jobs, synth, golden):
+    """bench.py's `train` block at spec: FastBPE.train(S85k-open, 8000) -- EVERY one of the 7,922 merges, the vocabulary, the
+    final stream and the histogram against the oracle (bpe.py:88-111), and the three 40-merge windows (start / middle / end)
+    against what the REFERENCE'S OWN PYTHON produced there (tests/golden/ref_s85k_open_windows.json, written by
+    tools/ref_python_baseline.py in the build container by importing the unmodified class)."""
+    tok = _train_against(swt, synth.s85k_open(), oracle_jobs["open"].result())
+    ref = golden("ref_s85k_open_windows.json")
+    assert ref["max_vocab"] == 8000 and len(ref["windows"]) == 3
+    for w in ref["windows"]:
+        a = w["first_merge"]
+        assert [list(m) for m in tok.merges_list[a:a + len(w["merges"])]] == w["merges"], a
+    tok.reset()
+

@@ -184,3 +184,18 @@ def test_wp_score_is_pythons_int_division(oracle):
     for cnt, fl, fr in cases:
         want = struct.unpack("<Q", struct.pack("<d", cnt / (fl * fr)))[0]
         assert oracle.wp_score_bits(cnt, fl, fr) == want, (cnt, fl, fr)
+
+
+def test_oracle_on_the_headline_corpus_against_the_reference_windows(oracle, golden):
+    """S85k-open (bench.py's training corpus): the reference's own FastBPE.train produced these merges when started at merge 0
+    (tools/ref_python_baseline.py; the later windows restart from the oracle's state and are checked there, and on the GPU box
+    by tests/test_gpu_configs.py where the oracle's full run is affordable)."""
+    from subword_tokenizers_amd import synth
+
+    ref = golden("ref_s85k_open_windows.json")
+    w0 = ref["windows"][0]
+    assert w0["first_merge"] == 0
+    orc = oracle.OracleBPETrainer(synth.s85k_open())
+    orc.run(ref["max_vocab"], len(w0["merges"]))
+    assert [list(m) for m in orc.merges_list] == w0["merges"]
+

@@ -107,7 +107,8 @@ def main():
 
     done = 0
     for start in starts:
-        orc.run(args.max_vocab, start - done)
+        if start > done:  # (max_steps 0 would mean "no limit")
+            orc.run(args.max_vocab, start - done)
         done = start
         assert orc.n_merges == start, (orc.n_merges, start)
         n_t = orc.n_symbols
