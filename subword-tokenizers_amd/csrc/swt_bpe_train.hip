@@ -116,6 +116,8 @@ __device__ __forceinline__ uint32_t table_slot(const PairTable &T, unsigned long
   return hash_slot(key, T.bits);
 }
 
+constexpr uint32_t kCidxPending = 0xFFFFFFFEu;  // cidx[slot]: the slot was listed by the exchange's settle pass; its mirror comes with the next step
+
 __device__ __forceinline__ void cand_push(const TrainCtx &C, uint32_t slot) {
   // past the capacity the list has lost a candidate: n_cand says so, and the next argmax refuses to answer (the flag is not
   // raised here: workgroups of the apply launch that is running must not see it change)
@@ -126,9 +128,9 @@ __device__ __forceinline__ void cand_push(const TrainCtx &C, uint32_t slot) {
 // count += delta with the candidate invariant kept: a count that crosses theta upwards joins the list (only the pairs a
 // merge creates ever rise)
 __device__ __forceinline__ void count_add(const TrainCtx &C, uint32_t slot, long long delta) {
-  if (C.cidx) {  // a listed pair keeps its compact copy in step
+  if (C.cidx) {  // a listed pair keeps its compact copy in step (kCidxPending: listed, not mirrored yet)
     const uint32_t ci = C.cidx[slot];
-    if (ci != 0xFFFFFFFFu)
+    if (ci < kCidxPending)
       (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&C.ccnt[ci]), (unsigned long long)delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (delta > 0 && C.theta) {
@@ -913,7 +915,7 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
       const unsigned long long delta = (unsigned long long)dl[u];
       const uint32_t slot = h[u];
       if (!C.pend) {  // count_add, with the compact copy's index already here
-        if (ci[u] != 0xFFFFFFFFu)
+        if (ci[u] < kCidxPending)
           (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&C.ccnt[ci[u]]), delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (dl[u] > 0 && C.theta)  // only the pairs a merge creates ever rise: they may cross theta
           was[u] = (long long)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&C.T.cnt[slot]), delta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1347,6 +1349,7 @@ __global__ __launch_bounds__(kTrainThreads) void fast_tie_kernel(const uint32_t 
   // number is taken, and the segment before it ends where this one begins
   if (lead) C.seg_start[C.step] = idx_cursor;
   if ((flags & kFlagReplan) || hdr[2] || hdr[1] >= limit) return;  // nothing runs until the host has looked (fast_apply_kernel: too)
+  if (C.halt_ext && *C.halt_ext) return;  // sharded: an exchange block overflowed (the same on every rank)
   SWT_STAMP(ts, 1);
   if (lead) {
     // a merged id that was reused in the last step voids the index from this step on
@@ -1748,6 +1751,274 @@ __global__ __launch_bounds__(kTrainThreads) void fast_apply_kernel(uint32_t *__r
   apply_body(sym, woff, freq, n_words, C, P);
 }
 
+// ---- the fast path, corpus-sharded (swt_dist.hip drives it) ----------------------------------------------------------------
+// Every rank holds the histogram of the WHOLE corpus, so fast_tie_kernel finds the same maximum and the same tied set on
+// every rank; what differs is where the tied pairs OCCUR.  bpe.py:102 orders them by first occurrence over the whole
+// corpus = (rank, word, offset), ranks being ordered by their sentence ranges.  Per step:
+//   fast_tie_kernel            as unsharded: local window scan from the local plateau cursor
+//   tie_pack_kernel            this rank's TieMsg: its <= kMaxBatch earliest tied pairs inside its window (with the
+//                              neighbour evidence), its earliest tied occurrence anywhere, whether the window was everything
+//   [all-gather of the TieMsgs]
+//   fast_apply_sharded_kernel  every workgroup of every rank derives the SAME batch from the gathered messages, then
+//                              apply_body on the local words (deltas into pend[], as the generic sharded step)
+//   pack_records -> [all-gather of the record blocks] -> add_blocks -> finish_exchange        (once per STEP, not per merge)
+// What is certain about the global order: the pairs a rank saw inside its window are its earliest ones; a pair it did not
+// see there may still occur behind the window -- unless the window was the whole rest of the shard (`exhausted`).  So the
+// batch is taken from: everything the ranks 0..r*-1 reported (all exhausted), plus the window of r*, the first rank that is
+// not; a pair seen by several ranks belongs to the first.  If that leaves nothing (r* saw no tied pair inside its window),
+// the step merges the one pair that is certain: r*'s earliest occurrence anywhere (its scan goes on until it has one).
+__global__ __launch_bounds__(kTrainThreads) void tie_pack_kernel(TrainCtx C, uint64_t n_words, uint32_t limit) {
+  __shared__ unsigned long long f_pos[kTieSet], f_key[kTieSet];
+  __shared__ uint32_t f_info[kTieSet][5];
+  __shared__ unsigned int n_found, n_inwin;
+  TrainState *st = C.st;
+  TieMsg *msg = C.tie_msg;
+  const unsigned par = C.step & 1u;
+  const unsigned int flags = st->flags;
+  const unsigned long long run_done = st->run_done[par], halt = st->halt;
+  const unsigned long long mx = st->max_count, tied = st->n_tied, n_list = st->n_list[par], win_end = st->win_end;
+  const bool idle = (flags & kFlagReplan) || halt || run_done >= limit || (C.halt_ext && *C.halt_ext);
+  if (threadIdx.x == 0) { n_found = 0; n_inwin = 0; }
+  __syncthreads();
+  if (idle || !mx) {  // fast_apply_sharded_kernel does nothing either (the same state on every rank)
+    if (threadIdx.x == 0) { msg->win_end = 0; msg->min_pos = kEmptyKey; msg->min_key = kEmptyKey; msg->n = 0; msg->exhausted = 1; }
+    return;
+  }
+  if (tied >= 2 && n_list) {
+    unsigned int my_k = 0xFFFFFFFFu;
+    unsigned long long my_pos = kEmptyKey;
+    if (threadIdx.x < n_list) {
+      const uint32_t info = C.tied_idx[par * kTieSet + threadIdx.x];
+      const size_t ci = (size_t)par * C.cand_cap + (info & 0x7FFFFFFFu);
+      my_pos = C.gpos[ci];
+      if (my_pos != kEmptyKey) {
+        my_k = atomicAdd(&n_found, 1u);
+        f_pos[my_k] = my_pos;
+        f_key[my_k] = C.tied_key[par * kTieSet + threadIdx.x];
+        f_info[my_k][0] = C.gnb_min[2 * ci];
+        f_info[my_k][1] = C.gnb_min[2 * ci + 1];
+        f_info[my_k][2] = C.gnb_max[2 * ci];
+        f_info[my_k][3] = C.gnb_max[2 * ci + 1];
+        f_info[my_k][4] = info >> 31;
+        if (my_pos < win_end) atomicAdd(&n_inwin, 1u);
+      }
+    }
+    __syncthreads();
+    const unsigned int nf = n_found;
+    if (my_k != 0xFFFFFFFFu) {
+      unsigned int rank = 0;
+      for (unsigned int u = 0; u < nf; u++) rank += f_pos[u] < my_pos ? 1u : 0u;  // positions are distinct
+      if (rank < kMaxBatch && my_pos < win_end) {
+        TieEntry &e = msg->e[rank];
+        e.pos = my_pos;
+        e.key = f_key[my_k];
+        e.nb_lo[0] = f_info[my_k][0]; e.nb_lo[1] = f_info[my_k][1];
+        e.nb_hi[0] = f_info[my_k][2]; e.nb_hi[1] = f_info[my_k][3];
+        e.danger = f_info[my_k][4];
+        e.pad = 0;
+      }
+      if (rank == 0) { msg->min_pos = my_pos; msg->min_key = f_key[my_k]; }
+    }
+    if (threadIdx.x == 0) {
+      if (!nf) { msg->min_pos = kEmptyKey; msg->min_key = kEmptyKey; }
+      msg->win_end = win_end;
+      msg->n = n_inwin < kMaxBatch ? n_inwin : kMaxBatch;  // (the pairs inside the window are a prefix of the order by position)
+      msg->exhausted = ((win_end >> 32) >= n_words || !nf) ? 1u : 0u;
+    }
+  } else if (threadIdx.x == 0) {
+    unsigned long long pos = kEmptyKey, key = st->best_key;  // one pair holds the maximum: every rank names it
+    if (tied >= 2) {  // a plateau wider than the tie set: the scan left this shard's earliest pair in wkey[]
+      pos = st->best2[par];
+      key = pos != kEmptyKey ? C.wkey[pos >> 32] : kEmptyKey;
+    }
+    msg->win_end = win_end;
+    msg->min_pos = pos;
+    msg->min_key = key;
+    msg->n = 0;
+    msg->exhausted = (tied >= 2 && pos != kEmptyKey) ? 0u : 1u;  // wide plateau: only the earliest occurrence is known
+  }
+}
+
+__global__ __launch_bounds__(kTrainThreads) void fast_apply_sharded_kernel(uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
+                                                                           const uint32_t *__restrict__ freq, uint64_t n_words, TrainCtx C,
+                                                                           StepLog *__restrict__ log, uint32_t first_merged, uint32_t limit) {
+  __shared__ BatchPlan P;
+  __shared__ unsigned long long g_key[kMaxBatch];
+  __shared__ uint32_t g_lo[kMaxBatch][2], g_hi[kMaxBatch][2], g_dng[kMaxBatch];
+  __shared__ unsigned int g_n;
+  TrainState *st = C.st;
+  const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+  const unsigned par = C.step & 1u;
+  __shared__ unsigned long long hdr[3];
+  if (threadIdx.x == 0) { hdr[0] = st->flags; hdr[1] = st->run_done[par]; hdr[2] = st->halt; }
+  const unsigned long long mx = st->max_count, tied_here = st->n_tied, n_list = st->n_list[par];
+  __syncthreads();
+  const unsigned int flags = (unsigned int)hdr[0];
+  const unsigned long long run_done = hdr[1];
+  if ((flags & kFlagReplan) || hdr[2] || run_done >= limit || (C.halt_ext && *C.halt_ext)) {
+    if (lead) st->run_done[par ^ 1u] = run_done;
+    return;
+  }
+  if (threadIdx.x == 0) {
+    g_n = 0;
+    P.K = 0;
+    P.first_m = first_merged + (uint32_t)run_done;
+    for (int u = 0; u < (int)kMaxBatch; u++) { P.l[u] = kHole; P.r[u] = kHole; }
+  }
+  __syncthreads();
+  // ---- the batch, from the gathered messages alone (so every workgroup of every rank decides alike) ----
+  // ranks in order; the first wave collects, the workgroup's barriers carry g_n from rank to rank (uniform trip count: the
+  // loop looks at nothing but the gathered messages and g_n)
+  __shared__ unsigned int g_lone;
+  if (threadIdx.x == 0) g_lone = 0;
+  __syncthreads();
+  if (mx) {
+    for (uint32_t r = 0; r < C.world; r++) {
+      const TieMsg &m = C.tie_all[r];
+      const uint32_t nr = m.n < kMaxBatch ? m.n : kMaxBatch;
+      if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const unsigned int gn = g_n;
+        unsigned long long key = kEmptyKey;
+        bool fresh = false;
+        if ((uint32_t)lane < nr) {
+          key = m.e[lane].key;
+          fresh = true;
+          for (unsigned int u = 0; u < gn; u++) fresh &= g_key[u] != key;  // a lower rank holds it earlier
+        }
+        const unsigned long long F = __ballot(fresh);
+        const unsigned int at = gn + (unsigned int)__popcll(F & ((1ull << lane) - 1ull));
+        if (fresh && at < kMaxBatch) {
+          g_key[at] = key;
+          g_lo[at][0] = 0xFFFFFFFFu; g_lo[at][1] = 0xFFFFFFFFu;
+          g_hi[at][0] = 0u; g_hi[at][1] = 0u;
+          g_dng[at] = m.e[lane].danger;
+        }
+        if (lane == 0) {
+          const unsigned int tot = gn + (unsigned int)__popcll(F);
+          g_n = tot < kMaxBatch ? tot : kMaxBatch;
+        }
+      }
+      __syncthreads();
+      const unsigned int gn = g_n;
+      // an untied step (every rank names the one pair that holds the maximum), or nothing certain but this rank's
+      // earliest occurrence behind its window: the batch is that single pair
+      const bool untied = m.min_pos == kEmptyKey && m.min_key != kEmptyKey && m.n == 0;
+      const bool behind = !m.exhausted && m.min_key != kEmptyKey;
+      if (gn == 0 && (untied || behind)) {
+        if (threadIdx.x == 0) {
+          g_key[0] = m.min_key; g_dng[0] = 1u;
+          g_lo[0][0] = g_lo[0][1] = 0xFFFFFFFFu; g_hi[0][0] = g_hi[0][1] = 0u;
+          g_n = 1; g_lone = 1;
+        }
+        break;
+      }
+      if (!m.exhausted || gn >= kMaxBatch) break;  // what the later ranks hold may come after something unseen here
+    }
+    __syncthreads();
+    // the evidence every rank saw of the collected pairs (any occurrence anywhere is a fact)
+    if (!g_lone && threadIdx.x < 64) {
+      const unsigned int gn = g_n;
+      for (uint32_t r = 0; r < C.world; r++) {
+        const TieMsg &m = C.tie_all[r];
+        const uint32_t nr = m.n < kMaxBatch ? m.n : kMaxBatch;
+        if (threadIdx.x < nr) {
+          const unsigned long long key = m.e[threadIdx.x].key;
+          for (unsigned int u = 0; u < gn; u++)
+            if (g_key[u] == key) {
+              atomicMin(&g_lo[u][0], m.e[threadIdx.x].nb_lo[0]);
+              atomicMin(&g_lo[u][1], m.e[threadIdx.x].nb_lo[1]);
+              atomicMax(&g_hi[u][0], m.e[threadIdx.x].nb_hi[0]);
+              atomicMax(&g_hi[u][1], m.e[threadIdx.x].nb_hi[1]);
+            }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 64 && mx) {
+    const int lane = threadIdx.x;
+    const unsigned int gn = g_n;
+    // the longest prefix whose members share no symbol, up to and including the first dangerous one (fast_apply_kernel)
+    const unsigned int nsel = gn;
+    const unsigned int rk = lane;
+    uint32_t a = kHole, b = kHole, dng = 0;
+    if (rk < nsel) {
+      a = (uint32_t)(g_key[rk] >> 32);
+      b = (uint32_t)g_key[rk];
+      dng = g_dng[rk] && !(g_lo[rk][0] < g_hi[rk][0] && g_lo[rk][1] < g_hi[rk][1] && a != b);
+    }
+    bool clash = false;
+#pragma unroll
+    for (int jj = 0; jj < (int)kMaxBatch; jj++) {
+      const uint32_t aj = __shfl(a, jj), bj = __shfl(b, jj);
+      if ((unsigned int)jj < rk && rk < nsel) clash |= a == aj || a == bj || b == aj || b == bj;
+    }
+    const unsigned long long m_clash = __ballot(clash), m_dng = __ballot(dng != 0 && rk < nsel);
+    const unsigned long long room = (unsigned long long)limit - run_done;
+    uint32_t K = nsel;
+    if (m_clash && (uint32_t)__builtin_ctzll(m_clash) < K) K = (uint32_t)__builtin_ctzll(m_clash);
+    if (m_dng && (uint32_t)__builtin_ctzll(m_dng) + 1 < K) K = (uint32_t)__builtin_ctzll(m_dng) + 1;
+    if ((unsigned long long)K > room) K = (uint32_t)room;
+    if (rk < K) { P.l[rk] = a; P.r[rk] = b; }
+    if (rk == 0) P.K = K;
+  }
+  __syncthreads();
+  const uint32_t K = P.K;
+  if (K == 0) {  // bpe.py:98-99: no pair left in any shard
+    if (lead) { st->halt = 2; st->run_done[par ^ 1u] = run_done; }
+    return;
+  }
+  // ---- where this rank's words of the K pairs are listed: its own tied list knows (the planner looked them up), else a lookup
+  if (threadIdx.x < kMaxBatch) P.ent0[threadIdx.x + 1] = ~0ull;
+  __syncthreads();
+  if (!(flags & kFlagIndexBroken)) {
+    if (tied_here >= 2 && threadIdx.x < n_list) {
+      const unsigned long long key = C.tied_key[par * kTieSet + threadIdx.x];
+      for (uint32_t q = 0; q < K; q++)
+        if (pair_key(P.l[q], P.r[q]) == key) P.ent0[q + 1] = plan_take(C, P, (int)q, C.tied_plan[par * kTieSet + threadIdx.x]);
+    } else if (tied_here < 2 && threadIdx.x == 0 && K == 1 && pair_key(P.l[0], P.r[0]) == st->best_key) {
+      P.ent0[1] = plan_take(C, P, 0, C.tied_plan[par * kTieSet]);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < K && P.ent0[threadIdx.x + 1] == ~0ull)
+    P.ent0[threadIdx.x + 1] = (flags & kFlagIndexBroken) ? 0ull : plan_member(C, P, (int)threadIdx.x);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    P.ent0[0] = 0;
+    for (uint32_t q = 0; q < K; q++) P.ent0[q + 1] += P.ent0[q];
+  }
+  if (lead) {
+    const unsigned long long my_pos = st->best2[par];  // this shard's earliest tied occurrence (the scan went on until it had one)
+    st->res_pos = my_pos;
+    st->win_key = pair_key(P.l[0], P.r[0]);
+    st->best2[par ^ 1u] = kEmptyKey;
+    st->n_synced = st->n_synced_next;
+    // the plateau cursor is local: every tied pair of this shard lies at or after its earliest tied occurrence
+    if (tied_here >= 2 && my_pos != kEmptyKey) { st->plateau = mx; st->cursor_w = (uint32_t)(my_pos >> 32); }
+    else if (st->plateau != mx) { st->plateau = mx; st->cursor_w = 0; }
+    st->run_done[par ^ 1u] = run_done + K;
+    st->run_active += 1;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < K) {
+    const uint32_t q = threadIdx.x, merged = P.first_m + q;
+    const unsigned long long n_syms = st->step_syms, n_cand = st->n_cand;
+    if (merged >= C.id_base && merged - C.id_base < C.seg_cap && C.seg_of[merged - C.id_base] == 0) C.seg_of[merged - C.id_base] = C.step;
+    else atomicOr(&st->flags, kFlagBrokenPending);
+    StepLog &row = log[run_done + q];
+    row.l = P.l[q];
+    row.r = P.r[q];
+    row.count = mx;
+    row.flag = 0ull;
+    row.n_syms = n_syms;
+    row.n_tied = g_n;
+    row.n_cand = n_cand;
+  }
+  __syncthreads();
+  apply_body(sym, woff, freq, n_words, C, P);
+}
+
 // ---- candidates --------------------------------------------------------------------------------------------------------
 // histogram of the live counts over 8 sub-buckets per octave: the host picks theta so that ~kCandTarget pairs pass it
 __device__ __forceinline__ uint32_t count_bucket(unsigned long long c) {
@@ -1850,7 +2121,13 @@ __global__ void add_blocks_kernel(const DeltaRec *__restrict__ blocks, uint32_t 
   }
 }
 
-// after add_blocks_kernel: pend[] of the touched slots back to zero and the list emptied -- or the halt raised
+// after add_blocks_kernel: pend[] of the touched slots back to zero and the list emptied -- or the halt raised.
+// Also the candidate list's new members.  add_blocks_kernel adds the ranks' blocks concurrently, so the ORDER in which the
+// deltas of one pair land differs from rank to rank: a push "when the count crosses theta" would list a pair twice on one
+// rank and once on another, the lists would differ in LENGTH, and a host decision that looks at the length (re-plan above
+// kCandHigh) would split the ranks.  So add_blocks_kernel adds without listing, and the listing happens here from the FINAL
+// counts, which are the same everywhere: every record's pair that now counts >= theta and is not listed yet is pushed once
+// (cidx[slot] goes from "none" to kCidxPending by CAS; the next step's housekeeper mirrors it).
 __global__ void finish_exchange_kernel(const DeltaRec *__restrict__ blocks, uint32_t world, uint64_t block_cap, TrainCtx C, unsigned int *halt) {
   __shared__ int bad;
   if (threadIdx.x == 0) {
@@ -1866,6 +2143,16 @@ __global__ void finish_exchange_kernel(const DeltaRec *__restrict__ blocks, uint
   }
   const unsigned long long n = C.st->n_touched;
   for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) C.pend[C.touched[i]] = 0;
+  if (C.theta && C.cidx)
+    for (uint32_t r = 0; r < world; r++) {
+      const DeltaRec *blk = blocks + (uint64_t)r * block_cap;
+      const uint64_t nr = blk[0].key;
+      for (uint64_t i = threadIdx.x; i < nr; i += blockDim.x) {
+        if (blk[i + 1].delta <= 0) continue;  // only a pair that gained can have risen to theta
+        const uint32_t slot = table_slot(C.T, blk[i + 1].key, C.st);  // (the key is there: add_blocks_kernel put it)
+        if (C.T.cnt[slot] >= (long long)C.theta && atomicCAS(&C.cidx[slot], 0xFFFFFFFFu, kCidxPending) == 0xFFFFFFFFu) cand_push(C, slot);
+      }
+    }
   __syncthreads();
   if (threadIdx.x == 0) C.st->n_touched = 0;
 }
@@ -2007,6 +2294,11 @@ TrainCtx swt_bpe_trainer::ctx() const {
   C.tstamp = d_tstamp;
   C.touched = d_touched;
   C.touched_cap = touched_cap;
+  C.halt_ext = sharded ? d_halt : nullptr;
+  C.tie_msg = d_tie_msg;
+  C.tie_all = d_tie_msgs;
+  C.world = world;
+  C.rank = rank;
   return C;
 }
 
@@ -2634,7 +2926,7 @@ void swt_bpe_train_destroy(swt_bpe_trainer *t) try {
                   (void *)t->d_steplog, (void *)t->d_sfreq, (void *)t->d_cand, (void *)t->d_ccnt, (void *)t->d_ckey, (void *)t->d_cidx, (void *)t->d_buckets, (void *)t->d_idx_tag,
                   (void *)t->d_idx_word, (void *)t->d_wstamp, (void *)t->d_wkey, (void *)t->d_tied_idx, (void *)t->d_tied_key, (void *)t->d_tied_plan, (void *)t->d_gpos, (void *)t->d_gnb_min, (void *)t->d_gnb_max, (void *)t->d_sym_alt, (void *)t->d_woff_alt, (void *)t->d_seg_start, (void *)t->d_seg_of, (void *)t->d_pend,
                   (void *)t->d_tstamp, (void *)t->d_touched, (void *)t->d_block, (void *)t->d_blocks_all, (void *)t->d_tie_line,
-                  (void *)t->d_tie_all, (void *)t->d_halt, (void *)t->K.keys, (void *)t->K.start, (void *)t->K.len, (void *)t->K.fill,
+                  (void *)t->d_tie_all, (void *)t->d_halt, (void *)t->d_tie_msg, (void *)t->d_tie_msgs, (void *)t->K.keys, (void *)t->K.start, (void *)t->K.len, (void *)t->K.fill,
                   (void *)t->K.words})
     if (p) (void)hipFree(p);
   table_free(t->T);
@@ -2976,6 +3268,10 @@ int trainer_enter_sharded(swt_bpe_trainer *t, uint32_t world, uint64_t block_cap
   SWT_HIP(hipMemsetAsync(t->d_halt, 0, 8, t->stream));
   SWT_HIP(hipMalloc((void **)&t->d_tie_line, 16));
   SWT_HIP(hipMalloc((void **)&t->d_tie_all, (size_t)world * 16));
+  SWT_HIP(hipMalloc((void **)&t->d_tie_msg, sizeof(TieMsg)));
+  SWT_HIP(hipMalloc((void **)&t->d_tie_msgs, (size_t)world * sizeof(TieMsg)));
+  SWT_HIP(hipMemsetAsync(t->d_tie_msg, 0, sizeof(TieMsg), t->stream));
+  SWT_HIP(hipMemsetAsync(t->d_tie_msgs, 0, (size_t)world * sizeof(TieMsg), t->stream));
   return trainer_set_block_cap(t, block_cap);
 }
 
@@ -3035,9 +3331,94 @@ void trainer_enqueue_decide_apply(swt_bpe_trainer *t, uint32_t rank, uint32_t lo
   trainer_enqueue_pack(t);
 }
 
+// ---- the sharded fast path: the host side of one round trip (the sizing rules of swt_bpe_train_run, over the whole corpus) ----
+// Every number below is a function of state that is the same on every rank (the counts, theta, the candidate list's length,
+// the merges done) -- except whether this rank's table had to grow, which voids its candidate list: that is why the runner
+// ORs `replan_first` over the ranks and all of them re-plan together, or their dry-point estimates would drift apart and
+// they would enqueue different numbers of steps.
+static void fast_trip_size(const swt_bpe_trainer *t, uint32_t remaining, double per_step, ShardTrip *trip) {
+  uint32_t steps = remaining < kRunBatch ? remaining : kRunBatch;
+  const double want = (double)remaining / per_step * 1.05 + 1.0;
+  if (want < (double)steps) steps = (uint32_t)want;
+  if (steps < 8) steps = remaining < 8 ? remaining : 8;
+  double c = (double)steps * per_step * 1.5 + 8.0;
+  if (c > (double)remaining) c = (double)remaining;
+  if (c > (double)kMaxRunSteps) c = (double)kMaxRunSteps;
+  uint32_t cap = (uint32_t)c;
+  if (cap < steps) cap = steps;
+  trip->steps = steps;
+  trip->cap = cap;
+}
+
+int trainer_fast_room(swt_bpe_trainer *t, uint32_t remaining, double per_step, ShardTrip *trip) {
+  int rc;
+  fast_trip_size(t, remaining, per_step, trip);
+  // every rank's new pairs land in every replica: the bound is over the whole corpus (trainer_prepare_batch)
+  const uint64_t by_sym = 2 * (t->n_base_global + t->n_applied + trip->cap + 1) + 1;
+  uint64_t per = t->h_st.max_count ? 2 * t->h_st.max_count : by_sym;
+  if (by_sym < per) per = by_sym;
+  if ((rc = ensure_room(t, per * trip->cap))) return rc;
+  trip->replan_first = !t->cand_valid || !t->theta || t->h_st.n_cand > kCandHigh;
+  return SWT_OK;
+}
+
+int trainer_fast_plan(swt_bpe_trainer *t, uint32_t remaining, double per_step, bool replan, uint32_t first_id, ShardTrip *trip) {
+  int rc;
+  for (int pass = 0;; pass++) {
+    if (replan && (rc = t->replan())) return rc;
+    fast_trip_size(t, remaining, per_step, trip);
+    trip->fast = t->theta != 0;
+    if (!trip->fast) {  // a plateau wider than the list: the generic step with the full-table argmax until the next re-plan
+      if (trip->steps > remaining) trip->steps = remaining;
+      trip->cap = trip->steps;
+      return ensure_steps(t, trip->steps, first_id + trip->cap);
+    }
+    if (t->theta > 1 && t->cand_built && pass == 0) {  // the dry point of the list (swt_bpe_train_run)
+      const double budget = t->dry_ratio * (double)t->cand_built - (double)t->since_replan;
+      if (budget < 24.0 && (double)remaining > budget && t->since_replan) {
+        if (t->dry_ratio < 2.0) t->dry_ratio *= 1.1;
+        replan = true;
+        continue;
+      }
+      const double most = budget / per_step + 1.0;
+      if (most < (double)trip->steps) {
+        trip->steps = most < 8.0 ? 8u : (uint32_t)most;
+        if (trip->steps > remaining) trip->steps = remaining;
+        if (trip->cap > trip->steps * kMaxBatch) trip->cap = trip->steps * kMaxBatch;
+      }
+    }
+    return ensure_steps(t, trip->steps, first_id + trip->cap);
+  }
+}
+
+// the step counters of the fast path start from zero, and no position of an earlier round trip is left
+int trainer_fast_begin(swt_bpe_trainer *t) {
+  SWT_HIP(hipMemsetAsync(&t->d_st->run_done[0], 0, 8 * 8, t->stream));
+  SWT_HIP(hipMemsetAsync(&t->d_st->best2[0], 0xFF, 2 * 8, t->stream));
+  SWT_HIP(hipMemsetAsync(t->d_gpos, 0xFF, 2 * (size_t)t->cand_cap * 8, t->stream));
+  SWT_HIP(hipMemsetAsync(t->d_gnb_min, 0xFF, 4 * (size_t)t->cand_cap * 4, t->stream));
+  SWT_HIP(hipMemsetAsync(t->d_gnb_max, 0, 4 * (size_t)t->cand_cap * 4, t->stream));
+  return SWT_OK;
+}
+
+void trainer_enqueue_fast_tie(swt_bpe_trainer *t, uint32_t limit) {
+  const TrainCtx C = t->ctx();
+  // (an empty shard runs the launches too: they carry its part of the exchange)
+  const unsigned tie_blocks = grid_for(t->n_words, 64, kTieBlocks);
+  hipLaunchKernelGGL(fast_tie_kernel, dim3(tie_blocks + 2), dim3(kTrainThreads), 0, t->stream, t->d_sym, t->d_woff, t->n_words, C, limit);
+  hipLaunchKernelGGL(tie_pack_kernel, dim3(1), dim3(kTrainThreads), 0, t->stream, C, t->n_words, limit);
+}
+
+void trainer_enqueue_fast_apply(swt_bpe_trainer *t, uint32_t first_merged, uint32_t limit) {
+  hipLaunchKernelGGL(fast_apply_sharded_kernel, dim3(kFastApplyBlocks), dim3(kTrainThreads), 0, t->stream, t->d_sym, t->d_woff, t->d_freq,
+                     t->n_words, t->ctx(), t->d_steplog, first_merged, limit);
+  trainer_enqueue_pack(t);
+}
+
 void trainer_enqueue_add_blocks(swt_bpe_trainer *t) {
   TrainCtx C = t->ctx();
-  C.pend = nullptr;  // the blocks go into the counts themselves
+  C.pend = nullptr;  // the blocks go into the counts themselves ...
+  C.theta = 0;       // ... and nothing is listed on the way: finish_exchange_kernel lists from the final counts
   hipLaunchKernelGGL(add_blocks_kernel, dim3(kPackBlocks), dim3(256), 0, t->stream, t->d_blocks_all, t->world, t->block_cap, C, t->d_halt);
   hipLaunchKernelGGL(finish_exchange_kernel, dim3(1), dim3(256), 0, t->stream, t->d_blocks_all, t->world, t->block_cap, t->ctx(), t->d_halt);
 }

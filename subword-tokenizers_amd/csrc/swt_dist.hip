@@ -296,6 +296,145 @@ static int exchange_again(swt_dist *d, swt_bpe_trainer **tr, uint32_t n_local) {
   return SWT_OK;
 }
 
+// One round trip of the generic step (argmax -> tie scan -> 16-byte all-gather -> decide + apply -> pack -> block all-gather ->
+// add): one merge per step, k steps.  The fast path falls back to it while a plateau is wider than the candidate list.
+static int enqueue_generic_steps(swt_dist *d, swt_bpe_trainer **tr, uint32_t n_local, uint32_t k, uint32_t first_id) {
+  int rc;
+  for (uint32_t s = 0; s < k; s++) {
+    for (uint32_t i = 0; i < n_local; i++) {
+      tr[i]->step_no++;
+      trainer_enqueue_tie_send(tr[i]);
+    }
+    if ((rc = gather_dev(d, tr, n_local, 16, [](swt_bpe_trainer *t) { return (const void *)t->d_tie_line; },
+                         [](swt_bpe_trainer *t) { return (void *)t->d_tie_all; })))
+      return rc;
+    for (uint32_t i = 0; i < n_local; i++) trainer_enqueue_decide_apply(tr[i], (uint32_t)rank_of(d, i), s, first_id + s);
+    if ((rc = gather_dev(d, tr, n_local, tr[0]->block_cap * sizeof(DeltaRec), [](swt_bpe_trainer *t) { return (const void *)t->d_block; },
+                         [](swt_bpe_trainer *t) { return (void *)t->d_blocks_all; })))
+      return rc;
+    for (uint32_t i = 0; i < n_local; i++) trainer_enqueue_add_blocks(tr[i]);
+  }
+  return SWT_OK;
+}
+
+// The fast path, sharded: per STEP fast_tie + tie_pack -> ONE all-gather of the ranks' tie messages (sizeof(TieMsg) bytes each)
+// -> fast_apply_sharded (every rank derives the same batch of up to 16 tied merges) + pack -> ONE all-gather of the record
+// blocks -> add + finish.  Up to 256 steps per host round trip, nothing synchronises in between.
+static int run_sharded_fast(swt_dist *d, swt_bpe_trainer **tr, uint32_t n_local, uint32_t max_steps, uint32_t first_merged, uint32_t *left,
+                            uint32_t *right, uint64_t *count, uint32_t *n_done) {
+  int rc;
+  std::vector<StepLog> hlog(kMaxRunSteps);
+  uint32_t done = 0;
+  bool exhausted = false;
+  int dry_runs = 0;
+  double per_step = 1.0;
+  while (done < max_steps && !exhausted) {
+    const uint32_t remaining = max_steps - done;
+    // head room on every local trainer; does any rank need a re-plan (its table grew, its list is long)?  All or none.
+    uint8_t want = 0;
+    std::vector<ShardTrip> trips(n_local);
+    for (uint32_t i = 0; i < n_local; i++) {
+      if ((rc = tr[i]->sync_state()) || (rc = tr[i]->check_state())) return rc;
+      if ((rc = trainer_fast_room(tr[i], remaining, per_step, &trips[i]))) return rc;
+      want |= trips[i].replan_first ? 1 : 0;
+    }
+    if (!d->local) {
+      std::vector<const void *> ptrs(1, &want);
+      std::vector<uint8_t> all;
+      if ((rc = gather_host(d, ptrs, 1, all, tr[0]->stream))) return rc;
+      for (uint8_t w : all) want |= w;
+    }
+    for (uint32_t i = 0; i < n_local; i++)
+      if ((rc = trainer_fast_plan(tr[i], remaining, per_step, want != 0, first_merged + done, &trips[i]))) return rc;
+    const ShardTrip trip = trips[0];
+    for (uint32_t i = 1; i < n_local; i++)
+      if (trips[i].steps != trip.steps || trips[i].cap != trip.cap || trips[i].fast != trip.fast)
+        return fail(SWT_ERR_STATE, "the shards sized a round trip differently (%u/%u steps, %u/%u merges): their replicas have diverged",
+                    trips[i].steps, trip.steps, trips[i].cap, trip.cap);
+    if (trip.cap > kMaxRunSteps) return fail(SWT_ERR_STATE, "a round trip was sized beyond the step log");
+    prof_begin(tr[0]->stream);
+    if (trip.fast) {
+      for (uint32_t i = 0; i < n_local; i++)
+        if ((rc = trainer_fast_begin(tr[i]))) return rc;
+      for (uint32_t s = 0; s < trip.steps; s++) {
+        for (uint32_t i = 0; i < n_local; i++) {
+          tr[i]->step_no++;
+          tr[i]->rank = (uint32_t)rank_of(d, i);
+          trainer_enqueue_fast_tie(tr[i], trip.cap);
+        }
+        if ((rc = gather_dev(d, tr, n_local, sizeof(TieMsg), [](swt_bpe_trainer *t) { return (const void *)t->d_tie_msg; },
+                             [](swt_bpe_trainer *t) { return (void *)t->d_tie_msgs; })))
+          return rc;
+        for (uint32_t i = 0; i < n_local; i++) trainer_enqueue_fast_apply(tr[i], first_merged + done, trip.cap);
+        if ((rc = gather_dev(d, tr, n_local, tr[0]->block_cap * sizeof(DeltaRec), [](swt_bpe_trainer *t) { return (const void *)t->d_block; },
+                             [](swt_bpe_trainer *t) { return (void *)t->d_blocks_all; })))
+          return rc;
+        for (uint32_t i = 0; i < n_local; i++) trainer_enqueue_add_blocks(tr[i]);
+      }
+    } else if ((rc = enqueue_generic_steps(d, tr, n_local, trip.steps, first_merged + done))) {
+      return rc;
+    }
+    prof_end(tr[0]->stream);
+    SWT_HIP(hipGetLastError());
+    unsigned int halt = 0;
+    SWT_HIP(hipMemcpyAsync(hlog.data(), tr[0]->d_steplog, trip.cap * sizeof(StepLog), hipMemcpyDeviceToHost, tr[0]->stream));
+    SWT_HIP(hipMemcpyAsync(&halt, tr[0]->d_halt, 4, hipMemcpyDeviceToHost, tr[0]->stream));
+    for (uint32_t i = 0; i < n_local; i++)
+      if ((rc = tr[i]->sync_state()) || (rc = tr[i]->check_state())) return rc;
+    uint32_t good = 0;
+    unsigned long long stop = 0;  // 0, 2 no pair left, 3 re-plan
+    if (trip.fast) {
+      const unsigned long long logged = tr[0]->h_st.run_done[(tr[0]->step_no + 1) & 1u];
+      if (logged > trip.cap) return fail(SWT_ERR_STATE, "the step log overran its round trip");
+      good = (uint32_t)logged;
+      stop = tr[0]->h_st.halt;
+      for (uint32_t i = 0; i < good; i++)
+        if (hlog[i].flag != 0) return fail(SWT_ERR_STATE, "the step log has a hole");
+      for (uint32_t i = 1; i < n_local; i++)
+        if (tr[i]->h_st.run_done[(tr[i]->step_no + 1) & 1u] != logged)
+          return fail(SWT_ERR_STATE, "the shards logged different numbers of merges: their replicas have diverged");
+    } else {
+      while (good < trip.cap && hlog[good].flag == 0) good++;
+      if (good < trip.cap && hlog[good].flag != 4) stop = hlog[good].flag;
+    }
+    for (uint32_t g = 0; g < good; g++) {
+      left[done] = hlog[g].l;
+      right[done] = hlog[g].r;
+      count[done] = hlog[g].count;
+      for (uint32_t i = 0; i < n_local; i++) tr[i]->trace.push_back(hlog[g]);
+      done++;
+    }
+    for (uint32_t i = 0; i < n_local; i++) {
+      swt_bpe_trainer *t = tr[i];
+      t->n_applied += good;
+      t->since_replan += good;
+      if (good) t->h_st.max_count = hlog[good - 1].count;
+      if (stop == 3) {
+        if (trip.fast && t->theta > 1 && t->cand_built && t->since_replan) {
+          t->dry_ratio = 0.9 * (double)t->since_replan / (double)t->cand_built;
+          t->dry_ratio = t->dry_ratio < 0.3 ? 0.3 : (t->dry_ratio > 2.0 ? 2.0 : t->dry_ratio);
+        }
+        t->cand_valid = false;
+      }
+    }
+    if (halt) {  // the last step was applied everywhere but its deltas did not fit: bigger blocks, that exchange again
+      if ((rc = exchange_again(d, tr, n_local))) return rc;
+    } else if (stop == 3) {
+      if (!good && ++dry_runs > 64) return fail(SWT_ERR_STATE, "the candidate list cannot be rebuilt");
+    } else if (stop) {
+      exhausted = true;  // bpe.py:98-99: no pair left anywhere
+    }
+    if (trip.fast && good && tr[0]->h_st.run_active) {
+      per_step = (double)good / (double)tr[0]->h_st.run_active;
+      if (per_step < 1.0) per_step = 1.0;
+      if (per_step > (double)kMaxBatch) per_step = (double)kMaxBatch;
+    }
+    if (good) dry_runs = 0;
+  }
+  *n_done = done;
+  return SWT_OK;
+}
+
 // Up to max_steps merges over all shards.  Outputs as swt_bpe_train_run (identical on every rank).
 int swt_bpe_train_run_sharded(swt_bpe_trainer **tr, uint32_t n_local, swt_dist *d, uint32_t max_steps, uint32_t first_merged, uint32_t *left,
                               uint32_t *right, uint64_t *count, uint32_t *n_done) try {
@@ -306,6 +445,9 @@ int swt_bpe_train_run_sharded(swt_bpe_trainer **tr, uint32_t n_local, swt_dist *
     if (!tr[i]->sharded) return fail(SWT_ERR_STATE, "call swt_bpe_train_shard_begin first");
   if ((uint64_t)first_merged + max_steps >= 0xFFFFFFFFull) return fail(SWT_ERR_UNSUPPORTED, "merged symbol ids would reach the reserved id");
   *n_done = 0;
+  // SWT_DIST_GENERIC=1: the one-merge-per-step runner of round 2 (kept for comparison and as the fallback form)
+  const char *generic = getenv("SWT_DIST_GENERIC");
+  if (!generic || !*generic || *generic == '0') return run_sharded_fast(d, tr, n_local, max_steps, first_merged, left, right, count, n_done);
   std::vector<StepLog> hlog(kMaxRunSteps);
   uint32_t done = 0;
   bool exhausted = false;

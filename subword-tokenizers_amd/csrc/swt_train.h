@@ -109,6 +109,24 @@ struct TiedPlan {
   uint32_t kind, want;
 };
 
+// Sharded fast path (swt_dist.hip): what one rank tells the others about the tie scan of a step -- its (at most kMaxBatch)
+// earliest tied pairs INSIDE the window every one of its workgroups scanned, with the neighbour evidence that can clear a
+// "dangerous" pair, and the earliest tied occurrence anywhere in its shard.  One fixed-size all-gather per step.
+struct TieEntry {
+  unsigned long long pos, key;  // word << 32 | offset in this shard; the pair
+  uint32_t nb_lo[2], nb_hi[2];  // smallest / largest left [0] and right [1] neighbour seen of the pair's occurrences
+  uint32_t danger, pad;         // dangerous by the symbol sets of the tied pairs (the same answer on every rank)
+};
+struct TieMsg {
+  unsigned long long win_end;   // the window's end (word << 32)
+  unsigned long long min_pos;   // earliest tied occurrence in this shard (kEmptyKey: none; the scan goes on past the window
+  unsigned long long min_key;   //   until it has one) and its pair.  Untied step: min_pos = kEmptyKey, min_key = THE pair
+  uint32_t n;                   // entries
+  uint32_t exhausted;           // the window reached the end of the shard, or the shard holds no tied pair at all: what this
+                                // rank reports is everything it has
+  TieEntry e[kMaxBatch];
+};
+
 // everything a training kernel needs, by value
 struct TrainCtx {
   PairTable T;
@@ -138,6 +156,11 @@ struct TrainCtx {
   long long *pend;         // sharded: per-slot pending deltas (nullptr: deltas go straight into cnt)
   uint32_t *tstamp, *touched;
   uint64_t touched_cap;
+  // sharded fast path
+  const unsigned int *halt_ext;  // an exchange block overflowed somewhere: steps are no-ops until the host has repeated it
+  TieMsg *tie_msg;               // this rank's message of the step
+  const TieMsg *tie_all;         // every rank's, in rank order (after the all-gather)
+  uint32_t world, rank;
 };
 
 }  // namespace swt
@@ -205,6 +228,8 @@ struct swt_bpe_trainer {
   swt::DeltaRec *d_block = nullptr, *d_blocks_all = nullptr;
   unsigned long long *d_tie_line = nullptr, *d_tie_all = nullptr;
   unsigned int *d_halt = nullptr;
+  swt::TieMsg *d_tie_msg = nullptr, *d_tie_msgs = nullptr;  // fast path: this rank's message, all ranks' messages
+  uint32_t rank = 0;
   swt::DevBuf tmp;
   std::vector<swt::StepLog> trace;  // every merge so far (swt_bpe_train_trace)
 
@@ -233,4 +258,11 @@ void trainer_enqueue_tie_send(swt_bpe_trainer *t);
 void trainer_enqueue_decide_apply(swt_bpe_trainer *t, uint32_t rank, uint32_t log_i, uint32_t merged);
 void trainer_enqueue_pack(swt_bpe_trainer *t);
 void trainer_enqueue_add_blocks(swt_bpe_trainer *t);
+// the fast two-launch step, sharded (several tied merges per step; see fast_apply_sharded_kernel)
+struct ShardTrip { uint32_t steps, cap; bool replan_first, fast; };
+int trainer_fast_room(swt_bpe_trainer *t, uint32_t remaining, double per_step, ShardTrip *trip);  // head room, wants a re-plan?
+int trainer_fast_plan(swt_bpe_trainer *t, uint32_t remaining, double per_step, bool replan, uint32_t first_id, ShardTrip *trip);
+int trainer_fast_begin(swt_bpe_trainer *t);
+void trainer_enqueue_fast_tie(swt_bpe_trainer *t, uint32_t limit);
+void trainer_enqueue_fast_apply(swt_bpe_trainer *t, uint32_t first_merged, uint32_t limit);
 }  // namespace swt

@@ -416,3 +416,20 @@ def test_headline_corpus_training_every_merge(swt, dev, oracle_jobs, synth, gold
         assert [list(m) for m in tok.merges_list[a:a + len(w["merges"])]] == w["merges"], a
     tok.reset()
 
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_headline_corpus_sharded_fast_path(swt, dev, oracle_jobs, synth, world):
+    """the sharded runner at the headline size: S85k-open cut into `world` contiguous sentence ranges, every shard a trainer of
+    this process (loop-back communicator: the same kernels and the same exchange protocol as over RCCL, device copies for the
+    collectives), to vocab 8,000 -- all 7,922 merges, batches of tied merges ordered by first occurrence over (rank, word,
+    offset), against the oracle's unsharded run (bpe.py:88-111)."""
+    from subword_tokenizers_amd.distributed import train_sharded_loopback
+
+    want = [tuple(m) for m in oracle_jobs["open"].result().merges_list]
+    merges, stats = train_sharded_loopback(synth.s85k_open(), 8000, world)
+    bad = next((i for i, (a, b) in enumerate(zip(merges, want)) if a != b), None)
+    assert bad is None and len(merges) == len(want), (bad, len(merges), len(want))
+    assert all(not (st["flags"] & 1) for st in stats)
+    # several merges per step: the fast path ran (one merge per step would need 7,922 steps)
+    assert stats[0]["steps"] < 6000, stats[0]
+
