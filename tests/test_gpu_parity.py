@@ -797,6 +797,38 @@ def test_pack_and_lower_by_separator_and_by_code_points(dev, corpora):
         assert text.tobytes() == b"".join(want)
 
 
+def test_joined_text_with_too_few_separators_is_rejected(dev, swt, ref_dir):
+    """include/swt.h: "SWT_ERR_INVALID when the separators do not add up".  The joined text holds 2 separators, the caller
+    announces 2,000 sentences: the output buffer is 1,997 bytes SHORTER than what the split would write if it trusted the
+    announcement (round 2 wrote past it: the mismatch only had to exceed the 64-byte pad).  Every entry point that takes the
+    joined form must refuse, and the handle must stay usable."""
+    import ctypes as C
+
+    N = dev
+    parts = [b"a" * 9000, b"b" * 9000, b"c" * 9000]
+    joined = np.frombuffer(b"\x00".join(parts), dtype=np.uint8).copy()
+    n_claim = 2000
+    out = np.zeros(joined.size, dtype=np.uint8)
+    off = np.zeros(n_claim + 1, dtype=np.uint64)
+    need = np.zeros(n_claim, dtype=np.uint8)
+    rc = N.lib().swt_utf8_prepare_joined(N.ptr(joined, N.u8p), int(joined.size), n_claim, N.ptr(out, N.u8p), N.ptr(off, N.u64p), N.ptr(need, N.u8p))
+    assert rc == N.ERR_INVALID and b"separators" in N.lib().swt_last_error()
+    bpe = swt.FastBPE()
+    bpe.load_resources(os.path.join(ref_dir, "resources", "pretrained", "FastBPE"))
+    with pytest.raises(N.SwtError) as e:
+        bpe._ensure_table().encode_joined(joined, n_claim)
+    assert e.value.code == N.ERR_INVALID
+    h = C.c_void_p()
+    rc = N.lib().swt_bpe_train_create_joined(N.ptr(joined, N.u8p), int(joined.size), n_claim, N.ptr(need, N.u8p), C.byref(h))
+    assert rc == N.ERR_INVALID and not h.value
+    # more separators than announced is refused as well, and a correct call still works afterwards
+    many = np.frombuffer(b"\x00".join([b"x y"] * 500), dtype=np.uint8).copy()
+    rc = N.lib().swt_utf8_prepare_joined(N.ptr(many, N.u8p), int(many.size), 100, N.ptr(out, N.u8p), N.ptr(off, N.u64p), N.ptr(need, N.u8p))
+    assert rc == N.ERR_INVALID
+    ids, ooff = bpe.encode_ids_batch(["Ala ma kota"] * 100)
+    assert ooff.size == 101 and ids.size == 100 * (int(ooff[1]))
+
+
 def _wp_order_cases(golden, ref_dir):
     import json
     for c in golden("wp_train_order.json"):
