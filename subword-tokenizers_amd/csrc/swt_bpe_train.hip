@@ -1108,6 +1108,96 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
   }
 }
 
+// ---- wordpiece.py:92 tie-break through the inverted index -----------------------------------------------------------------
+// A WordPiece score moves whenever a symbol frequency does, so the plateau cursor of the BPE scan does not hold and
+// tie_kernel had to read the stream from word 0 at every tied step: ~0.5 MB and ~25 us per merge on S85k-lex, most of the
+// step.  But the tied pairs are few, and the index knows the words of each: the waves go through the list of live pairs once
+// more (its mirror is complete: wp_list_argmax_kernel ran), and a wave that meets a pair holding the maximum looks its words
+// up (k0 list or log segment, as an apply would), finds the pair's first position in each and keeps the minimum -- the same
+// best_pos the stream scan leaves.  An index that was abandoned (kFlagIndexBroken) falls back to that scan, in this kernel.
+__global__ __launch_bounds__(kTrainThreads) void wp_tie_index_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
+                                                                     uint64_t n_words, TrainCtx C, const ArgPart *__restrict__ parts,
+                                                                     uint32_t n_parts) {
+  __shared__ unsigned long long s_mx, s_tied;
+  if (threadIdx.x < 64) {
+    unsigned long long m, c, k;
+    arg_collect(parts, n_parts, m, c, k);
+    if (threadIdx.x == 0) { s_mx = m; s_tied = c; }
+  }
+  __syncthreads();
+  if (s_tied < 2 || s_mx == 0) return;
+  if (cand_dry(C, s_mx)) return;  // decide_kernel reports it
+  const unsigned long long mx = s_mx;
+  TrainState *st = C.st;
+  if (st->flags & kFlagIndexBroken) {  // the stream scan of tie_kernel
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+      if ((w << 32) >= __hip_atomic_load(&st->best_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      const uint64_t b0 = woff[w], b1 = woff[w + 1];
+      uint32_t a = kHole;
+      uint64_t ai = 0;
+      for (uint64_t i = b0; i < b1; i++) {
+        const uint32_t b = sym[i];
+        if (b == kHole) continue;
+        if (a != kHole) {
+          const unsigned long long key = pair_key(a, b);
+          if (pair_value(key, table_get(C.T, key), C.sfreq) == mx) {
+            atomicMin(&st->best_pos, (unsigned long long)((w << 32) | (ai - b0)));
+            break;
+          }
+        }
+        a = b;
+        ai = i;
+      }
+    }
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  unsigned long long n = st->n_cand;
+  if (n > C.cand_cap) n = C.cand_cap;
+  const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+  const uint64_t gw = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  for (uint64_t base = gw * 64; base < n; base += n_waves * 64) {
+    const uint64_t i = base + lane;
+    unsigned long long key = kEmptyKey;
+    bool hit = false;
+    if (i < n) {
+      const long long v = C.ccnt[i];
+      key = C.ckey[i];
+      hit = v > 0 && key != kEmptyKey && pair_value(key, v, C.sfreq) == mx;
+    }
+    unsigned long long H = __ballot(hit);
+    while (H) {  // one tied pair at a time, the whole wave on its word list
+      const int src = __builtin_ctzll(H);
+      H &= H - 1ull;
+      const unsigned long long k = __shfl(key, src);
+      const uint32_t l = (uint32_t)(k >> 32), r = (uint32_t)k;
+      const TiedPlan t = plan_lookup(C, l, r);
+      if (!t.kind) continue;
+      const uint32_t *list = t.kind == 2 ? C.idx_word + t.start : C.K.words + t.start;
+      const uint32_t *tags = t.kind == 2 ? C.idx_tag + t.start : nullptr;
+      for (uint64_t e = lane; e < t.n_ent; e += 64) {
+        if (tags && tags[e] != t.want) continue;
+        const uint64_t w = list[e];
+        if (w >= n_words) continue;
+        if ((w << 32) >= __hip_atomic_load(&st->best_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;  // a later word cannot win
+        const uint64_t b0 = woff[w], b1 = woff[w + 1];
+        uint32_t a = kHole;
+        uint64_t ai = 0;
+        for (uint64_t j = b0; j < b1; j++) {
+          const uint32_t b = sym[j];
+          if (b == kHole) continue;
+          if (a == l && b == r) {
+            atomicMin(&st->best_pos, (unsigned long long)((w << 32) | (ai - b0)));
+            break;
+          }
+          a = b;
+          ai = j;
+        }
+      }
+    }
+  }
+}
+
 // a plan of one pair (every path but the fast one)
 __device__ __forceinline__ void plan_single(const TrainCtx &C, BatchPlan &P, uint32_t l, uint32_t r, uint32_t m) {
   if (threadIdx.x == 0) {
@@ -2739,7 +2829,10 @@ void swt_bpe_trainer::enqueue_argmax() {
     n_parts = grid_for(cap, 256 * 8, kArgParts);
     hipLaunchKernelGGL(argmax_full_kernel, dim3(n_parts), dim3(256), 0, stream, T.keys, T.cnt, cap, d_parts, (const long long *)d_sfreq);
   }
-  if (n_words)
+  if (!n_words) return;
+  if (theta && d_sfreq)  // WordPiece: the tied pairs' first positions through the index (stream scan inside, if the index is void)
+    hipLaunchKernelGGL(wp_tie_index_kernel, dim3(64), dim3(kTrainThreads), 0, stream, d_sym, d_woff, n_words, C, d_parts, n_parts);
+  else
     hipLaunchKernelGGL(tie_kernel, dim3(grid_for(n_words, kTrainThreads, kTieBlocks)), dim3(kTrainThreads), 0, stream, d_sym, d_woff,
                        n_words, C, d_parts, n_parts);
 }

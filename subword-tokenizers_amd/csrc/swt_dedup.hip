@@ -5,8 +5,14 @@ namespace swt {
 
 constexpr uint8_t kClsWs = SWT_CLS_BERT_WS, kClsPunct = SWT_CLS_BERT_PUNCT, kClsPySpace = SWT_CLS_PY_SPACE;
 constexpr int kClsLds = 1024;  // code points whose class is served from LDS (64 lanes x 16 B)
-constexpr int kDTile = 1024;
-constexpr int kDCap = 1536;  // staged bytes per chunk: a 1-KiB tile's span plus the end of its last sentence fits; with 2048 the LDS
+#ifndef SWT_DTILE
+#define SWT_DTILE 1024
+#endif
+#ifndef SWT_DCAP
+#define SWT_DCAP 1536
+#endif
+constexpr int kDTile = SWT_DTILE;  // (build parameters: tools/gpu_dd_sweep.sh)
+constexpr int kDCap = SWT_DCAP;  // staged bytes per chunk: a 1-KiB tile's span plus the end of its last sentence fits; with 2048 the LDS
                              // (8.1 KB) left 4.9 waves per SIMD and the waves waited 57 % of their cycles -- 1536 (6.2 KB, 6.4
                              // waves per SIMD) made wordref 16 % faster on the 141 MB FastWP batch
 constexpr int kDBlocks = kDCap / 64;
