@@ -545,6 +545,7 @@ __device__ __forceinline__ unsigned long long pair_at(const uint32_t *__restrict
 __device__ __forceinline__ void open_step(const TrainCtx &C, uint32_t merged, bool valid) {
   TrainState *st = C.st;
   C.seg_start[C.step] = st->idx_cursor;
+  st->last_open = C.step;
   if (st->idx_cursor > C.idx_cap) st->flags |= kFlagIndexBroken;  // entries were dropped: whole-stream applies from here on
   if (!valid) return;
   if (merged >= C.id_base && merged - C.id_base < C.seg_cap && C.seg_of[merged - C.id_base] == 0) C.seg_of[merged - C.id_base] = C.step;
@@ -1171,8 +1172,19 @@ __global__ __launch_bounds__(kTrainThreads) void wp_tie_index_kernel(const uint3
       H &= H - 1ull;
       const unsigned long long k = __shfl(key, src);
       const uint32_t l = (uint32_t)(k >> 32), r = (uint32_t)k;
-      const TiedPlan t = plan_lookup(C, l, r);
+      TiedPlan t = plan_lookup(C, l, r);
       if (!t.kind) continue;
+      if (t.kind == 2) {
+        // This launch runs BEFORE the step's decide kernel opens the step's segment: seg_start[] is written up to last_open
+        // only, and the newest segment ends where the log stands (no apply is in flight).  (Reading seg_start[seg + 1] here
+        // took a stale 0 for the end of the previous step's segment -- a list "length" of 2^64 - start, and a GPU memory
+        // fault on its first GPU run: gpurun_out/r03b_pytest.log.)
+        const uint32_t sl = seg_of_symbol(C, l), sr = seg_of_symbol(C, r);
+        const uint32_t seg = sl > sr ? sl : sr;
+        const unsigned long long end = seg >= st->last_open ? st->idx_cursor : C.seg_start[seg + 1];
+        t.n_ent = end > t.start ? end - t.start : 0ull;
+        if (t.start + t.n_ent > C.idx_cap) t.n_ent = t.start < C.idx_cap ? C.idx_cap - t.start : 0ull;  // (entries past the log were dropped)
+      }
       const uint32_t *list = t.kind == 2 ? C.idx_word + t.start : C.K.words + t.start;
       const uint32_t *tags = t.kind == 2 ? C.idx_tag + t.start : nullptr;
       for (uint64_t e = lane; e < t.n_ent; e += 64) {

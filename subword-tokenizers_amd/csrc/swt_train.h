@@ -64,6 +64,8 @@ struct TrainState {
   // what the merge steps have looked at so far (bench.py's bytes-per-merge model; one lane adds, launches are serial)
   unsigned long long ent_scanned;  // index entries the apply launches went through
   unsigned long long tie_words;    // words the tie scans' first trips covered
+  unsigned long long last_open;    // the last step whose index segment has been opened (seg_start[] is written up to here): a
+                                   // segment at or after it ends where the log stands, not at seg_start[seg + 1]
 };
 
 struct StepCmd {
