@@ -1109,52 +1109,13 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ sym, const uin
   }
 }
 
-// ---- wordpiece.py:92 tie-break through the inverted index -----------------------------------------------------------------
-// A WordPiece score moves whenever a symbol frequency does, so the plateau cursor of the BPE scan does not hold and
-// tie_kernel had to read the stream from word 0 at every tied step: ~0.5 MB and ~25 us per merge on S85k-lex, most of the
-// step.  But the tied pairs are few, and the index knows the words of each: the waves go through the list of live pairs once
-// more (its mirror is complete: wp_list_argmax_kernel ran), and a wave that meets a pair holding the maximum looks its words
-// up (k0 list or log segment, as an apply would), finds the pair's first position in each and keeps the minimum -- the same
-// best_pos the stream scan leaves.  An index that was abandoned (kFlagIndexBroken) falls back to that scan, in this kernel.
-__global__ __launch_bounds__(kTrainThreads) void wp_tie_index_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
-                                                                     uint64_t n_words, TrainCtx C, const ArgPart *__restrict__ parts,
-                                                                     uint32_t n_parts) {
-  __shared__ unsigned long long s_mx, s_tied;
-  if (threadIdx.x < 64) {
-    unsigned long long m, c, k;
-    arg_collect(parts, n_parts, m, c, k);
-    if (threadIdx.x == 0) { s_mx = m; s_tied = c; }
-  }
-  __syncthreads();
-  if (s_tied < 2 || s_mx == 0) return;
-  if (cand_dry(C, s_mx)) return;  // decide_kernel reports it
-  const unsigned long long mx = s_mx;
+// The tied pairs' first positions through the index: the waves of the launch share the list of live pairs; a wave that meets
+// a pair whose score is `mx` goes through that pair's words.  Entries below n_mirrored are read from the mirror, the others
+// from the table (wp_step_kernel calls this before the step's new candidates are mirrored).
+__device__ __forceinline__ void wp_tie_by_index(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff, uint64_t n_words,
+                                                const TrainCtx &C, unsigned long long mx, unsigned long long n, unsigned long long n_mirrored) {
   TrainState *st = C.st;
-  if (st->flags & kFlagIndexBroken) {  // the stream scan of tie_kernel
-    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
-      if ((w << 32) >= __hip_atomic_load(&st->best_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-      const uint64_t b0 = woff[w], b1 = woff[w + 1];
-      uint32_t a = kHole;
-      uint64_t ai = 0;
-      for (uint64_t i = b0; i < b1; i++) {
-        const uint32_t b = sym[i];
-        if (b == kHole) continue;
-        if (a != kHole) {
-          const unsigned long long key = pair_key(a, b);
-          if (pair_value(key, table_get(C.T, key), C.sfreq) == mx) {
-            atomicMin(&st->best_pos, (unsigned long long)((w << 32) | (ai - b0)));
-            break;
-          }
-        }
-        a = b;
-        ai = i;
-      }
-    }
-    return;
-  }
   const int lane = threadIdx.x & 63;
-  unsigned long long n = st->n_cand;
-  if (n > C.cand_cap) n = C.cand_cap;
   const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
   const uint64_t gw = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   for (uint64_t base = gw * 64; base < n; base += n_waves * 64) {
@@ -1162,8 +1123,9 @@ __global__ __launch_bounds__(kTrainThreads) void wp_tie_index_kernel(const uint3
     unsigned long long key = kEmptyKey;
     bool hit = false;
     if (i < n) {
-      const long long v = C.ccnt[i];
-      key = C.ckey[i];
+      long long v;
+      if (i < n_mirrored) { v = C.ccnt[i]; key = C.ckey[i]; }
+      else { const uint32_t slot = C.cand[i]; v = C.T.cnt[slot]; key = C.T.keys[slot]; }
       hit = v > 0 && key != kEmptyKey && pair_value(key, v, C.sfreq) == mx;
     }
     unsigned long long H = __ballot(hit);
@@ -1208,6 +1170,54 @@ __global__ __launch_bounds__(kTrainThreads) void wp_tie_index_kernel(const uint3
       }
     }
   }
+}
+
+// ---- wordpiece.py:92 tie-break through the inverted index -----------------------------------------------------------------
+// A WordPiece score moves whenever a symbol frequency does, so the plateau cursor of the BPE scan does not hold and
+// tie_kernel had to read the stream from word 0 at every tied step: ~0.5 MB and ~25 us per merge on S85k-lex, most of the
+// step.  But the tied pairs are few, and the index knows the words of each: the waves go through the list of live pairs once
+// more (its mirror is complete: wp_list_argmax_kernel ran), and a wave that meets a pair holding the maximum looks its words
+// up (k0 list or log segment, as an apply would), finds the pair's first position in each and keeps the minimum -- the same
+// best_pos the stream scan leaves.  An index that was abandoned (kFlagIndexBroken) falls back to that scan, in this kernel.
+__global__ __launch_bounds__(kTrainThreads) void wp_tie_index_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
+                                                                     uint64_t n_words, TrainCtx C, const ArgPart *__restrict__ parts,
+                                                                     uint32_t n_parts) {
+  __shared__ unsigned long long s_mx, s_tied;
+  if (threadIdx.x < 64) {
+    unsigned long long m, c, k;
+    arg_collect(parts, n_parts, m, c, k);
+    if (threadIdx.x == 0) { s_mx = m; s_tied = c; }
+  }
+  __syncthreads();
+  if (s_tied < 2 || s_mx == 0) return;
+  if (cand_dry(C, s_mx)) return;  // decide_kernel reports it
+  const unsigned long long mx = s_mx;
+  TrainState *st = C.st;
+  if (st->flags & kFlagIndexBroken) {  // the stream scan of tie_kernel
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+      if ((w << 32) >= __hip_atomic_load(&st->best_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      const uint64_t b0 = woff[w], b1 = woff[w + 1];
+      uint32_t a = kHole;
+      uint64_t ai = 0;
+      for (uint64_t i = b0; i < b1; i++) {
+        const uint32_t b = sym[i];
+        if (b == kHole) continue;
+        if (a != kHole) {
+          const unsigned long long key = pair_key(a, b);
+          if (pair_value(key, table_get(C.T, key), C.sfreq) == mx) {
+            atomicMin(&st->best_pos, (unsigned long long)((w << 32) | (ai - b0)));
+            break;
+          }
+        }
+        a = b;
+        ai = i;
+      }
+    }
+    return;
+  }
+  unsigned long long n = st->n_cand;
+  if (n > C.cand_cap) n = C.cand_cap;
+  wp_tie_by_index(sym, woff, n_words, C, mx, n, n);
 }
 
 // a plan of one pair (every path but the fast one)
@@ -2121,6 +2131,107 @@ __global__ __launch_bounds__(kTrainThreads) void fast_apply_sharded_kernel(uint3
   apply_body(sym, woff, freq, n_words, C, P);
 }
 
+// ---- WordPiece: argmax + tie-break + decision in ONE launch ----------------------------------------------------------------
+// The generic step costs four launches (argmax, tie, decide, apply) and what a WordPiece merge costs on the device IS its
+// launches: ~8 us each, the work inside them is small (S85k-lex: ~2,400 live pairs, a few dozen words per merge).  While the
+// list of live pairs is short (kWpStepList), every workgroup takes the maximum score over it by itself -- as fast_tie_kernel
+// does for BPE -- the waves share the tied pairs' index lookups (wp_tie_by_index), and the workgroup that finishes LAST (a
+// ticket) reads the final first position and does what decide_kernel does: the merge command for apply_kernel, the log line,
+// the step's index segment, the symbol frequencies.  No apply is in flight during this launch, so the stream, the counts and
+// the frequencies stand still.  Two launches per merge instead of four.
+__global__ __launch_bounds__(kTrainThreads) void wp_step_kernel(const uint32_t *__restrict__ sym, const uint64_t *__restrict__ woff,
+                                                                uint64_t n_words, TrainCtx C, StepCmd *cmd, StepLog *log, uint32_t log_i,
+                                                                uint32_t merged) {
+  TrainState *st = C.st;
+  __shared__ unsigned int s_last;
+  const unsigned long long n_all = st->n_cand;
+  const unsigned long long n = n_all < C.cand_cap ? n_all : C.cand_cap;
+  const unsigned long long n_synced = st->n_synced < n ? st->n_synced : n;
+  const unsigned int flags = st->flags;
+  unsigned long long m = 0, c = 0, k = kEmptyKey;
+  for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    long long v;
+    unsigned long long key;
+    if (i < n_synced) { v = C.ccnt[i]; key = C.ckey[i]; }
+    else {
+      const uint32_t slot = C.cand[i];
+      v = C.T.cnt[slot];
+      key = C.T.keys[slot];
+      if (blockIdx.x == 0) {  // the pairs the last merge made get their mirror (the others read them from the table meanwhile)
+        C.ccnt[i] = v;
+        C.ckey[i] = key;
+        C.cidx[slot] = (uint32_t)i;
+      }
+    }
+    if (v > 0 && key != kEmptyKey) {
+      const unsigned long long val = pair_value(key, v, C.sfreq);
+      if (val >= m) arg_combine(m, c, k, val, 1ull, key);
+    }
+  }
+  const BlockArg a = block_reduce(m, c, k);
+  const bool dry = (flags & kFlagReplan) || n_all > C.cand_cap;  // cand_dry at theta 1: the list lost a pair, or was voided
+  if (!dry && a.mx && a.tied >= 2) {
+    if (flags & kFlagIndexBroken) {  // no index: the stream scan (tie_kernel)
+      for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        if ((w << 32) >= __hip_atomic_load(&st->best_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        const uint64_t b0 = woff[w], b1 = woff[w + 1];
+        uint32_t x = kHole;
+        uint64_t xi = 0;
+        for (uint64_t i = b0; i < b1; i++) {
+          const uint32_t y = sym[i];
+          if (y == kHole) continue;
+          if (x != kHole) {
+            const unsigned long long key = pair_key(x, y);
+            if (pair_value(key, table_get(C.T, key), C.sfreq) == a.mx) {
+              atomicMin(&st->best_pos, (unsigned long long)((w << 32) | (xi - b0)));
+              break;
+            }
+          }
+          x = y;
+          xi = i;
+        }
+      }
+    } else {
+      wp_tie_by_index(sym, woff, n_words, C, a.mx, n, n_synced);
+    }
+  }
+  // ---- the last workgroup to get here decides
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(&st->ticket, 1ull) == (unsigned long long)gridDim.x - 1ull ? 1u : 0u;
+  __syncthreads();
+  if (!s_last || threadIdx.x != 0) return;
+  __threadfence();
+  st->ticket = 0;
+  unsigned long long key = a.key, pos = kEmptyKey;
+  if (!dry && a.mx && a.tied >= 2) {
+    pos = __hip_atomic_load(&st->best_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    key = pos != kEmptyKey ? pair_at(sym, woff, pos) : kEmptyKey;
+  }
+  st->max_count = dry ? 0 : a.mx;
+  st->n_tied = (dry || !a.mx) ? 0 : a.tied;
+  st->best_key = key;
+  st->win_key = key;
+  st->res_pos = pos;
+  st->best_pos = kEmptyKey;
+  if (dry) st->flags |= kFlagReplan;
+  st->n_synced = n;
+  const bool ok = !dry && a.mx > 0 && key != kEmptyKey;
+  cmd->l = (uint32_t)(key >> 32);
+  cmd->r = (uint32_t)key;
+  cmd->m = merged;
+  cmd->valid = ok ? 1u : 0u;
+  open_step(C, merged, ok);
+  if (ok) wp_move_freq(C.T, cmd->l, cmd->r, merged, C.sfreq);
+  log[log_i].l = cmd->l;
+  log[log_i].r = cmd->r;
+  log[log_i].count = a.mx;
+  log[log_i].flag = ok ? 0ull : (dry ? 3ull : 2ull);
+  log[log_i].n_syms = st->n_syms;
+  log[log_i].n_tied = a.tied;
+  log[log_i].n_cand = n_all;
+}
+
 // ---- candidates --------------------------------------------------------------------------------------------------------
 // histogram of the live counts over 8 sub-buckets per octave: the host picks theta so that ~kCandTarget pairs pass it
 __device__ __forceinline__ uint32_t count_bucket(unsigned long long c) {
@@ -2574,6 +2685,7 @@ int swt_bpe_trainer::replan() {
     }
     theta = 1;
     cand_built = live;
+    h_st.n_cand = live;  // (the host's copy is from before the build: the fused step is chosen by the list's length)
     since_replan = 0;
     cand_valid = true;
     hipLaunchKernelGGL(cand_build_kernel, dim3(grid_for(cap, 256, 2048)), dim3(256), 0, stream, ctx(), cap);
@@ -3226,11 +3338,20 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
       SWT_HIP(hipMemsetAsync(t->d_gnb_min, 0xFF, 4 * (size_t)t->cand_cap * 4, t->stream));
       SWT_HIP(hipMemsetAsync(t->d_gnb_max, 0, 4 * (size_t)t->cand_cap * 4, t->stream));
     }
+    // (the list may grow past the limit within the trip: the kernel's loops are strided, only slower then)
+    const bool wp_fused = t->d_sfreq && t->theta && t->n_words && t->h_st.n_cand <= kWpStepList && !getenv("SWT_WP_GENERIC");
     prof_begin(t->stream);  // one bracket around the whole batch of merge steps: bench.py divides by the merges done
     for (uint32_t i = 0; i < steps; i++) {
       t->step_no++;
       if (fast) {
         t->enqueue_fast_step(first_merged + done, cap);
+        continue;
+      }
+      if (wp_fused) {  // WordPiece, a short list: argmax + tie-break + decision in one launch
+        hipLaunchKernelGGL(wp_step_kernel, dim3(kWpStepBlocks), dim3(kTrainThreads), 0, t->stream, t->d_sym, t->d_woff, t->n_words, t->ctx(),
+                           t->d_cmd, t->d_steplog, i, first_merged + done + i);
+        hipLaunchKernelGGL(apply_kernel, dim3(kFastApplyBlocks), dim3(kTrainThreads), 0, t->stream, t->d_sym, t->d_woff, t->d_freq, t->n_words,
+                           t->ctx(), t->d_cmd);
         continue;
       }
       t->enqueue_argmax();

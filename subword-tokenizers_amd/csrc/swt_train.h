@@ -22,6 +22,8 @@ constexpr uint32_t kTieSet = 256;       // tied pairs a workgroup keeps in its L
 #endif
 constexpr uint32_t kTieBlocks = SWT_TIE_BLOCKS;
 constexpr uint32_t kApplyBlocks = 512;
+constexpr uint32_t kWpStepBlocks = 32;     // wp_step_kernel: every workgroup takes the argmax of the list itself
+constexpr uint32_t kWpStepList = 16384;    // ... which pays while the list of live pairs is at most this long
 #ifndef SWT_APPLY_BLOCKS
 #define SWT_APPLY_BLOCKS 128
 #endif
@@ -66,6 +68,7 @@ struct TrainState {
   unsigned long long tie_words;    // words the tie scans' first trips covered
   unsigned long long last_open;    // the last step whose index segment has been opened (seg_start[] is written up to here): a
                                    // segment at or after it ends where the log stands, not at seg_start[seg + 1]
+  unsigned long long ticket;       // wp_step_kernel: workgroups that have finished (the last one decides the step)
 };
 
 struct StepCmd {
