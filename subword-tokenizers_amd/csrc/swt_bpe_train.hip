@@ -44,6 +44,7 @@
 // record block, all-gathers the blocks (RCCL) and every rank adds every block to its replica.
 #include <algorithm>
 #include <cstdlib>
+#include <ctime>
 #include <rocprim/device/device_scan.hpp>
 
 #include "swt_common.h"
@@ -2149,23 +2150,42 @@ __global__ __launch_bounds__(kTrainThreads) void wp_step_kernel(const uint32_t *
   const unsigned long long n_synced = st->n_synced < n ? st->n_synced : n;
   const unsigned int flags = st->flags;
   unsigned long long m = 0, c = 0, k = kEmptyKey;
-  for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
-    long long v;
-    unsigned long long key;
-    if (i < n_synced) { v = C.ccnt[i]; key = C.ckey[i]; }
-    else {
-      const uint32_t slot = C.cand[i];
-      v = C.T.cnt[slot];
-      key = C.T.keys[slot];
-      if (blockIdx.x == 0) {  // the pairs the last merge made get their mirror (the others read them from the table meanwhile)
-        C.ccnt[i] = v;
-        C.ckey[i] = key;
-        C.cidx[slot] = (uint32_t)i;
+  // eight entries per lane and trip, each stage's loads in flight together: counts + keys (two coalesced streams), then the
+  // two symbol frequencies of every pair (gathers), then the divisions.  Entry by entry this loop was a chain of dependent L2
+  // round trips -- most of what the launch cost.
+  constexpr int kU = 8;
+  for (uint64_t i0 = threadIdx.x; i0 < n; i0 += (uint64_t)blockDim.x * kU) {
+    long long v[kU], fl[kU], fr[kU];
+    unsigned long long key[kU];
+    uint32_t slot[kU];
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      const uint64_t i = i0 + (uint64_t)u * blockDim.x;
+      v[u] = 0; key[u] = kEmptyKey; slot[u] = 0xFFFFFFFFu;
+      if (i < n_synced) { v[u] = C.ccnt[i]; key[u] = C.ckey[i]; }
+      else if (i < n) slot[u] = C.cand[i];
+    }
+#pragma unroll
+    for (int u = 0; u < kU; u++)
+      if (slot[u] != 0xFFFFFFFFu) { v[u] = C.T.cnt[slot[u]]; key[u] = C.T.keys[slot[u]]; }
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      const bool on = v[u] > 0 && key[u] != kEmptyKey;
+      fl[u] = on ? C.sfreq[key[u] >> 32] : 0;
+      fr[u] = on ? C.sfreq[(uint32_t)key[u]] : 0;
+      if (slot[u] != 0xFFFFFFFFu && blockIdx.x == 0) {  // the pairs the last merge made get their mirror (the others read them from the table meanwhile)
+        const uint64_t i = i0 + (uint64_t)u * blockDim.x;
+        C.ccnt[i] = v[u];
+        C.ckey[i] = key[u];
+        C.cidx[slot[u]] = (uint32_t)i;
       }
     }
-    if (v > 0 && key != kEmptyKey) {
-      const unsigned long long val = pair_value(key, v, C.sfreq);
-      if (val >= m) arg_combine(m, c, k, val, 1ull, key);
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      if (v[u] > 0 && key[u] != kEmptyKey) {
+        const unsigned long long val = wp_score_bits((unsigned long long)v[u], (unsigned long long)fl[u], (unsigned long long)fr[u]);
+        if (val >= m) arg_combine(m, c, k, val, 1ull, key[u]);
+      }
     }
   }
   const BlockArg a = block_reduce(m, c, k);
@@ -2440,6 +2460,12 @@ __global__ __launch_bounds__(64) void decide_sharded_kernel(TrainCtx C, const Ar
 }  // namespace swt
 
 using namespace swt;
+
+static double host_now() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 static unsigned grid_for(uint64_t n, int threads, unsigned cap = 1u << 20) {
   uint64_t g = (n + threads - 1) / threads;
@@ -3341,6 +3367,7 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
     // (the list may grow past the limit within the trip: the kernel's loops are strided, only slower then)
     const bool wp_fused = t->d_sfreq && t->theta && t->n_words && t->h_st.n_cand <= kWpStepList && !getenv("SWT_WP_GENERIC");
     prof_begin(t->stream);  // one bracket around the whole batch of merge steps: bench.py divides by the merges done
+    const double enq0 = getenv("SWT_TRAIN_DEBUG") ? host_now() : 0.0;
     for (uint32_t i = 0; i < steps; i++) {
       t->step_no++;
       if (fast) {
@@ -3360,6 +3387,7 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
       t->enqueue_apply();
     }
     prof_end(t->stream);
+    const double enq1 = getenv("SWT_TRAIN_DEBUG") ? host_now() : 0.0;
     SWT_HIP(hipGetLastError());
     if (cap > kMaxRunSteps) return fail(SWT_ERR_STATE, "a round trip was sized beyond the step log (%u rows)", cap);
     SWT_HIP(hipMemcpyAsync(hlog.data(), t->d_steplog, cap * sizeof(StepLog), hipMemcpyDeviceToHost, t->stream));
@@ -3385,8 +3413,8 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
       done++;
     }
     if (getenv("SWT_TRAIN_DEBUG"))
-      fprintf(stderr, "trip: steps %u cap %u -> %u merges, stop %llu, per_step %.2f, listed %llu since %llu ratio %.2f, max %llu theta %llu\n", steps, cap,
-              good, stop, per_step, (unsigned long long)t->cand_built, (unsigned long long)t->since_replan, t->dry_ratio,
+      fprintf(stderr, "trip: steps %u (host enqueue %.1f us) cap %u -> %u merges, stop %llu, per_step %.2f, listed %llu since %llu ratio %.2f, max %llu theta %llu\n", steps,
+              (enq1 - enq0) * 1e6, cap, good, stop, per_step, (unsigned long long)t->cand_built, (unsigned long long)t->since_replan, t->dry_ratio,
               (unsigned long long)(good ? hlog[good - 1].count : 0), (unsigned long long)t->theta);
     t->n_applied += good;
     t->since_replan += good;
