@@ -89,7 +89,7 @@ def build_pyhost(force=False):
     inc = sysconfig.get_paths().get("include")
     if not cc or not inc or not os.path.exists(os.path.join(inc, "Python.h")):
         return None
-    r = subprocess.run([cc, "-O2", "-Wall", "-shared", "-fPIC", "-I", inc, PYHOST_SRC, "-o", PYHOST_PATH],
+    r = subprocess.run([cc, "-O2", "-Wall", "-shared", "-fPIC", "-pthread", "-I", inc, PYHOST_SRC, "-o", PYHOST_PATH],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         return None

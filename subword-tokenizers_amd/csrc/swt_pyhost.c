@@ -109,50 +109,167 @@ __attribute__((target("ssse3"))) static uint8_t *ucs2_ssse3(const uint16_t *p, P
   return d;
 }
 
+// ---- one string: its exact UTF-8 length, and its bytes ---------------------------------------------------------------------
+static inline long long utf8_size(PyObject *o) {
+  const Py_ssize_t len = PyUnicode_GET_LENGTH(o);
+  if (PyUnicode_IS_ASCII(o)) return (long long)len;
+  const int kind = PyUnicode_KIND(o);
+  const void *data = PyUnicode_DATA(o);
+  long long n = (long long)len;
+  if (kind == PyUnicode_1BYTE_KIND) {
+    const uint8_t *p = (const uint8_t *)data;
+    for (Py_ssize_t k = 0; k < len; k++) n += p[k] >> 7;
+  } else if (kind == PyUnicode_2BYTE_KIND) {
+    const uint16_t *p = (const uint16_t *)data;
+    Py_ssize_t k = 0;
+    const __m128i zero = _mm_setzero_si128();
+    __m128i acc = zero;  // per 16-bit lane: (c >= 0x80) + (c >= 0x800), summed
+    for (; k + 8 <= len; k += 8) {
+      const __m128i x = _mm_loadu_si128((const __m128i *)(p + k));
+      const __m128i ge80 = _mm_cmpeq_epi16(_mm_and_si128(x, _mm_set1_epi16((short)0xFF80)), zero);   // 0xFFFF where c < 0x80
+      const __m128i ge800 = _mm_cmpeq_epi16(_mm_and_si128(x, _mm_set1_epi16((short)0xF800)), zero);  // 0xFFFF where c < 0x800
+      // lanes hold -1 where the test FAILS to add: count the zeros instead: 2 + ge80 + ge800 (each -1 or 0)
+      acc = _mm_add_epi16(acc, _mm_add_epi16(_mm_set1_epi16(2), _mm_add_epi16(ge80, ge800)));
+      if ((k & 0x3FF8) == 0x3FF8) {  // flush before a 16-bit lane can overflow (<= 2 per step)
+        uint16_t l[8];
+        _mm_storeu_si128((__m128i *)l, acc);
+        for (int j = 0; j < 8; j++) n += l[j];
+        acc = zero;
+      }
+    }
+    uint16_t l[8];
+    _mm_storeu_si128((__m128i *)l, acc);
+    for (int j = 0; j < 8; j++) n += l[j];
+    for (; k < len; k++) n += (p[k] >= 0x80) + (p[k] >= 0x800);
+  } else {
+    const uint32_t *p = (const uint32_t *)data;
+    for (Py_ssize_t k = 0; k < len; k++) n += (p[k] >= 0x80) + (p[k] >= 0x800) + (p[k] >= 0x10000);
+  }
+  return n;
+}
+
+static inline uint8_t *put_str(PyObject *o, uint8_t *d, int ssse3) {
+  const Py_ssize_t len = PyUnicode_GET_LENGTH(o);
+  const int kind = PyUnicode_KIND(o);
+  const void *data = PyUnicode_DATA(o);
+  if (PyUnicode_IS_ASCII(o)) {
+    memcpy(d, data, (size_t)len);
+    return d + len;
+  }
+  if (kind == PyUnicode_1BYTE_KIND) {
+    const uint8_t *p = (const uint8_t *)data;
+    for (Py_ssize_t k = 0; k < len; k++) d = put_cp(d, p[k]);
+  } else if (kind == PyUnicode_2BYTE_KIND) {
+    d = ssse3 ? ucs2_ssse3((const uint16_t *)data, len, d) : ucs2_sse2((const uint16_t *)data, len, d);
+  } else {
+    const uint32_t *p = (const uint32_t *)data;
+    for (Py_ssize_t k = 0; k < len; k++) d = put_cp(d, p[k]);
+  }
+  return d;
+}
+
+static long long count_zero_bytes(const uint8_t *q, const uint8_t *end) {
+  const __m128i zero = _mm_setzero_si128(), one = _mm_set1_epi8(1);
+  __m128i acc = zero;  // two 64-bit sums of the bytes that are zero
+  for (; q + 16 <= end; q += 16)
+    acc = _mm_add_epi64(acc, _mm_sad_epu8(_mm_and_si128(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)q), zero), one), zero));
+  uint64_t part[2];
+  _mm_storeu_si128((__m128i *)part, acc);
+  long long n = (long long)(part[0] + part[1]);
+  for (; q < end; q++) n += *q == 0;
+  return n;
+}
+
+// ---- the join over several host threads -----------------------------------------------------------------------------------
+// One core converts ~2 GB/s; the GPU side of an encode call takes the 8.5 MB of S85k in ~0.5 ms, so the join WAS the call
+// (4 ms of 6).  The strings are immutable and the caller's thread holds the GIL for the whole call (nothing else in the
+// interpreter runs), so worker threads may read the strings' buffers: two passes over contiguous ranges of the list -- exact
+// UTF-8 sizes, a prefix sum over the ranges, then every range written straight to its final place.
+#include <pthread.h>
+#include <unistd.h>
+
+typedef struct {
+  PyObject **items;
+  Py_ssize_t lo, hi;     // strings [lo, hi)
+  uint8_t *dst;          // pass 2: where this range starts
+  long long bytes;       // pass 1: out -- the range's size (separators in front of every string but the list's first)
+  long long nul;         // pass 2: out -- zero bytes written
+  int ssse3, pass;
+} JoinJob;
+
+static void *join_worker(void *arg) {
+  JoinJob *j = (JoinJob *)arg;
+  if (j->pass == 1) {
+    long long n = 0;
+    for (Py_ssize_t i = j->lo; i < j->hi; i++) n += utf8_size(j->items[i]) + (i ? 1 : 0);
+    j->bytes = n;
+  } else {
+    uint8_t *d = j->dst;
+    for (Py_ssize_t i = j->lo; i < j->hi; i++) {
+      if (i) *d++ = 0;
+      d = put_str(j->items[i], d, j->ssse3);
+    }
+    j->nul = count_zero_bytes(j->dst, d);
+  }
+  return NULL;
+}
+
+static int join_threads(Py_ssize_t n, long long bound) {
+  if (n < 4096 || bound < (1 << 20)) return 1;
+  const char *e = getenv("SWT_JOIN_THREADS");
+  long t = e && *e ? strtol(e, NULL, 10) : 0;
+  if (t <= 0) {
+    t = sysconf(_SC_NPROCESSORS_ONLN);
+    if (t > 8) t = 8;  // the copy is memory-bound well before that many cores
+  }
+  if (t > 32) t = 32;
+  return t < 1 ? 1 : (int)t;
+}
+
 // Writes the texts' UTF-8 with ONE zero byte between neighbours to dst (cap >= swt_py_join_bound + 32).  Returns the bytes written;
 // *n_nul = zero code points INSIDE the texts (the separator form needs 0).  -1: the list changed under us / cap too small.
 long long swt_py_join_fill(PyObject *list, uint8_t *dst, long long cap, long long *n_nul) {
   if (!PyList_Check(list) || !dst || !n_nul) return -1;
   const Py_ssize_t n = PyList_GET_SIZE(list);
-  uint8_t *d = dst, *const end = dst + cap;
   const int ssse3 = __builtin_cpu_supports("ssse3");
   if (ssse3 && !g_shuf_ready) shuf_init();
-  long long nul = 0;
-  for (Py_ssize_t i = 0; i < n; i++) {
-    PyObject *o = PyList_GET_ITEM(list, i);
+  PyObject **items = ((PyListObject *)list)->ob_item;
+  long long bound = n;
+  for (Py_ssize_t i = 0; i < n; i++) {  // (swt_py_join_bound has made every string ready; this is the check that the list is still that list)
+    PyObject *o = items[i];
     if (!PyUnicode_Check(o) || PyUnicode_READY(o) < 0) { PyErr_Clear(); return -1; }
-    const Py_ssize_t len = PyUnicode_GET_LENGTH(o);
-    const int kind = PyUnicode_KIND(o);
-    const void *data = PyUnicode_DATA(o);
-    if ((long long)(end - d) < (long long)len * (PyUnicode_IS_ASCII(o) ? 1 : kind == 1 ? 2 : kind == 2 ? 3 : 4) + 17) return -1;  // 16 bytes of slack: the vector stores
-    if (i) *d++ = 0;
-    if (PyUnicode_IS_ASCII(o)) {
-      memcpy(d, data, (size_t)len);
-      d += len;
-    } else if (kind == PyUnicode_1BYTE_KIND) {
-      const uint8_t *p = (const uint8_t *)data;
-      for (Py_ssize_t k = 0; k < len; k++) d = put_cp(d, p[k]);
-    } else if (kind == PyUnicode_2BYTE_KIND) {
-      d = ssse3 ? ucs2_ssse3((const uint16_t *)data, len, d) : ucs2_sse2((const uint16_t *)data, len, d);
-    } else {
-      const uint32_t *p = (const uint32_t *)data;
-      for (Py_ssize_t k = 0; k < len; k++) d = put_cp(d, p[k]);
+    const long long len = PyUnicode_GET_LENGTH(o);
+    bound += PyUnicode_IS_ASCII(o) ? len : len * (PyUnicode_KIND(o) == PyUnicode_1BYTE_KIND ? 2 : PyUnicode_KIND(o) == PyUnicode_2BYTE_KIND ? 3 : 4);
+  }
+  if (bound + 17 > cap) return -1;  // 16 bytes of slack: the vector stores
+  int T = join_threads(n, bound);
+  JoinJob job[32];
+  pthread_t th[32];
+  for (int pass = 1; pass <= 2; pass++) {
+    long long at = 0;
+    for (int t = 0; t < T; t++) {
+      job[t].items = items;
+      job[t].lo = n * t / T;
+      job[t].hi = n * (t + 1) / T;
+      job[t].ssse3 = ssse3;
+      job[t].pass = pass;
+      if (pass == 2) { job[t].dst = dst + at; at += job[t].bytes; }
     }
+    if (pass == 2 && at + 17 > cap) return -1;
+    int started = 0;
+    for (int t = 1; t < T; t++) {
+      if (pthread_create(&th[t], NULL, join_worker, &job[t]) != 0) break;
+      started = t;
+    }
+    join_worker(&job[0]);
+    for (int t = started + 1; t < T; t++) join_worker(&job[t]);  // threads that could not be had: their ranges on this one
+    for (int t = 1; t <= started; t++) pthread_join(th[t], NULL);
   }
+  long long total = 0, nul = 0;
+  for (int t = 0; t < T; t++) { total += job[t].bytes; nul += job[t].nul; }
   // a zero byte in UTF-8 is U+0000 and nothing else: what is not a separator came from inside a text
-  {
-    const __m128i zero = _mm_setzero_si128(), one = _mm_set1_epi8(1);
-    __m128i acc = zero;  // two 64-bit sums of the bytes that are zero
-    const uint8_t *q = dst;
-    for (; q + 16 <= d; q += 16)
-      acc = _mm_add_epi64(acc, _mm_sad_epu8(_mm_and_si128(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)q), zero), one), zero));
-    uint64_t part[2];
-    _mm_storeu_si128((__m128i *)part, acc);
-    nul += (long long)(part[0] + part[1]);
-    for (; q < d; q++) nul += *q == 0;
-  }
   *n_nul = nul - (n ? (long long)(n - 1) : 0);
-  return (long long)(d - dst);
+  return total;
 }
 
 // ids -> the reference's output shape, List[List[str]]: sentence s gets [table[inv[k]] for k in off[s]..off[s+1]) (new lists, the

@@ -326,6 +326,26 @@ def test_join_texts_is_join_plus_encode(native):
         joined, n_nul = native.join_texts(ts)
         data, nul = want(ts)
         assert joined.tobytes() == data and n_nul == nul, ts
+    # lists long enough for the threaded form (>= 4,096 strings and 1 MiB): every kind of string at the seams of the ranges,
+    # with 1, 3 and 8 threads, and empty strings in bulk
+    big = ["".join(rng.choice(alphabets[i % len(alphabets)]) for _ in range(rng.randrange(150, 400))) for i in range(6000)]
+    big[0] = ""
+    big[2999] = "\x00"
+    big[-1] = "ł" * 4097 + "中"
+    for threads in ("1", "3", "8"):
+        monkey_env = os.environ.get("SWT_JOIN_THREADS")
+        os.environ["SWT_JOIN_THREADS"] = threads
+        try:
+            joined, n_nul = native.join_texts(big)
+        finally:
+            if monkey_env is None:
+                del os.environ["SWT_JOIN_THREADS"]
+            else:
+                os.environ["SWT_JOIN_THREADS"] = monkey_env
+        data, nul = want(big)
+        assert joined.tobytes() == data and n_nul == nul, threads
+    joined, n_nul = native.join_texts([""] * 5000 + ["a" * (1 << 20)] + [""] * 5000)
+    assert joined.size == 10000 + (1 << 20) and n_nul == 0 and joined[5000:5000 + (1 << 20)].tobytes() == b"a" * (1 << 20)
     saved = native._pyhost
     try:
         native._pyhost = False  # the str.join + str.encode form
