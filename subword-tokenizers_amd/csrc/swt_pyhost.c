@@ -148,7 +148,11 @@ static inline long long utf8_size(PyObject *o) {
   return n;
 }
 
-static inline uint8_t *put_str(PyObject *o, uint8_t *d, int ssse3) {
+// `exact`: nothing is stored behind the string's last byte (the vector forms store whole 16-byte lanes and advance by what was
+// valid: harmless while the next string of the SAME thread overwrites the excess, fatal at the end of a thread's range, where
+// the bytes behind belong to another thread -- the first GPU-box run of the threaded join came back with one stray zero byte per
+// range boundary, which the device rightly refused: "the joined text holds 5006 separators, not n_sent - 1")
+static inline uint8_t *put_str(PyObject *o, uint8_t *d, int ssse3, int exact) {
   const Py_ssize_t len = PyUnicode_GET_LENGTH(o);
   const int kind = PyUnicode_KIND(o);
   const void *data = PyUnicode_DATA(o);
@@ -160,7 +164,12 @@ static inline uint8_t *put_str(PyObject *o, uint8_t *d, int ssse3) {
     const uint8_t *p = (const uint8_t *)data;
     for (Py_ssize_t k = 0; k < len; k++) d = put_cp(d, p[k]);
   } else if (kind == PyUnicode_2BYTE_KIND) {
-    d = ssse3 ? ucs2_ssse3((const uint16_t *)data, len, d) : ucs2_sse2((const uint16_t *)data, len, d);
+    if (exact) {
+      const uint16_t *p = (const uint16_t *)data;
+      for (Py_ssize_t k = 0; k < len; k++) d = put_cp(d, p[k]);
+    } else {
+      d = ssse3 ? ucs2_ssse3((const uint16_t *)data, len, d) : ucs2_sse2((const uint16_t *)data, len, d);
+    }
   } else {
     const uint32_t *p = (const uint32_t *)data;
     for (Py_ssize_t k = 0; k < len; k++) d = put_cp(d, p[k]);
@@ -207,7 +216,9 @@ static void *join_worker(void *arg) {
     uint8_t *d = j->dst;
     for (Py_ssize_t i = j->lo; i < j->hi; i++) {
       if (i) *d++ = 0;
-      d = put_str(j->items[i], d, j->ssse3);
+      // every string but the list's first takes at least its separator byte, so the last 17 strings of a range cover the 16
+      // bytes in front of the next range
+      d = put_str(j->items[i], d, j->ssse3, j->hi - i <= 17);
     }
     j->nul = count_zero_bytes(j->dst, d);
   }

@@ -344,6 +344,18 @@ def test_join_texts_is_join_plus_encode(native):
                 os.environ["SWT_JOIN_THREADS"] = monkey_env
         data, nul = want(big)
         assert joined.tobytes() == data and n_nul == nul, threads
+    # the seams: every string two-byte (the vector form stores 16-byte lanes) and short, so that a store of one range would
+    # reach into the next range if it were allowed to (it was, once: a stray zero byte per seam on the GPU box)
+    seam = [("ł" + "ab" * (i % 5)) for i in range(4096)] + ["x" * (1 << 20)]
+    for threads in ("2", "8", "16"):
+        os.environ["SWT_JOIN_THREADS"] = threads
+        try:
+            for _ in range(20):
+                joined, n_nul = native.join_texts(seam)
+                assert n_nul == 0 and int((joined == 0).sum()) == len(seam) - 1, threads
+        finally:
+            del os.environ["SWT_JOIN_THREADS"]
+    assert joined.tobytes() == want(seam)[0]
     joined, n_nul = native.join_texts([""] * 5000 + ["a" * (1 << 20)] + [""] * 5000)
     assert joined.size == 10000 + (1 << 20) and n_nul == 0 and joined[5000:5000 + (1 << 20)].tobytes() == b"a" * (1 << 20)
     saved = native._pyhost
