@@ -26,9 +26,20 @@ typedef uint64_t u64u __attribute__((aligned(1)));  // unaligned 8-byte access (
 // and EVERY lookup that met its tag compared the word with the representative's bytes in the text: a random 16-byte read per
 // word occurrence out of a text of 10^8 bytes -- wordref fetched 5-10x the text through the L2 (profiles/r03_wp_encode_FETCH_SIZE).
 // Now a word of at most 16 bytes (all but a few per thousand) is settled by the slot's own 32 bytes.
-// Protocol: the inserter takes the slot by CAS on meta (prefix bit clear), stores w0 / w1, then sets the bit with RELEASE; a
-// reader that sees the bit takes an ACQUIRE fence and reads the prefix; one that does not (the inserter is in between) compares
-// with the text as before.  A slot never changes within a call once its bit is set, so the comparison is exact either way.
+// Protocol (MI355X has one L2 per XCD, and they are not coherent with each other inside a kernel: only device-scope atomics
+// -- which go to the memory side -- see each other's writes at once):
+//   inserter   CAS on meta (device scope, prefix bit clear) takes the slot; w0 / w1 are stored with device-scope stores; once
+//              those are acknowledged (a wait, no cache maintenance) the prefix bit is OR-ed into meta.  A slot never changes
+//              again within the call.
+//   fast read  a PLAIN (cached) load of {meta, w0}: if that copy shows this call's epoch, the prefix bit and the wanted
+//              tag/length, the copy was fetched after the bit was set, i.e. after the prefix was complete (a cache line is
+//              filled from one state of memory), and it can never go stale because the slot is final: the word is settled from
+//              the XCD's own L2 -- no trip to the memory side, which is what every lookup cost before, twice.
+//   slow read  anything else (an old epoch, no bit yet, another word): the device-scope path -- atomic load of meta, the prefix
+//              by device-scope loads behind the bit (issued after meta has returned: a control dependency), or the text while
+//              the inserter is between its two steps -- and the CAS for a free slot.
+// (The first version of this took an acquire FENCE at device scope before reading the prefix: correct, and 9x slower -- on
+// this chip that fence invalidates the XCD's L2.  gpurun_out/r03e_*.)
 struct alignas(32) DdSlot {
   unsigned long long meta, w0, w1, pad;
 };
@@ -77,19 +88,32 @@ __device__ __forceinline__ unsigned long long dd_hash(const uint8_t *p, uint32_t
   return h;
 }
 
-// the inserter's second half: the prefix, then the bit that says so (release: a reader that sees the bit sees the prefix)
+// the inserter's second half: the prefix to the memory side, a wait until it is there, then the bit that says so
 __device__ __forceinline__ void dd_publish(DdSlot &S, unsigned long long w0, unsigned long long w1) {
   __hip_atomic_store(&S.w0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(&S.w1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  (void)__hip_atomic_fetch_or(&S.meta, kDdPfx, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt: the two stores are acknowledged; no cache is touched
+  (void)__hip_atomic_fetch_or(&S.meta, kDdPfx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// the reader's half, after it has seen the prefix bit in meta
+// the slow reader's half, after a device-scope load of meta has shown the prefix bit (control dependency: these loads are
+// issued after that one has returned)
 __device__ __forceinline__ bool dd_prefix_equal(const DdSlot &S, unsigned long long w0, unsigned long long w1) {
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the compiler keeps the order too
   const unsigned long long r0 = __hip_atomic_load(&S.w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned long long r1 = __hip_atomic_load(&S.w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return r0 == w0 && r1 == w1;
+}
+
+// the fast read: a cached copy of the slot that already shows the final state of THIS word settles it (see DdSlot)
+__device__ __forceinline__ bool dd_cached_hit(const DdSlot &S, unsigned long long head, unsigned long long w0, unsigned long long w1,
+                                              uint32_t len) {
+  // plain loads (volatile only so that the compiler performs them here, every time): meta first, the prefix behind it
+  const unsigned long long m = *reinterpret_cast<const volatile unsigned long long *>(&S.meta);
+  const unsigned long long c0 = *reinterpret_cast<const volatile unsigned long long *>(&S.w0);
+  if ((m & ~kDOffMask) != (head | kDdPfx) || c0 != w0) return false;
+  if (len <= 8) return true;
+  return *reinterpret_cast<const volatile unsigned long long *>(&S.w1) == w1;
 }
 
 __device__ uint32_t dd_find_or_insert(const DedupTab &D, const uint8_t *__restrict__ text, const uint8_t *mine, uint32_t len,
@@ -157,6 +181,7 @@ __device__ __forceinline__ uint32_t dd_find_or_insert_lds(const DedupTab &D, con
   const unsigned long long head = ((unsigned long long)D.epoch << 56) | (((h >> 40) & 0x7Full) << 48) | ((unsigned long long)lf << 40);
   uint32_t idx = (uint32_t)h & mask;
   for (;;) {
+    if (len <= 16 && dd_cached_hit(D.slot[idx], head, w0, w1, len)) return idx;
     unsigned long long v = __hip_atomic_load(&D.slot[idx].meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((uint32_t)(v >> 56) != D.epoch) {  // free in this call (never used, or left over from an earlier call)
       const unsigned long long prev = atomicCAS(&D.slot[idx].meta, v, head | gpos);

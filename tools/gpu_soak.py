@@ -17,7 +17,7 @@ budget = float(os.environ.get("SWT_SOAK_SECONDS", "150"))
 rng = np.random.default_rng(seed)
 print("soak seed", seed, flush=True)
 t_end = time.time() + budget
-stats = {"train": 0, "train_merges": 0, "bpe": 0, "bpe_tokens": 0, "wp": 0, "wp_tokens": 0}
+stats = {"train": 0, "train_merges": 0, "bpe": 0, "bpe_tokens": 0, "wp": 0, "wp_tokens": 0, "shard": 0, "shard_merges": 0, "wptrain": 0, "wptrain_merges": 0}
 
 
 def fail(what, **kw):
@@ -111,9 +111,70 @@ def wp_trial():
     tok._trie.close()
 
 
+def shard_trial():
+    """the sharded runner (loop-back: every shard a trainer of this process) in its fast and its generic form: a random word
+    list cut into 2..5 contiguous ranges (some empty), merges and counts against the oracle on the whole list"""
+    alpha = int(rng.integers(2, 12)); n_words = int(rng.integers(20, 6000)); lo = int(rng.integers(1, 4)); hi = lo + int(rng.integers(1, 9))
+    fmax = int(rng.choice([1, 1, 2, 9])); n_merges = int(rng.integers(10, 400)); world = int(rng.integers(2, 6))
+    lens = rng.integers(lo, hi + 1, size=n_words)
+    off = np.zeros(n_words + 1, dtype=np.uint64); off[1:] = np.cumsum(lens)
+    sym = (97 + rng.integers(0, alpha, size=int(off[-1]))).astype(np.uint32)
+    freq = rng.integers(1, fmax + 1, size=n_words).astype(np.uint32)
+    orc = O.OracleBPETrainer.from_words(sym, off, freq)
+    orc.run(10 ** 9, n_merges)
+    ids, cnt = orc.merge_ids()
+    cuts = sorted(int(x) for x in rng.integers(0, n_words + 1, size=world - 1))
+    bounds = [0] + cuts + [n_words]
+    os.environ["SWT_DIST_GENERIC"] = "1" if rng.random() < 0.25 else "0"
+    trainers = []
+    for r in range(world):
+        a, b = bounds[r], bounds[r + 1]
+        trainers.append(N.BpeTrainer.from_words(sym[int(off[a]):int(off[b])], off[a:b + 1] - off[a], freq[a:b]))
+    comm = N.Dist.loopback(world)
+    try:
+        comm.shard_begin(trainers)
+        ls, rs, cs = [], [], []
+        slices = None if rng.random() < 0.5 else tuple(int(x) for x in rng.integers(1, 120, size=4))
+        i = 0
+        while len(ls) < len(ids):
+            ask = len(ids) - len(ls) if slices is None else min(slices[i % len(slices)], len(ids) - len(ls))
+            l, r, c = comm.run(trainers, ask, N.SYM_BASE + len(ls))
+            if len(l) != ask: fail("shard: short run", world=world, bounds=bounds, at=len(ls), ask=ask, got=len(l))
+            ls += l.tolist(); rs += r.tolist(); cs += c.tolist(); i += 1
+        got = np.stack([np.asarray(ls, dtype=np.uint32), np.asarray(rs, dtype=np.uint32)], axis=1) if ls else np.zeros((0, 2), np.uint32)
+        if len(ids) and ((got != ids[:, :2]).any() or not np.array_equal(np.asarray(cs, dtype=np.uint64), cnt)):
+            bad = int(np.nonzero((got != ids[:, :2]).any(axis=1))[0][0]) if (got != ids[:, :2]).any() else -1
+            fail("shard: merges", alpha=alpha, n_words=n_words, lo=lo, hi=hi, fmax=fmax, n_merges=n_merges, world=world, bounds=bounds,
+                 generic=os.environ["SWT_DIST_GENERIC"], slices=slices, first_bad=bad)
+    finally:
+        for t in trainers: t.close()
+        comm.close()
+    stats["shard"] += 1; stats["shard_merges"] += len(ids)
+
+
+def wptrain_trial():
+    """NaiveWP.train (fused step while the list of live pairs is short, the generic four launches with SWT_WP_GENERIC) against
+    the oracle's merge order on random sentences over a small alphabet"""
+    alpha = ALPHAS[int(rng.integers(len(ALPHAS)))].replace("-", "")
+    texts = texts_over(alpha, int(rng.integers(70, 400)), False)
+    if rng.random() < 0.3: os.environ["SWT_WP_GENERIC"] = "1"
+    else: os.environ.pop("SWT_WP_GENERIC", None)
+    orc = O.OracleWPTrainer(texts)
+    target = orc.vocab_size + int(rng.integers(5, 250))
+    orc.run(target)
+    tok = S.NaiveWP(); tok.train(list(texts), target)
+    got = [tuple(m) for m in tok._merge_order]; want = [tuple(m) for m in orc.merges_list]
+    if got != want:
+        bad = next((i for i, (a, b) in enumerate(zip(got, want)) if a != b), min(len(got), len(want)))
+        fail("wp train: merge order", alpha=alpha, n=len(texts), target=target, first_bad=bad, generic=os.environ.get("SWT_WP_GENERIC"))
+    tok.reset()
+    os.environ.pop("SWT_WP_GENERIC", None)
+    stats["wptrain"] += 1; stats["wptrain_merges"] += len(want)
+
+
 k = 0
 while time.time() < t_end:
-    (train_trial, bpe_trial, wp_trial)[k % 3]()
+    (train_trial, bpe_trial, wp_trial, shard_trial, wptrain_trial)[k % 5]()
     k += 1
     if k % 30 == 0: print(k, stats, flush=True)
 print("soak ok: seed", seed, stats, flush=True)
