@@ -835,6 +835,7 @@ int swt_bpe_encode_dev(swt_bpe_table *t, const uint8_t *d_text, uint64_t n_bytes
   if (!raw && !(flags & SWT_BPE_NO_DEDUP) && t->dd.opt_mode != 1 &&
       (t->dd.opt_mode == 2 || (n_bytes >= kDedupMinBytes && t->dd.pays(n_bytes)))) {
     rc = bpe_encode_dedup(t, d_text, n_bytes, d_sent_off, n_sent, d_out_ids, d_out_off, d_n_tokens, d_cls, st);
+    if (rc == 0 && t->dd.opt_mode == 0) t->dd.note(n_bytes, st);
     if (rc <= 0) return rc;  // done, or a real error
   }
   // raw-word mode: no classes, so nothing splits and nothing is dropped

@@ -21,32 +21,8 @@ constexpr uint32_t kRefSlot = 0x80000000u;
 
 typedef uint64_t u64u __attribute__((aligned(1)));  // unaligned 8-byte access (one global_load / ds_read on gfx950)
 
-// A table slot.  meta = epoch:8 | prefix valid:1 | tag:7 | byte length:8 | representative offset:40; w0 / w1 = the word's
-// first 16 bytes (zero-padded), valid once the inserter has set the prefix bit.  Until round 3 a slot was the meta word alone
-// and EVERY lookup that met its tag compared the word with the representative's bytes in the text: a random 16-byte read per
-// word occurrence out of a text of 10^8 bytes -- wordref fetched 5-10x the text through the L2 (profiles/r03_wp_encode_FETCH_SIZE).
-// Now a word of at most 16 bytes (all but a few per thousand) is settled by the slot's own 32 bytes.
-// Protocol (MI355X has one L2 per XCD, and they are not coherent with each other inside a kernel: only device-scope atomics
-// -- which go to the memory side -- see each other's writes at once):
-//   inserter   CAS on meta (device scope, prefix bit clear) takes the slot; w0 / w1 are stored with device-scope stores; once
-//              those are acknowledged (a wait, no cache maintenance) the prefix bit is OR-ed into meta.  A slot never changes
-//              again within the call.
-//   fast read  a PLAIN (cached) load of {meta, w0}: if that copy shows this call's epoch, the prefix bit and the wanted
-//              tag/length, the copy was fetched after the bit was set, i.e. after the prefix was complete (a cache line is
-//              filled from one state of memory), and it can never go stale because the slot is final: the word is settled from
-//              the XCD's own L2 -- no trip to the memory side, which is what every lookup cost before, twice.
-//   slow read  anything else (an old epoch, no bit yet, another word): the device-scope path -- atomic load of meta, the prefix
-//              by device-scope loads behind the bit (issued after meta has returned: a control dependency), or the text while
-//              the inserter is between its two steps -- and the CAS for a free slot.
-// (The first version of this took an acquire FENCE at device scope before reading the prefix: correct, and 9x slower -- on
-// this chip that fence invalidates the XCD's L2.  gpurun_out/r03e_*.)
-struct alignas(32) DdSlot {
-  unsigned long long meta, w0, w1, pad;
-};
-constexpr unsigned long long kDdPfx = 1ull << 55;
-
 struct DedupTab {
-  DdSlot *slot;
+  unsigned long long *slot;      // epoch:8 | tag:8 | byte length:8 | representative offset:40
   unsigned long long *rec;       // per slot: the inserter leaves the byte length; the unique-word encode replaces it by
                                  // token count:32 | place of the tokens in its scratch:32
   uint64_t n_bytes;              // size of the text (wide compares stay inside it)
@@ -88,67 +64,32 @@ __device__ __forceinline__ unsigned long long dd_hash(const uint8_t *p, uint32_t
   return h;
 }
 
-// the inserter's second half: the prefix to the memory side, a wait until it is there, then the bit that says so
-__device__ __forceinline__ void dd_publish(DdSlot &S, unsigned long long w0, unsigned long long w1) {
-  __hip_atomic_store(&S.w0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(&S.w1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt: the two stores are acknowledged; no cache is touched
-  (void)__hip_atomic_fetch_or(&S.meta, kDdPfx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// the slow reader's half, after a device-scope load of meta has shown the prefix bit (control dependency: these loads are
-// issued after that one has returned)
-__device__ __forceinline__ bool dd_prefix_equal(const DdSlot &S, unsigned long long w0, unsigned long long w1) {
-  __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the compiler keeps the order too
-  const unsigned long long r0 = __hip_atomic_load(&S.w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long r1 = __hip_atomic_load(&S.w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return r0 == w0 && r1 == w1;
-}
-
-// the fast read: a cached copy of the slot that already shows the final state of THIS word settles it (see DdSlot)
-__device__ __forceinline__ bool dd_cached_hit(const DdSlot &S, unsigned long long head, unsigned long long w0, unsigned long long w1,
-                                              uint32_t len) {
-  // plain loads (volatile only so that the compiler performs them here, every time): meta first, the prefix behind it
-  const unsigned long long m = *reinterpret_cast<const volatile unsigned long long *>(&S.meta);
-  const unsigned long long c0 = *reinterpret_cast<const volatile unsigned long long *>(&S.w0);
-  if ((m & ~kDOffMask) != (head | kDdPfx) || c0 != w0) return false;
-  if (len <= 8) return true;
-  return *reinterpret_cast<const volatile unsigned long long *>(&S.w1) == w1;
-}
-
 __device__ uint32_t dd_find_or_insert(const DedupTab &D, const uint8_t *__restrict__ text, const uint8_t *mine, uint32_t len,
                                       uint64_t gpos, bool &is_new) {
   is_new = false;
   if (len >= 255u) { is_new = true; return dd_own_slot(D, gpos); }
   const unsigned long long h = dd_hash(mine, len);
-  const unsigned long long w0 = dd_pack8(mine, len), w1 = len > 8 ? dd_pack8(mine + 8, len - 8) : 0ull;
   const uint32_t mask = (1u << D.bits) - 1u;
   const uint32_t lf = len;
   uint32_t probes = 0;
-  const unsigned long long head = ((unsigned long long)D.epoch << 56) | (((h >> 40) & 0x7Full) << 48) | ((unsigned long long)lf << 40);
+  const unsigned long long head = ((unsigned long long)D.epoch << 56) | (((h >> 40) & 0xFFull) << 48) | ((unsigned long long)lf << 40);
   uint32_t idx = (uint32_t)h & mask;
   for (;;) {
-    unsigned long long v = __hip_atomic_load(&D.slot[idx].meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long v = __hip_atomic_load(&D.slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((uint32_t)(v >> 56) != D.epoch) {  // free in this call (never used, or left over from an earlier call)
-      const unsigned long long prev = atomicCAS(&D.slot[idx].meta, v, head | gpos);
+      const unsigned long long prev = atomicCAS(&D.slot[idx], v, head | gpos);
       if (prev == v) {
-        dd_publish(D.slot[idx], w0, w1);
         is_new = true;
         return idx;
       }
       v = prev;
       if ((uint32_t)(v >> 56) != D.epoch) continue;  // changed to another stale value?  look again
     }
-    if ((v & ~(kDOffMask | kDdPfx)) == head) {
+    if ((v & ~kDOffMask) == head) {
       const uint8_t *rep = text + (v & kDOffMask);
       bool same = true;
-      uint32_t from = 0;
-      if (v & kDdPfx) {  // the first 16 bytes from the slot
-        same = dd_prefix_equal(D.slot[idx], w0, w1);
-        from = 16;
-      }
-      for (uint32_t i = from; i < len && same; i++)
-        if (rep[i] != mine[i]) same = false;
+      for (uint32_t i = 0; i < len; i++)
+        if (rep[i] != mine[i]) { same = false; break; }
       if (same) return idx;
     }
     if (++probes >= kDdMaxProbes) { is_new = true; return dd_own_slot(D, gpos); }
@@ -178,30 +119,25 @@ __device__ __forceinline__ uint32_t dd_find_or_insert_lds(const DedupTab &D, con
   const uint32_t mask = (1u << D.bits) - 1u;
   const uint32_t lf = len;
   uint32_t probes = 0;
-  const unsigned long long head = ((unsigned long long)D.epoch << 56) | (((h >> 40) & 0x7Full) << 48) | ((unsigned long long)lf << 40);
+  const unsigned long long head = ((unsigned long long)D.epoch << 56) | (((h >> 40) & 0xFFull) << 48) | ((unsigned long long)lf << 40);
   uint32_t idx = (uint32_t)h & mask;
   for (;;) {
-    if (len <= 16 && dd_cached_hit(D.slot[idx], head, w0, w1, len)) return idx;
-    unsigned long long v = __hip_atomic_load(&D.slot[idx].meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long v = __hip_atomic_load(&D.slot[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((uint32_t)(v >> 56) != D.epoch) {  // free in this call (never used, or left over from an earlier call)
-      const unsigned long long prev = atomicCAS(&D.slot[idx].meta, v, head | gpos);
+      const unsigned long long prev = atomicCAS(&D.slot[idx], v, head | gpos);
       if (D.diag & 1u) atomicAdd(&D.overflow[prev == v ? 1 : 2], 1u);
       if (prev == v) {
-        dd_publish(D.slot[idx], w0, w1);
         is_new = true;  // listed by the caller
         return idx;
       }
       v = prev;
       if ((uint32_t)(v >> 56) != D.epoch) continue;
     }
-    if ((v & ~(kDOffMask | kDdPfx)) == head) {
+    if ((v & ~kDOffMask) == head) {
       const uint64_t ro = v & kDOffMask;
       const uint8_t *rep = text + ro;
       bool same;
-      if (v & kDdPfx) {  // the slot's own bytes settle the first 16; a longer word goes on in the text
-        same = dd_prefix_equal(D.slot[idx], w0, w1);
-        for (uint32_t i = 16; i < len && same; i++) same = rep[i] == mine[i];
-      } else if (ro + 16 <= D.n_bytes) {
+      if (ro + 16 <= D.n_bytes) {
         unsigned long long r0 = *reinterpret_cast<const u64u *>(rep), r1 = *reinterpret_cast<const u64u *>(rep + 8);
         if (len < 8) { r0 &= (1ull << (8 * len)) - 1ull; r1 = 0; }
         else if (len < 16) r1 &= (1ull << (8 * (len - 8))) - 1ull;
@@ -467,13 +403,10 @@ __global__ __launch_bounds__(64) void ureg_kernel(const uint8_t *__restrict__ te
                                                       const unsigned long long *__restrict__ new_blk_base,
                                                       const unsigned long long *__restrict__ d_total, uint32_t *__restrict__ uslot,
                                                       uint64_t *__restrict__ uoff, uint8_t *__restrict__ utext,
-                                                      uint64_t *__restrict__ plan2, uint64_t n_tiles2, uint32_t tile2_min,
-                                                      unsigned long long *__restrict__ d_note, uint32_t size_class) {
+                                                      uint64_t *__restrict__ plan2, uint64_t n_tiles2, uint32_t tile2_min) {
   const int lane = threadIdx.x;
   const uint64_t t = blockIdx.x;
   const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
-  // for the next call's table size: distinct words << 8 | log2 of this call's bytes, ONE word (the host reads it unsynchronised)
-  if (t == 0 && lane == 0) *d_note = ((*d_total >> 32) << 8) | (unsigned long long)size_class;
   // The plan of the launch that encodes the unique words (plan2[tt] = first unique word that starts at or after byte
   // tt * tile2) is written here too: that launch has a fixed n_tiles2 workgroups, so the tile size follows from the
   // number of unique bytes, which only the device knows.  A boundary inside (start, end] of a word belongs to the word
@@ -760,13 +693,13 @@ bool DedupEngine::pays(uint64_t n_bytes) {
 
 void DedupEngine::note(uint64_t n_bytes, hipStream_t st) {
   if (!seen.p) {
-    if (seen.reserve(32)) return;
-    for (int i = 0; i < 4; i++) seen.as<unsigned long long>()[i] = 0;
+    if (seen.reserve(16)) return;
+    seen.as<unsigned long long>()[0] = 0;
+    seen.as<unsigned long long>()[1] = 0;
   }
   unsigned long long *h = seen.as<unsigned long long>();
   h[1] = n_bytes;
   (void)hipMemcpyAsync(h, misc.p, 8, hipMemcpyDeviceToHost, st);
-  (void)hipMemcpyAsync(h + 2, misc.as<unsigned long long>() + 3, 8, hipMemcpyDeviceToHost, st);  // ureg_kernel's note
   skipped = 0;
 }
 
@@ -780,38 +713,21 @@ int dedup_front(DedupEngine &E, TileWorkspace &ws, const uint8_t *d_text, uint64
   // (see DedupTab); never cleared (epoch).  rec[] = the table's slots, then the own slots of the words that overflowed.
   uint32_t bits = 16;
   while ((1ull << bits) < n_bytes / 32 && bits < 24) bits++;
-  // ... and of that allocation the call USES only what the last call of this size found to be needed: four slots per distinct
-  // word.  The counters say why (profiles/r03_*_FETCH_SIZE: wordref fetched 5-10x the text, wp_refs<count> 2x): the lookups
-  // are random reads, and 2^23 slots + records for the ~10^5 distinct chunks of the FastWP batch spread the hot entries over
-  // 13 MB of cache lines -- three times the L2 of an XCD.  A table that turns out too small is still exact (own slots).
-  uint32_t use_bits = bits;
-  uint32_t size_class = 0;
-  while ((2ull << size_class) <= n_bytes) size_class++;  // floor(log2(n_bytes))
-  if (!E.opt_table_bits && E.seen.p) {
-    const unsigned long long packed = reinterpret_cast<const volatile unsigned long long *>(E.seen.p)[2];
-    const unsigned long long uniq = packed >> 8;
-    if (uniq && (packed & 0xFF) == size_class) {  // a call of this size has reported
-      uint32_t want = 16;
-      while ((1ull << want) < 4 * uniq + 1024 && want < bits) want++;
-      use_bits = want;
-    }
-  }
   if (E.opt_table_bits) {  // SWT_OPT_DEDUP_TABLE_BITS (tests: a table so small that words overflow it)
     bits = E.opt_table_bits;
-    use_bits = bits;
     if (bits != E.bits) E.bits = 0;
   }
   if (bits > E.bits) {
     E.slot.release();
-    if ((rc = E.slot.reserve(((size_t)1 << bits) * sizeof(DdSlot)))) return rc;
-    SWT_HIP(hipMemsetAsync(E.slot.p, 0, ((size_t)1 << bits) * sizeof(DdSlot), st));
+    if ((rc = E.slot.reserve(((size_t)1 << bits) * 8))) return rc;
+    SWT_HIP(hipMemsetAsync(E.slot.p, 0, ((size_t)1 << bits) * 8, st));
     E.bits = bits;
     E.epoch = 0;
   }
   const uint32_t ovf_shift = mode == kDedupWp ? 0u : 1u;
   if ((rc = E.rec.reserve((((size_t)1 << E.bits) + (n_bytes >> ovf_shift) + 2) * 8))) return rc;
   if (++E.epoch >= 256) {
-    SWT_HIP(hipMemsetAsync(E.slot.p, 0, ((size_t)1 << E.bits) * sizeof(DdSlot), st));
+    SWT_HIP(hipMemsetAsync(E.slot.p, 0, ((size_t)1 << E.bits) * 8, st));
     E.epoch = 1;
   }
   // a tabled word has at least two bytes (BPE: a one-symbol word is not tabled) or one (WP)
@@ -828,11 +744,11 @@ int dedup_front(DedupEngine &E, TileWorkspace &ws, const uint8_t *d_text, uint64
   }
   unsigned long long *d_misc = E.misc.as<unsigned long long>();  // [0] unique words:32 | their bytes:32, [1..2] diagnostics
   DedupTab D;
-  D.slot = E.slot.as<DdSlot>();
+  D.slot = E.slot.as<unsigned long long>();
   D.rec = E.rec.as<unsigned long long>();
   D.n_bytes = n_bytes;
   D.diag = (ablation_knob(2) & 4) ? 1u : 0u;
-  D.bits = use_bits < E.bits ? use_bits : E.bits;
+  D.bits = E.bits;
   D.epoch = E.epoch;
   D.ovf_shift = ovf_shift;
   D.newlist = E.newlist.as<unsigned long long>();
@@ -855,13 +771,12 @@ int dedup_front(DedupEngine &E, TileWorkspace &ws, const uint8_t *d_text, uint64
   if (mode == kDedupWp)
     hipLaunchKernelGGL(ureg_kernel<kDedupWp>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, d_sent_off, plan1, D, new_local,
                        new_blk + 1 + nb_new, d_misc, E.uslot.as<uint32_t>(), E.uoff.as<uint64_t>(), E.utext.as<uint8_t>(), d_plan2,
-                       n_tiles2, tile2_min, d_misc + 3, size_class);
+                       n_tiles2, tile2_min);
   else
     hipLaunchKernelGGL(ureg_kernel<kDedupBpe>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, d_sent_off, plan1, D, new_local,
                        new_blk + 1 + nb_new, d_misc, E.uslot.as<uint32_t>(), E.uoff.as<uint64_t>(), E.utext.as<uint8_t>(), d_plan2,
-                       n_tiles2, tile2_min, d_misc + 3, size_class);
+                       n_tiles2, tile2_min);
   SWT_HIP(hipGetLastError());
-  E.note(n_bytes, st);  // what this call found, for the next one (table size; FastBPE: whether the dedup pays at all)
   if (D.diag) {
     unsigned long long h[3] = {0, 0, 0};
     SWT_HIP(hipMemcpyAsync(h, d_misc, 24, hipMemcpyDeviceToHost, st));
