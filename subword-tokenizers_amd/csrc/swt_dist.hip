@@ -352,6 +352,22 @@ static int run_sharded_fast(swt_dist *d, swt_bpe_trainer **tr, uint32_t n_local,
         return fail(SWT_ERR_STATE, "the shards sized a round trip differently (%u/%u steps, %u/%u merges): their replicas have diverged",
                     trips[i].steps, trip.steps, trips[i].cap, trip.cap);
     if (trip.cap > kMaxRunSteps) return fail(SWT_ERR_STATE, "a round trip was sized beyond the step log");
+    if (!d->local) {
+      // Every rank is about to enqueue `steps` pairs of collectives without looking up again: ranks that sized the trip
+      // differently would wait for each other for ever.  They cannot differ while the replicas agree -- so check that they do,
+      // from what every rank sees of every rank (all of them take the same way out): one small host gather per round trip.
+      unsigned long long mine[4] = {((unsigned long long)trip.steps << 32) | trip.cap, trip.fast ? 1ull : 0ull, tr[0]->theta, tr[0]->h_st.n_cand};
+      std::vector<const void *> ptrs(1, mine);
+      std::vector<uint8_t> all;
+      if ((rc = gather_host(d, ptrs, sizeof mine, all, tr[0]->stream))) return rc;
+      for (int r = 0; r < d->world; r++)
+        if (memcmp(all.data() + (size_t)r * sizeof mine, all.data(), sizeof mine) != 0) {
+          const unsigned long long *o = reinterpret_cast<const unsigned long long *>(all.data() + (size_t)r * sizeof mine);
+          const unsigned long long *z = reinterpret_cast<const unsigned long long *>(all.data());
+          return fail(SWT_ERR_STATE, "rank %d sized the round trip differently from rank 0 (steps|cap %llx / %llx, fast %llu / %llu, theta %llu / %llu, "
+                                     "candidates %llu / %llu): the replicas have diverged", r, o[0], z[0], o[1], z[1], o[2], z[2], o[3], z[3]);
+        }
+    }
     prof_begin(tr[0]->stream);
     if (trip.fast) {
       for (uint32_t i = 0; i < n_local; i++)
