@@ -619,13 +619,17 @@ def mixed_encode_block(args, torch, dist, rank, N, bpe, wp, n_each, steps, warmu
         bufs.append((to_dev(torch, text), to_dev(torch, off.view(np.int64)), torch.empty(nb + 64, dtype=torch.int32, device="cuda"),
                      torch.empty(n_each + 1, dtype=torch.int64, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda"), nb))
     d_status = torch.empty(n_each + 8, dtype=torch.uint8, device="cuda")
+    # the two halves are independent calls on handles of their own: each goes out on its OWN stream, so that the short kernels
+    # of one pipeline (scans, plans, the passes over the unique words) run beside the long ones of the other
     stream = torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
 
     def step():
         t, o, out, oo, nt, nb = bufs[0]
         bpe._table.encode_dev(t.data_ptr(), nb, o.data_ptr(), n_each, out.data_ptr(), oo.data_ptr(), nt.data_ptr(), 0, stream)
         t, o, out, oo, nt, nb = bufs[1]
-        wp._trie.encode_dev(t.data_ptr(), nb, o.data_ptr(), n_each, out.data_ptr(), oo.data_ptr(), d_status.data_ptr(), nt.data_ptr(), stream)
+        wp._trie.encode_dev(t.data_ptr(), nb, o.data_ptr(), n_each, out.data_ptr(), oo.data_ptr(), d_status.data_ptr(), nt.data_ptr(), side.cuda_stream)
 
     for _ in range(warmup):
         step()
@@ -678,14 +682,17 @@ def mixed_encode_block(args, torch, dist, rank, N, bpe, wp, n_each, steps, warmu
         raise SystemExit("PARITY FAILURE: FastWP statuses differ from the oracle (mixed)")
     n_tok = int(bufs[0][4].item()) + int(bufs[1][4].item())
     algo = n_bytes + 4.0 * n_tok + 8.0 * 2 * (n_each + 1)
-    per_step_s = call_ms / 1e3 / max(calls // 2, 1)
+    # the two calls overlap (two streams): what a step costs is the timed region's wall per step; the HIP-event spans of the two
+    # calls (first kernel .. last kernel of each, summed) are reported beside it
+    per_step_s = elapsed / steps
     achieved = algo / per_step_s / 1e9
     res["tokens_per_gpu"] = n_tok
     res["roofline"] = check_frac({
         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
         "traffic": traffic_from_profile("mixed_encode"),
-        "kernel": "one FastBPE call + one FastWP call (both dedup pipelines), first kernel .. last kernel of each",
-        "kernel_us": round(per_step_s * 1e6, 2), "algorithmic_bytes_per_launch": int(algo), "launches_timed": int(calls // 2)})
+        "kernel": "one FastBPE call + one FastWP call (both dedup pipelines) on two streams: wall of the timed steps",
+        "kernel_us": round(per_step_s * 1e6, 2), "algorithmic_bytes_per_launch": int(algo), "launches_timed": int(steps),
+        "sum_of_call_spans_us": round(call_ms * 1e3 / max(calls // 2, 1), 2)})
     sub_bytes = int(b_off[sub]) + int(w_off[sub])
     res["cpu_baseline"] = {
         "value": round(sub_bytes / 1e6 / cpu1_s, 3), "unit": "MB/s", "cores": 1, "kind": "port",

@@ -3319,10 +3319,17 @@ int swt_bpe_train_run(swt_bpe_trainer *t, uint32_t max_steps, uint32_t first_mer
       if (cap < steps) cap = steps;
     }
     // room for everything the round trip may create (the symbol count grows by one per merge, counts never grow)
-    const uint64_t by_sym = 2 * (t->n_base + t->n_applied + cap + 1) + 1;
-    uint64_t per = new_pairs_bound(t, t->h_st.max_count);
-    if (t->h_st.max_count == 0 || by_sym < per) per = by_sym;
-    uint64_t extra = per * cap;
+    // New pairs per merge: two per occurrence (occurrences <= the pair's count, and counts never grow: the maximum at the start
+    // of the trip bounds every merge of it), and never more than (x, m) / (m, y) over the distinct symbols plus (m, m) -- the
+    // symbols there are when the LAST merge of the trip happens, not now.  (Until round 3 the second bound was taken with the
+    // symbol count at the start of the trip: a trip of many merges over a tiny alphabet outgrew it, and the table passed load
+    // 1/2 -- silently, until check_state() looked: tools/gpu_soak.py seed 12787955, profiles/r03h_soak.txt.)
+    const uint64_t by_count = (!t->d_sfreq && t->h_st.max_count) ? 2 * t->h_st.max_count : ~0ull;  // (WordPiece: max_count is a score)
+    uint64_t extra = 0;
+    for (uint32_t k2 = 0; k2 < cap; k2++) {  // merge k2 of the trip sees n_base + n_applied + k2 symbols
+      const uint64_t by_sym = 2 * (t->n_base + t->n_applied + k2 + 1) + 1;
+      extra += by_sym < by_count ? by_sym : by_count;
+    }
     // (every new pair costs the stream a symbol: a round trip cannot make more than two per live symbol)
     if (!t->sharded && t->h_st.n_syms && 2 * t->h_st.n_syms + 64 < extra) extra = 2 * t->h_st.n_syms + 64;
     if ((rc = ensure_room(t, extra))) return rc;
