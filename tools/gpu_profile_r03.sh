@@ -44,3 +44,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   run_pmc bpe_encode_open $c --workload bpe_encode --corpus open --steps 8 --warmup 2 --lean
 done
 ls $O
+cd $R
+timeout -k 10 500 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo default_bench_exit=$?
+timeout -k 10 300 python bench.py --workload wp_train > $O/bench_wp_train.json 2> $O/bench_wp_train.err; echo wp_train_exit=$?
+timeout -k 10 400 python bench.py --workload bpe_train_1g > $O/bench_bpe_train_1g.json 2> $O/bench_bpe_train_1g.err; echo bpe_train_1g_exit=$?
+SWT_BENCH_FORCE_SHARDED=1 timeout -k 10 300 python bench.py --workload bpe_train --steps 1 > $O/bench_forced_sharded_fast.json 2> $O/bench_forced_sharded_fast.err; echo forced_sharded_fast_exit=$?
+SWT_BENCH_FORCE_SHARDED=1 SWT_DIST_GENERIC=1 timeout -k 10 300 python bench.py --workload bpe_train --steps 1 > $O/bench_forced_sharded_generic.json 2> $O/bench_forced_sharded_generic.err; echo forced_sharded_generic_exit=$?
