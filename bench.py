@@ -327,7 +327,9 @@ def train_bench(args, torch, dist, rank, world, N, sents, max_vocab, name, repea
     return {"metric": "BPE train seconds per 1k merges", "s_per_1k_merges": round(wall / n_merges * 1000, 5), "train_wall_s": round(wall, 4),
             "merge_loop_s": round(loop_s, 4), "us_per_merge_device": round(per_merge_s * 1e6, 2), "n_merges": len(merges),
             "workload": "FastBPE.train on %s to max_vocab=%d: %d merges, %d unique words, %d -> %d symbols" % (name, max_vocab, len(merges), w0, n0, n_final),
-            "parallelism": "single GPU" if world == 1 else "corpus-sharded x%d, per-merge delta all-gather (RCCL)" % world,
+            "parallelism": ("single GPU" if world == 1 and not os.environ.get("SWT_BENCH_FORCE_SHARDED") else
+                            "corpus-sharded x%d over RCCL: per step one tie-message all-gather + one record-block all-gather (%s form)"
+                            % (world, "generic one-merge-per-step" if os.environ.get("SWT_DIST_GENERIC", "0") not in ("", "0") else "fast")),
             "roofline": roof,
             "cpu_baseline": {"value": round(cpu_s / cpu_sample * 1000, 3), "unit": "s/1k-merges", "cores": 1, "kind": "port",
                              "sample": "first %d merges of the same run through oracle/swt_oracle.c orc_train_run (the reference's "
