@@ -566,3 +566,39 @@ def test_decode_ids_large_outputs_equal_the_per_id_spelling(swt, native, ref_dir
         native._pyhost = saved
     with pytest.raises(IndexError):
         tok.decode_ids(np.full(5000, native.SYM_BASE + len(st.strings), dtype=np.uint32))
+
+
+def test_sharded_trainer_refuses_a_string_collision_and_a_repeated_pair(native):
+    """distributed.ShardedBpeTrainer.train (bpe.py:88-111 over shards): two merges spelling one string (never
+    observed on real data) cannot be replayed by a sharded run -- the unsharded class rebuilds from the text, a rank has no way to
+    -- so the host loop must say so instead of drifting from the reference; and a pair selected twice means the replicas have
+    diverged.  Driven here by a stub engine with the two-method interface (no device)."""
+    from subword_tokenizers_amd.distributed import ShardedBpeTrainer
+
+    a, b, c, base = ord("a"), ord("b"), ord("c"), native.SYM_BASE
+
+    class Engine:
+        def __init__(self, merges):
+            self.merges = merges
+
+        def begin(self):
+            return np.array([a, b, c], dtype=np.uint32)
+
+        def run(self, want, first):
+            assert first == base
+            m = self.merges[:want]
+            return (np.array([x for x, _ in m], dtype=np.uint32), np.array([y for _, y in m], dtype=np.uint32),
+                    np.array([5] * len(m), dtype=np.uint64))
+
+    # (b,c)->"bc", (a,b)->"ab", (ab,c)->"abc", then (a,bc) spells "abc" again
+    tr = ShardedBpeTrainer(Engine([(b, c), (a, b), (base + 1, c), (a, base)]), 0, 2)
+    with pytest.raises(RuntimeError, match="already names symbol"):
+        tr.train(3 + 4)
+    assert tr.merges_list[:3] == [("b", "c"), ("a", "b"), ("ab", "c")]
+    tr = ShardedBpeTrainer(Engine([(b, c), (a, b), (b, c)]), 0, 2)
+    with pytest.raises(RuntimeError, match="selected twice"):
+        tr.train(3 + 3)
+    # the ordinary case: the merges come back as strings, the vocabulary grows by one per merge, an early end is noticed
+    tr = ShardedBpeTrainer(Engine([(b, c), (a, base)]), 0, 2)
+    assert tr.train(3 + 5) == [("b", "c"), ("a", "bc")] and tr.vocab == {"a", "b", "c", "bc", "abc"}
+
