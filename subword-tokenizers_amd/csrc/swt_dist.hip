@@ -328,22 +328,35 @@ static int run_sharded_fast(swt_dist *d, swt_bpe_trainer **tr, uint32_t n_local,
   bool exhausted = false;
   int dry_runs = 0;
   double per_step = 1.0;
+  int deferred_rc = 0;  // an error found after a trip: it leaves through the gather below, so that EVERY rank leaves
   while (done < max_steps && !exhausted) {
     const uint32_t remaining = max_steps - done;
     // head room on every local trainer; does any rank need a re-plan (its table grew, its list is long)?  All or none.
-    uint8_t want = 0;
+    // An error on one rank (a capacity check, an allocation) must not leave the others waiting in a collective: the ranks
+    // exchange a status byte with the re-plan bit, and all of them return when one of them failed.
+    uint8_t msg[2] = {0, 0};  // [0] wants a re-plan, [1] failed
     std::vector<ShardTrip> trips(n_local);
-    for (uint32_t i = 0; i < n_local; i++) {
-      if ((rc = tr[i]->sync_state()) || (rc = tr[i]->check_state())) return rc;
-      if ((rc = trainer_fast_room(tr[i], remaining, per_step, &trips[i]))) return rc;
-      want |= trips[i].replan_first ? 1 : 0;
+    int local_rc = deferred_rc;
+    for (uint32_t i = 0; i < n_local && !local_rc; i++) {
+      if ((local_rc = tr[i]->sync_state()) || (local_rc = tr[i]->check_state())) break;
+      if ((local_rc = trainer_fast_room(tr[i], remaining, per_step, &trips[i]))) break;
+      msg[0] |= trips[i].replan_first ? 1 : 0;
     }
+    msg[1] = local_rc ? 1 : 0;
     if (!d->local) {
-      std::vector<const void *> ptrs(1, &want);
+      const std::string kept = swt_last_error();  // (the gather may overwrite the text of this rank's own error)
+      std::vector<const void *> ptrs(1, msg);
       std::vector<uint8_t> all;
-      if ((rc = gather_host(d, ptrs, 1, all, tr[0]->stream))) return rc;
-      for (uint8_t w : all) want |= w;
+      if ((rc = gather_host(d, ptrs, 2, all, tr[0]->stream))) return local_rc ? local_rc : rc;
+      for (int r = 0; r < d->world; r++) {
+        msg[0] |= all[2 * r];
+        if (all[2 * r + 1] && !local_rc) return fail(SWT_ERR_STATE, "rank %d reported an error in its training state; this rank stops with it", r);
+      }
+      if (local_rc) return fail(local_rc, "%s", kept.c_str());
+    } else if (local_rc) {
+      return local_rc;
     }
+    const uint8_t want = msg[0];
     for (uint32_t i = 0; i < n_local; i++)
       if ((rc = trainer_fast_plan(tr[i], remaining, per_step, want != 0, first_merged + done, &trips[i]))) return rc;
     const ShardTrip trip = trips[0];
@@ -395,20 +408,22 @@ static int run_sharded_fast(swt_dist *d, swt_bpe_trainer **tr, uint32_t n_local,
     unsigned int halt = 0;
     SWT_HIP(hipMemcpyAsync(hlog.data(), tr[0]->d_steplog, trip.cap * sizeof(StepLog), hipMemcpyDeviceToHost, tr[0]->stream));
     SWT_HIP(hipMemcpyAsync(&halt, tr[0]->d_halt, 4, hipMemcpyDeviceToHost, tr[0]->stream));
-    for (uint32_t i = 0; i < n_local; i++)
-      if ((rc = tr[i]->sync_state()) || (rc = tr[i]->check_state())) return rc;
+    for (uint32_t i = 0; i < n_local && !deferred_rc; i++)
+      if ((deferred_rc = tr[i]->sync_state()) || (deferred_rc = tr[i]->check_state())) break;
+    if (deferred_rc) continue;  // (through the status gather at the top)
     uint32_t good = 0;
     unsigned long long stop = 0;  // 0, 2 no pair left, 3 re-plan
     if (trip.fast) {
       const unsigned long long logged = tr[0]->h_st.run_done[(tr[0]->step_no + 1) & 1u];
-      if (logged > trip.cap) return fail(SWT_ERR_STATE, "the step log overran its round trip");
+      if (logged > trip.cap) { deferred_rc = fail(SWT_ERR_STATE, "the step log overran its round trip"); continue; }
       good = (uint32_t)logged;
       stop = tr[0]->h_st.halt;
-      for (uint32_t i = 0; i < good; i++)
-        if (hlog[i].flag != 0) return fail(SWT_ERR_STATE, "the step log has a hole");
-      for (uint32_t i = 1; i < n_local; i++)
+      for (uint32_t i = 0; i < good && !deferred_rc; i++)
+        if (hlog[i].flag != 0) deferred_rc = fail(SWT_ERR_STATE, "the step log has a hole");
+      for (uint32_t i = 1; i < n_local && !deferred_rc; i++)
         if (tr[i]->h_st.run_done[(tr[i]->step_no + 1) & 1u] != logged)
-          return fail(SWT_ERR_STATE, "the shards logged different numbers of merges: their replicas have diverged");
+          deferred_rc = fail(SWT_ERR_STATE, "the shards logged different numbers of merges: their replicas have diverged");
+      if (deferred_rc) continue;
     } else {
       while (good < trip.cap && hlog[good].flag == 0) good++;
       if (good < trip.cap && hlog[good].flag != 4) stop = hlog[good].flag;
