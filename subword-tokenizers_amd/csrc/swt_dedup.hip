@@ -1,4 +1,6 @@
 // swt_dedup.hip -- word-level dedup inside one encode call (see swt_dedup.h), the kernels and the two host halves.
+#include <cstdlib>
+
 #include "swt_dedup.h"
 
 namespace swt {
@@ -155,6 +157,20 @@ __device__ __forceinline__ uint32_t dd_find_or_insert_lds(const DedupTab &D, con
   }
 }
 
+// ---- the split, sixteen bytes per lane (FastWP chunks) -------------------------------------------------------------------------
+// wordref_kernel<kDedupWp> issues 254 M vector and 199 M scalar instructions per 141 MB call -- 81 % of the vector pipe's time
+// (profiles/r03_sq_counters.txt) -- and two thirds of them are the split loop: one byte per lane, 64 bytes per trip, five
+// ballots and ~70 scalar mask operations per trip.  A chunk between str.isspace characters needs none of the pre-tokenizer's
+// classes, so the lane form takes SIXTEEN bytes per lane (one ds_read_b128), finds the ASCII whitespace of its four dwords with
+// carry-free byte arithmetic, looks only its (rare) non-ASCII lead bytes up in the class table, and does the mask algebra of the
+// byte-lane loop on its own 16 bits -- the whitespace smear and the "byte before me" across the lane boundary from the lane
+// below (one shuffle) -- a whole KiB per trip.  It leaves EXACTLY what the byte-lane loop leaves (endm / wst / nwb per 64-byte
+// block, the list of word starts, the cut): the rest of the kernel does not know the difference, and every dedup test compares
+// the two forms' outputs through the oracle.  SWT_DD_OLD_SPLIT=1 runs the byte-lane loop instead (comparison).
+__device__ __forceinline__ uint32_t dd_nibble(uint32_t flags_bit7) {  // bit 7 of each of the 4 bytes -> 4 bits, byte 0 lowest
+  return ((((flags_bit7 >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
+}
+
 struct WordrefLds {
   __attribute__((aligned(16))) uint8_t txt[kDCap + 16];
   uint16_t wl[kDCap];
@@ -170,7 +186,8 @@ struct WordrefLds {
 // Mode kDedupBpe: words end at BertPreTokenizer whitespace, every punctuation code point is a word of its own, and a
 // one-symbol word is recorded as its own token.  Mode kDedupWp: words are the chunks between str.isspace characters and
 // every one of them goes through the table.
-template <int Mode>
+// Lanes16: the split takes sixteen bytes per lane (an instance of its own, so that neither form pays the other's registers)
+template <int Mode, bool Lanes16 = false>
 __global__ __launch_bounds__(64) void wordref_kernel(const uint8_t *__restrict__ text, uint64_t n_bytes,
                                                      const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
                                                      const uint8_t *__restrict__ cls_tab, DedupTab D, uint32_t *__restrict__ wref,
@@ -222,6 +239,100 @@ __global__ __launch_bounds__(64) void wordref_kernel(const uint8_t *__restrict__
     uint32_t nw = 0;
     bool prev_wb = true;
     int cut = -1;
+    if (Lanes16) {
+      // carried from trip to trip: the last lane's raw whitespace and continuation bits (the lane below lane 0)
+      uint32_t carry_wb = 0x8000u, carry_ct = 0u;  // chunk start: "the byte before belongs to whitespace"
+      const uint32_t n_groups = nblk * 4;          // 16-byte groups that lie in the blocks the kernel looks at
+      for (uint32_t g0 = 0; g0 < n_groups; g0 += 64) {
+        const uint32_t g = g0 + (uint32_t)lane, p0 = g * 16;
+        const uint4 x = *reinterpret_cast<const uint4 *>(&L.txt[p0 < (uint32_t)kDCap ? p0 : 0]);
+        uint32_t sp_all = 0, pn_all = 0, ct_all = 0, hi_all = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t w = q == 0 ? x.x : (q == 1 ? x.y : (q == 2 ? x.z : x.w)), x7 = w & 0x7F7F7F7Fu, hi = w & 0x80808080u;
+          // a byte below 0x80 lies in [lo, hi] iff bit 7 of (b + 0x80 - lo) is set and bit 7 of (b + 0x7F - hi) is not: no carry
+          // leaves a byte.  The ASCII ranges are checked against the class table on the host (dedup_front).
+#define SWT_IN(lo_, hi_) ((x7 + (0x80u - (lo_)) * 0x01010101u) & ~(x7 + (0x7Fu - (hi_)) * 0x01010101u))
+          uint32_t in_ws, in_pn = 0;
+          if (Mode == kDedupWp) {
+            in_ws = SWT_IN(0x09u, 0x0Du) | SWT_IN(0x1Cu, 0x20u);  // str.isspace
+          } else {
+            in_ws = SWT_IN(0x09u, 0x0Du) | SWT_IN(0x20u, 0x20u);  // the pre-tokenizer's whitespace ...
+            in_pn = SWT_IN(0x21u, 0x2Fu) | SWT_IN(0x3Au, 0x40u) | SWT_IN(0x5Bu, 0x60u) | SWT_IN(0x7Bu, 0x7Eu);  // ... and punctuation
+          }
+#undef SWT_IN
+          sp_all |= dd_nibble(in_ws & ~hi & 0x80808080u) << (4 * q);
+          if (kPunctSplits) pn_all |= dd_nibble(in_pn & ~hi & 0x80808080u) << (4 * q);
+          ct_all |= dd_nibble(hi & ~(w << 1)) << (4 * q);  // 10xxxxxx: a continuation byte
+          hi_all |= dd_nibble(hi & (w << 1)) << (4 * q);   // 11xxxxxx: a lead byte whose class the table knows
+        }
+        // my 16 bytes' place in [off0, staged)
+        const uint32_t lo = off0 > p0 ? (off0 - p0 < 16u ? off0 - p0 : 16u) : 0u;
+        const uint32_t hi_n = staged > p0 ? (staged - p0 < 16u ? staged - p0 : 16u) : 0u;
+        const uint32_t inr16 = (((1u << hi_n) - 1u) & ~((1u << lo) - 1u)) & 0xFFFFu;
+        uint32_t sp16 = sp_all & inr16, pn16 = pn_all & inr16;
+        const uint32_t ct16 = ct_all & inr16;
+        // the non-ASCII lead bytes: decode and look up, as the byte-lane loop does for every byte
+        for (uint32_t m = hi_all & inr16; m; m &= m - 1u) {
+          const uint32_t j = (uint32_t)__builtin_ctz(m), p = p0 + j;
+          const uint8_t b = L.txt[p];
+          int len = utf8_len(b);
+          if (p + len > staged) len = (int)(staged - p);
+          uint32_t cp = b;
+          if (len > 1) {
+            cp = b & (0xFF >> (len + 1));
+            for (int i = 1; i < len; i++) cp = (cp << 6) | (L.txt[p + i] & 0x3F);
+          }
+          const uint8_t c = cp < (uint32_t)kClsLds ? L.cls_lo[cp] : (cp < kNumCodePoints ? cls_tab[cp] : (uint8_t)0);
+          if (c & kWsBit) sp16 |= 1u << j;
+          if (kPunctSplits && (c & kClsPunct)) pn16 |= 1u << j;
+        }
+        const uint32_t wsm16 = (sp16 | ~inr16) & 0xFFFFu;  // bytes outside the chunk behave as whitespace
+        const uint32_t lead16 = ~ct16 & 0xFFFFu;
+        // whitespace smear over continuation bytes and "the byte before me", with the lane below as the low half of a window
+        const uint32_t raw16 = wsm16 | pn16;  // bytes of whitespace / punctuation characters, before the smear
+        uint32_t below_wb = __shfl_up(raw16, 1), below_ct = __shfl_up(ct16, 1);
+        if (lane == 0) { below_wb = carry_wb; below_ct = carry_ct; }
+        const uint32_t c32 = below_ct | (ct16 << 16);
+        uint32_t wb32 = below_wb | (raw16 << 16);
+        wb32 |= (wb32 << 1) & c32;
+        wb32 |= (wb32 << 1) & c32;
+        wb32 |= (wb32 << 1) & c32;
+        const uint32_t ss16 = reinterpret_cast<const uint16_t *>(L.sbits)[g < (uint32_t)(kDBlocks + 1) * 4u ? g : 0];
+        const uint32_t first16 = g == 0 ? (1u << off0) : 0u;
+        const uint32_t before16 = ((wb32 >> 15) | ss16 | first16) & 0xFFFFu;
+        const uint32_t sym16 = lead16 & ~wsm16 & inr16;
+        const uint32_t ws16 = sym16 & (pn16 | before16);
+        // chunk cut candidates: word boundaries strictly inside, with room for a whole UTF-8 char behind them
+        const uint32_t c_lo = off0 + 1u > p0 ? (off0 + 1u - p0 < 16u ? off0 + 1u - p0 : 16u) : 0u;
+        const uint32_t c_hi = staged >= p0 + 4u ? (staged - 3u - p0 < 16u ? staged - 3u - p0 : 16u) : 0u;  // p + 4 <= staged
+        const uint32_t cutr16 = (c_hi > c_lo ? (((1u << c_hi) - 1u) & ~((1u << c_lo) - 1u)) : 0u) & 0xFFFFu;
+        const uint32_t cut16 = lead16 & (wsm16 | pn16 | ss16) & cutr16 & inr16;
+        const unsigned long long CUTL = __ballot(cut16 != 0u);
+        if (CUTL) {
+          const int src = 63 - __builtin_clzll(CUTL);
+          const uint32_t top = __shfl(cut16, src);
+          cut = (int)((g0 + (uint32_t)src) * 16u + 31u - (uint32_t)__builtin_clz(top));
+        }
+        // words: ranks by a wave scan of the lanes' counts
+        const uint32_t n_mine = (uint32_t)__popc(ws16);
+        uint32_t incl = n_mine;
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t y = __shfl_up(incl, d);
+          if (lane >= d) incl += y;
+        }
+        uint32_t at = nw + incl - n_mine;
+        if (g < n_groups) {
+          reinterpret_cast<uint16_t *>(L.endm)[g] = (uint16_t)(wsm16 | ws16);
+          reinterpret_cast<uint16_t *>(L.wst)[g] = (uint16_t)ws16;
+          if ((g & 3u) == 0u) L.nwb[g >> 2] = at;
+          for (uint32_t m = ws16; m; m &= m - 1u) L.wl[at++] = (uint16_t)(p0 + (uint32_t)__builtin_ctz(m));
+        }
+        nw += __shfl(incl, 63);
+        carry_wb = __shfl(raw16, 63);
+        carry_ct = __shfl(ct16, 63);
+      }
+    } else
     for (uint32_t blk = 0; blk < nblk; blk++) {
       const uint32_t p = blk * 64 + lane;
       const bool inr = p >= off0 && p < staged;
@@ -759,10 +870,29 @@ int dedup_front(DedupEngine &E, TileWorkspace &ws, const uint8_t *d_text, uint64
   uint64_t *plan1 = ws.plan.as<uint64_t>();
   unsigned long long *new_local = E.new_local.as<unsigned long long>(), *new_blk = E.new_blk.as<unsigned long long>();
   launch_plan(d_sent_off, n_sent, n_tiles, kDTile, plan1, st);
+  // the lane-per-16-bytes split knows str.isspace in ASCII as two ranges: if the class table ever says otherwise, or on request
+  // (SWT_DD_OLD_SPLIT=1), the byte-lane loop runs
+  static const bool ascii_ok = [] {
+    const uint8_t *cls = host_class_table();
+    for (uint32_t c = 0; c < 128; c++) {
+      if (((cls[c] & kClsPySpace) != 0) != ((c >= 0x09 && c <= 0x0D) || (c >= 0x1C && c <= 0x20))) return false;
+      if (((cls[c] & kClsWs) != 0) != ((c >= 0x09 && c <= 0x0D) || c == 0x20)) return false;
+      if (((cls[c] & kClsPunct) != 0) != ((c >= 0x21 && c <= 0x2F) || (c >= 0x3A && c <= 0x40) || (c >= 0x5B && c <= 0x60) || (c >= 0x7B && c <= 0x7E))) return false;
+    }
+    return true;
+  }();
+  const char *old_split = getenv("SWT_DD_OLD_SPLIT");
+  const uint32_t split_flag = (!ascii_ok || (old_split && *old_split && *old_split != '0')) ? 0x80000000u : 0u;
   prof_begin(st, 3);
-  if (mode == kDedupWp)
+  if (mode == kDedupWp && !split_flag)
+    hipLaunchKernelGGL((wordref_kernel<kDedupWp, true>), dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off, plan1, d_cls, D,
+                       wref, ws.sent_local.as<uint32_t>(), E.tile_words.as<uint32_t>(), (uint32_t)ablation_knob(2));
+  else if (mode == kDedupWp)
     hipLaunchKernelGGL(wordref_kernel<kDedupWp>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off, plan1, d_cls, D, wref,
                        ws.sent_local.as<uint32_t>(), E.tile_words.as<uint32_t>(), (uint32_t)ablation_knob(2));
+  else if (!split_flag)
+    hipLaunchKernelGGL((wordref_kernel<kDedupBpe, true>), dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off, plan1, d_cls, D,
+                       wref, ws.sent_local.as<uint32_t>(), E.tile_words.as<uint32_t>(), (uint32_t)ablation_knob(2));
   else
     hipLaunchKernelGGL(wordref_kernel<kDedupBpe>, dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off, plan1, d_cls, D, wref,
                        ws.sent_local.as<uint32_t>(), E.tile_words.as<uint32_t>(), (uint32_t)ablation_knob(2));
