@@ -582,27 +582,14 @@ __global__ __launch_bounds__(64) void refcount_kernel(const uint64_t *__restrict
   if (s_lo != s_hi) {
     uint32_t *my_rec = wref + sent_off[s_lo];
     const uint32_t n_w = tile_words[t];
-    constexpr int kB = 4;  // records per lane and trip, their table lookups in flight together (see wp_refs_kernel)
-    for (uint32_t k0 = 0; k0 < n_w; k0 += 64 * kB) {
-      uint32_t v[kB];
-      unsigned long long r[kB];
-#pragma unroll
-      for (int u = 0; u < kB; u++) {
-        const uint32_t k = k0 + (uint32_t)u * 64u + threadIdx.x;
-        v[u] = k < n_w ? my_rec[k] : 0u;
-      }
-#pragma unroll
-      for (int u = 0; u < kB; u++) r[u] = (v[u] & kRefSlot) ? rec[v[u] & ~kRefSlot] : 0ull;  // count:32 | unique index:32
-#pragma unroll
-      for (int u = 0; u < kB; u++) {
-        const uint32_t k = k0 + (uint32_t)u * 64u + threadIdx.x;
-        if (k >= n_w) continue;
-        if (v[u] & kRefSlot) {
-          total += (uint32_t)(r[u] >> 32);
-          my_rec[k] = kRefSlot | (uint32_t)r[u];
-        } else {
-          total += 1;
-        }
+    for (uint32_t k = threadIdx.x; k < n_w; k += 64) {
+      const uint32_t v = my_rec[k];
+      if (v & kRefSlot) {
+        const unsigned long long r = rec[v & ~kRefSlot];  // count:32 | unique index:32
+        total += (uint32_t)(r >> 32);
+        my_rec[k] = kRefSlot | (uint32_t)r;
+      } else {
+        total += 1;
       }
     }
     for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
@@ -632,47 +619,24 @@ __global__ __launch_bounds__(64) void refwrite_kernel(const uint64_t *__restrict
   uint32_t run = 0;
   for (uint32_t k0 = 0;; k0 += kDCap) {
     const uint32_t k1 = n_w - k0 > (uint32_t)kDCap ? k0 + kDCap : n_w;
-    constexpr int kB = 4;  // records per lane and trip: record -> dense entry -> tokens, each stage's loads in flight together
-    for (uint32_t j0 = k0; j0 < k1; j0 += 64 * kB) {
-      uint32_t v[kB], n[kB], ex[kB];
-      uint64_t src[kB];
-#pragma unroll
-      for (int u = 0; u < kB; u++) {
-        const uint32_t j = j0 + (uint32_t)u * 64u + (uint32_t)lane;
-        v[u] = j < k1 ? my_rec[j] : 0u;
+    for (uint32_t j0 = k0; j0 < k1; j0 += 64) {
+      const uint32_t j = j0 + lane;
+      uint64_t src = 0;
+      uint32_t v = 0, n = 0;
+      if (j < k1) {
+        v = my_rec[j];
+        n = ref_count_dense(v, rec, src);
       }
-#pragma unroll
-      for (int u = 0; u < kB; u++) {
-        const uint32_t j = j0 + (uint32_t)u * 64u + (uint32_t)lane;
-        src[u] = 0;
-        n[u] = j < k1 ? ref_count_dense(v[u], rec, src[u]) : 0u;
+      uint32_t x = n;
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= d) x += y;
       }
-#pragma unroll
-      for (int u = 0; u < kB; u++) {
-        if (j0 + (uint32_t)u * 64u >= k1) { ex[u] = run; continue; }  // (wave-uniform)
-        const uint32_t j = j0 + (uint32_t)u * 64u + (uint32_t)lane;
-        uint32_t x = n[u];
-        for (int d = 1; d < 64; d <<= 1) {
-          const uint32_t y = __shfl_up(x, d);
-          if (lane >= d) x += y;
-        }
-        ex[u] = run + x - n[u];
-        if (j < k1) pre[j - k0] = ex[u];
-        run += __shfl(x, 63);
-      }
-      for (uint32_t i = 0;; i++) {  // token i of every word of the batch
-        uint32_t tk[kB];
-        bool any = false;
-#pragma unroll
-        for (int u = 0; u < kB; u++) {
-          tk[u] = v[u];  // a one-symbol word is its own token
-          if (i < n[u]) { if (v[u] & kRefSlot) tk[u] = u_ids[src[u] + i]; any = true; }
-        }
-        if (!any) break;
-#pragma unroll
-        for (int u = 0; u < kB; u++)
-          if (i < n[u]) out_ids[base + ex[u] + i] = tk[u];
-      }
+      const uint32_t ex = run + x - n;
+      if (j < k1) pre[j - k0] = ex;
+      if (n == 1 && !(v & kRefSlot)) out_ids[base + ex] = v;
+      else for (uint32_t i = 0; i < n; i++) out_ids[base + ex + i] = u_ids[src + i];
+      run += __shfl(x, 63);
     }
     __syncthreads();
     // sentences whose first word lies in [k0, k1) -- and, on the last chunk, those behind the last word
@@ -759,33 +723,13 @@ __global__ __launch_bounds__(64) void wp_refs_kernel(const uint64_t *__restrict_
   }
   bool any_bad = false;
   uint32_t my_sum = 0;
-  // kRefBatch word records per lane and trip, each stage's loads in flight together (record -> its table / dense entry): the
-  // waves of these two launches waited 88 % of their cycles (profiles/r03_sq_counters.txt) on chains of three dependent loads
-  // per 64 words
-  constexpr int kRefBatch = 4;
-  for (uint32_t k0 = 0; k0 < n_w; k0 += 64 * kRefBatch) {
-    uint32_t v[kRefBatch];
-    unsigned long long r[kRefBatch];
-#pragma unroll
-    for (int u = 0; u < kRefBatch; u++) {
-      const uint32_t k = k0 + (uint32_t)u * 64u + (uint32_t)lane;
-      v[u] = k < n_w ? my_rec[k] : kRefSlot;
-    }
-#pragma unroll
-    for (int u = 0; u < kRefBatch; u++) {
-      const uint32_t k = k0 + (uint32_t)u * 64u + (uint32_t)lane;
-      r[u] = k < n_w ? rec[v[u] & ~kRefSlot] : 0ull;
-    }
-#pragma unroll
-    for (int u = 0; u < kRefBatch; u++) {
-      const uint32_t k = k0 + (uint32_t)u * 64u + (uint32_t)lane;
-      if (k >= n_w) continue;
-      if (!Write) my_rec[k] = kRefSlot | (uint32_t)r[u];
-      const uint32_t c = (uint32_t)(r[u] >> 32);
-      cnt[k] = c;
-      any_bad |= c == kRecFailed;
-      my_sum += c;
-    }
+  for (uint32_t k = lane; k < n_w; k += 64) {
+    const unsigned long long r = rec[my_rec[k] & ~kRefSlot];
+    if (!Write) my_rec[k] = kRefSlot | (uint32_t)r;
+    const uint32_t c = (uint32_t)(r >> 32);
+    cnt[k] = c;
+    any_bad |= c == kRecFailed;
+    my_sum += c;
   }
   any_bad = __any(any_bad);
   __syncthreads();
@@ -810,46 +754,21 @@ __global__ __launch_bounds__(64) void wp_refs_kernel(const uint64_t *__restrict_
     }
   }
   uint32_t run = 0;
-  for (uint32_t k0 = 0; k0 < n_w; k0 += 64 * kRefBatch) {
-    uint32_t n[kRefBatch], ex[kRefBatch], v[kRefBatch];
-    uint64_t src[kRefBatch];
-#pragma unroll
-    for (int u = 0; u < kRefBatch; u++) {
-      const uint32_t k = k0 + (uint32_t)u * 64u + (uint32_t)lane;
-      n[u] = k < n_w ? cnt[k] : 0u;
-      v[u] = (Write && k < n_w) ? my_rec[k] : kRefSlot;  // (read a moment ago: L1 / L2)
+  for (uint32_t k0 = 0; k0 < n_w; k0 += 64) {
+    const uint32_t k = k0 + lane;
+    const uint32_t n = k < n_w ? cnt[k] : 0u;
+    uint32_t x = n;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(x, d);
+      if (lane >= d) x += y;
     }
-#pragma unroll
-    for (int u = 0; u < kRefBatch; u++) src[u] = (Write && n[u]) ? (rec[v[u] & ~kRefSlot] & 0xFFFFFFFFull) : 0ull;
-#pragma unroll
-    for (int u = 0; u < kRefBatch; u++) {
-      if (k0 + (uint32_t)u * 64u >= n_w) { ex[u] = run; continue; }  // (wave-uniform)
-      const uint32_t k = k0 + (uint32_t)u * 64u + (uint32_t)lane;
-      uint32_t x = n[u];
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-      }
-      ex[u] = run + x - n[u];
-      if (k < n_w) cnt[k] = ex[u];
-      run += __shfl(x, 63);
+    const uint32_t ex = run + x - n;
+    if (k < n_w) cnt[k] = ex;
+    if (Write && n) {
+      const uint64_t src = rec[my_rec[k] & ~kRefSlot] & 0xFFFFFFFFull;
+      for (uint32_t i = 0; i < n; i++) out_ids[base + ex + i] = u_ids[src + i];
     }
-    if (Write) {
-      // token i of every word of the batch: the loads of a trip in flight together, then the stores
-      for (uint32_t i = 0;; i++) {
-        uint32_t tk[kRefBatch];
-        bool any = false;
-#pragma unroll
-        for (int u = 0; u < kRefBatch; u++) {
-          tk[u] = 0;
-          if (i < n[u]) { tk[u] = u_ids[src[u] + i]; any = true; }
-        }
-        if (!any) break;
-#pragma unroll
-        for (int u = 0; u < kRefBatch; u++)
-          if (i < n[u]) out_ids[base + ex[u] + i] = tk[u];
-      }
-    }
+    run += __shfl(x, 63);
   }
   __syncthreads();
   if (!Write) {
