@@ -31,7 +31,7 @@ with open(out, "w") as o:
     o.write("kernel,launches,mean_%s_KiB_per_launch,total_KiB\n" % sys.argv[2])
     tot = 0.0
     for k, v in sorted(per.items()):
-        o.write("%s,%d,%.1f,%.1f\n" % (k, len(v), sum(v) / len(v), sum(v)))
+        o.write("%s,%d,%.1f,%.1f\n" % (k, len(v), sum(v) / len(v), sum(v)))  # (kernel names hold commas -- template arguments: read from the right)
         tot += sum(v)
     o.write("ALL swt kernels,,,%.1f\n" % tot)
 print(open(out).read()[:1800])
