@@ -20,7 +20,10 @@
 //          and only symbols next to a merge probe the table again -- one L2 round trip per round for the wave
 //     E/F  order-preserving ballot compaction to the tile's output run, per-sentence offsets
 // A word longer than a chunk falls to a one-lane global-memory path (correct, slow, pathological inputs only).
+#include <cstdlib>
 #include <cstring>
+#include <unordered_map>
+#include <utility>
 
 #include "swt_dedup.h"
 #include "swt_tile.h"
@@ -50,38 +53,59 @@ constexpr int kClsLds = SWT_CLS_LDS;    // code points whose class is served fro
 constexpr int kBpeTile = SWT_BPE_TILE;   // bytes of sentence starts per tile.  Measured on S85k-open with 256-byte chunks (tools/gpu_enc_sweep.sh):
                                          // 96: 489 us, 128: 481, 160: 467, 192: 453, 224: 456, 256: 460; 512-byte chunks: 558 (fewer resident waves)
 constexpr int kBpeCap = SWT_BPE_CAP;    // staged bytes per chunk
+#ifndef SWT_LANE_TILE
+#define SWT_LANE_TILE 384
+#endif
+#ifndef SWT_LANE_CAP
+#define SWT_LANE_CAP 512
+#endif
+constexpr int kLaneTile = SWT_LANE_TILE;  // the word-lane kernel (bpe_lane_kernel): bytes of sentence starts per tile ...
+constexpr int kLaneCap = SWT_LANE_CAP;    // ... and staged bytes per chunk (a batch of 64 word lanes wants ~350 bytes of text)
 constexpr uint64_t kDirectBytes = 1024, kDirectSents = 64;  // up to here one workgroup and one launch do the whole call
 constexpr uint32_t kNoPos = 0xFFFFu;
 
-__device__ __forceinline__ bool slot_lookup(const BpeSlot *__restrict__ slots, uint32_t bits, uint32_t l, uint32_t r,
-                                            uint32_t &rank, uint32_t &merged) {
-  const uint64_t key = pair_key(l, r);
-  const uint32_t mask = (1u << bits) - 1u;
-  uint32_t h = hash_slot(key, bits);
-  for (;;) {
-    const uint4 raw = *reinterpret_cast<const uint4 *>(&slots[h]);
-    const uint64_t k = ((uint64_t)raw.y << 32) | raw.x;
-    if (k == key) { rank = raw.z; merged = raw.w; return true; }
-    if (k == kEmptyKey) return false;
-    h = (h + 1) & mask;
-  }
+// The rank table is a two-choice cuckoo table (built once on the host, swt_bpe_table_create): a pair lives in slot h1 or in
+// slot h2, so a lookup is two independent 16-byte loads and two compares -- no probe loop, and a wave never goes round
+// again because one of its lanes met a collision.  The hashes are 24-bit multiplies (full-rate v_mul_u32_u24; symbol ids
+// are below 2^24 for any table under five million merges, larger ids only hash worse) with one xor-shift between them.
+struct BpeHash { uint32_t a, b, c; };
+constexpr BpeHash kHash1{0x9E3779u, 0x85EBCBu, 0xC2B2AFu}, kHash2{0x27D4EBu, 0x165667u, 0x9E3779u};
+__host__ __device__ __forceinline__ uint32_t bpe_hash(uint32_t l, uint32_t r, uint32_t sh, BpeHash k) {
+  uint32_t x = (l & 0xFFFFFFu) * k.a + (r & 0xFFFFFFu) * k.b;
+  x ^= x >> 16;
+  return ((x & 0xFFFFFFu) * k.c) >> sh;   // sh = 32 - log2(slots)
 }
 
-__device__ __forceinline__ uint32_t slot_value(const BpeSlot *__restrict__ slots, uint32_t bits, uint32_t l, uint32_t r) {
-  uint32_t v, m;
-  return slot_lookup(slots, bits, l, r, v, m) ? v : kNoRank;
+__device__ __forceinline__ bool slot_lookup(const BpeSlot *__restrict__ slots, uint32_t sh, uint32_t l, uint32_t r,
+                                            uint32_t &rank, uint32_t &merged) {
+  const uint4 r1 = *reinterpret_cast<const uint4 *>(&slots[bpe_hash(l, r, sh, kHash1)]);
+  const uint4 r2 = *reinterpret_cast<const uint4 *>(&slots[bpe_hash(l, r, sh, kHash2)]);
+  const bool h1 = r1.x == r && r1.y == l, h2 = r2.x == r && r2.y == l;
+  rank = h1 ? r1.z : r2.z;
+  merged = h1 ? r1.w : r2.w;
+  return h1 || h2;
+}
+
+__device__ __forceinline__ uint32_t slot_value(const BpeSlot *__restrict__ slots, uint32_t sh, uint32_t l, uint32_t r) {
+  const uint4 r1 = *reinterpret_cast<const uint4 *>(&slots[bpe_hash(l, r, sh, kHash1)]);
+  const uint4 r2 = *reinterpret_cast<const uint4 *>(&slots[bpe_hash(l, r, sh, kHash2)]);
+  // both loads are issued before either is looked at; a pair lives in at most one slot and kNoRank is all ones, so the two
+  // selects combine with AND (written as a select of a select the compiler makes the second load wait for the first compare)
+  const uint32_t a = (r1.x == r && r1.y == l) ? r1.z : kNoRank;
+  const uint32_t b = (r2.x == r && r2.y == l) ? r2.z : kNoRank;
+  return a & b;
 }
 
 // FastBPE.encode_word on a symbol array (bpe.py:210-238), serial form for the one-lane fallback: repeat { lowest-rank
 // adjacent pair; replace all of its occurrences left to right, non-overlapping }.  Returns the new length.
-__device__ uint32_t merge_word(uint32_t *s, uint32_t n, const BpeSlot *__restrict__ slots, uint32_t bits) {
+__device__ uint32_t merge_word(uint32_t *s, uint32_t n, const BpeSlot *__restrict__ slots, uint32_t sh) {
   while (n >= 2) {
     uint32_t best = 0xFFFFFFFFu, bm = 0, bl = 0, br = 0;
     uint32_t a = s[0];
     for (uint32_t i = 0; i + 1 < n; i++) {
       const uint32_t b = s[i + 1];
       uint32_t rk, mg;
-      if (slot_lookup(slots, bits, a, b, rk, mg) && rk < best) { best = rk; bm = mg; bl = a; br = b; }
+      if (slot_lookup(slots, sh, a, b, rk, mg) && rk < best) { best = rk; bm = mg; bl = a; br = b; }
       a = b;
     }
     if (best == 0xFFFFFFFFu) break;
@@ -101,7 +125,7 @@ struct GiantResult { uint64_t end; uint32_t ntok; };
 // One lane, global memory only: the word (or single separator) starting at byte `pos`, bounded by
 // `send` (end of its sentence).  Tokens go to `out` (which doubles as the symbol workspace).
 __device__ GiantResult giant_word(const uint8_t *__restrict__ text, uint64_t pos, uint64_t send,
-                                  const uint8_t *__restrict__ cls_tab, const BpeSlot *__restrict__ slots, uint32_t bits,
+                                  const uint8_t *__restrict__ cls_tab, const BpeSlot *__restrict__ slots, uint32_t sh,
                                   uint32_t *out) {
   GiantResult r{pos, 0};
   uint32_t n = 0;
@@ -122,7 +146,7 @@ __device__ GiantResult giant_word(const uint8_t *__restrict__ text, uint64_t pos
     r.end += len;
     first = false;
   }
-  n = merge_word(out, n, slots, bits);
+  n = merge_word(out, n, slots, sh);
   for (uint32_t i = 1; i < n; i++) out[i] |= SWT_BPE_CONT;
   r.ntok = n;
   return r;
@@ -160,7 +184,7 @@ template <bool Packed, int Cap, int Mode>
 __global__ __launch_bounds__(64) void bpe_encode_kernel(
     const uint8_t *__restrict__ text, uint64_t n_bytes, const uint64_t *__restrict__ sent_off,
     const uint64_t *__restrict__ plan, const uint8_t *__restrict__ cls_tab, const BpeSlot *__restrict__ slots,
-    uint32_t bits, const uint32_t *__restrict__ merged_of_rank, uint32_t *__restrict__ scratch,
+    uint32_t sh, const uint32_t *__restrict__ merged_of_rank, uint32_t *__restrict__ scratch,
     uint32_t *__restrict__ sent_local, uint32_t *__restrict__ tile_tok, const uint32_t *__restrict__ uslot,
     unsigned long long *__restrict__ rec, unsigned long long *__restrict__ drec, DirectOut direct, uint32_t dbg_arg) {
 #ifdef SWT_ABLATION
@@ -315,7 +339,7 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
           uint64_t s = s_next;
           while (s < s_hi && sent_off[s] <= cb) s++;
           const uint64_t send = sent_off[s];  // s <= s_hi and sent_off[s_hi] = span_end > cb
-          L.giant = giant_word(text, cb, send, cls_tab, slots, bits, tile_out + run);
+          L.giant = giant_word(text, cb, send, cls_tab, slots, sh, tile_out + run);
         }
         __syncthreads();
         const GiantResult g = L.giant;
@@ -355,9 +379,8 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
     // ---- C2. the table value of every adjacent pair of every listed symbol: the whole first merge round
     // (bpe.py:211-219), four independent probes in flight per lane; each value also goes into its word's minimum
     for (uint32_t k0 = 0; k0 < na; k0 += 256) {
-      uint32_t pl[4], pr[4], hh[4], hd[4];
+      uint32_t pl[4], pr[4], hd[4];
       bool want[4];
-      uint4 raw[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const uint32_t k = k0 + u * 64 + lane;
@@ -374,21 +397,15 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
             pr[u] = L.sym[qn];
           }
         }
-        hh[u] = want[u] ? hash_slot(pair_key(pl[u], pr[u]), bits) : 0u;
       }
+      uint32_t vv[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) raw[u] = *reinterpret_cast<const uint4 *>(&slots[hh[u]]);
+      for (int u = 0; u < 4; u++) vv[u] = slot_value(slots, sh, pl[u], pr[u]);
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const uint32_t k = k0 + u * 64 + lane;
-        uint32_t v = kNoRank;
-        if (want[u]) {
-          const uint64_t key = pair_key(pl[u], pr[u]);
-          const uint64_t kk = ((uint64_t)raw[u].y << 32) | raw[u].x;
-          if (kk == key) v = raw[u].z;
-          else if (kk != kEmptyKey) v = slot_value(slots, bits, pl[u], pr[u]);
-          if (v != kNoRank && !(dbg & 8)) atomicMin(&L.wm[0][hd[u]], v);
-        }
+        const uint32_t v = want[u] ? vv[u] : kNoRank;
+        if (v != kNoRank && !(dbg & 8)) atomicMin(&L.wm[0][hd[u]], v);
         if (k < na) L.aval[k] = v;
       }
     }
@@ -447,7 +464,7 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
           const uint32_t sr = taken ? (tk2 ? mg : sy2) : (tk1 ? mg : sy1);
           uint32_t vn = v;
           if (!has_r) vn = kNoRank;
-          else if (taken || tk1) vn = slot_value(slots, bits, sn, sr);
+          else if (taken || tk1) vn = slot_value(slots, sh, sn, sr);
           __syncthreads();  // the reset of the next round's minima (above) comes before the lanes feed them
           if (keep && vn != kNoRank) atomicMin(&L.wm[cur ^ 1][hw], vn);
           const unsigned long long KEEP = __ballot(keep);
@@ -545,7 +562,7 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
                 dirty = nq != kNoPos && bit_at(L.tk, nq);
               }
               if (nq == kNoPos) v = kNoRank;
-              else if (dirty) v = slot_value(slots, bits, sp, bit_at(L.tk, nq) ? mg : L.sym[nq]);
+              else if (dirty) v = slot_value(slots, sh, sp, bit_at(L.tk, nq) ? mg : L.sym[nq]);
               if (v != kNoRank) atomicMin(&L.wm[cur ^ 1][h >> 1], v);
             }
           }
@@ -609,6 +626,383 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
 }
 
 
+// ======================================================================================================================
+// bpe_lane_kernel -- the word-lane form of the same call (round 3; the default).
+//
+// The kernel above keeps one lane per BYTE through the merge rounds: a round costs the wave the same ~170 instructions
+// whether 64 symbols take part or three, and a tile goes through as many rounds as its longest word has merges (the SQ
+// counters of round 2: 19.7 scalar + 14 vector instructions per input byte, the scalar pipe bound).  Here the split stays
+// byte-parallel (ballots), but it leaves the symbols DENSE (indexed by symbol, not by byte) together with the table value of
+// every adjacent pair (probed right there, all lanes at once), and then one lane owns one WORD:
+//   W    the multi-symbol words of the chunk, sorted into three length classes so that the 64 words of a batch run a
+//        similar number of rounds
+//   D    lane = word.  The word's slots stay where the split put them; a 32-bit mask says which are still live.  A round =
+//        leftmost minimum over the live slots' cached pair values (four slots per step) -> the pair merges in place, its
+//        right slot dies, and the two pairs next to the merged symbol are probed again (two lookups in flight).  On a
+//        PROPER table (every pair ranks above the merges that produce its symbols: any trained table) merging one
+//        occurrence per round is the reference's "all occurrences of the best pair, left to right" (bpe.py:221-235) --
+//        what is left of the pair is still the minimum and is found leftmost-first in the next round.  Tables without that
+//        property, and words beyond 32 symbols, take slow_word(): the same loop in its literal form (all occurrences per
+//        round, compaction), one lane per word.
+//   E/F  ballot compaction over the SYMBOL space, sentence offsets through the split's symbol masks.
+// Token ids, offsets and the launches around the kernel (plan, scan, gather / the dedup records) are those of the kernel above.
+template <int Cap>
+struct LaneLds {
+  static constexpr int Blocks = Cap / 64;
+  __attribute__((aligned(16))) uint8_t txt[Cap + 16];
+  uint32_t sym[Cap + 4];      // per symbol: id (| SWT_BPE_CONT unless it opens its word), kInvalidTok once consumed
+  uint32_t val[Cap + 4];      // per symbol: table value of (this symbol, next live symbol of the word), kNoRank when none
+  uint32_t wl2[Cap / 2 + 1];  // multi-symbol words by length class: first symbol | symbols << 16
+  uint16_t wl[Cap + 2];       // first symbol of every word, in text order
+  unsigned long long sbits[Blocks + 1];    // sentence-start bit per byte
+  unsigned long long symmask[Blocks + 1];  // symbol bit per byte
+  unsigned long long vmask[Blocks + 1];    // phase E: live-token bit per symbol
+  uint32_t sympre[Blocks + 1];             // symbols before each 64-byte block
+  uint32_t blkpre[Blocks + 1];             // tokens before each block of 64 symbols
+  uint32_t cls2[64];                       // classes of U+0000..U+03FF, two bits each
+  GiantResult giant;
+};
+
+constexpr uint32_t kDirtyVal = 0xFFFFFFFEu;  // above every table value (ranks stay below 2^32 - 2), below kNoRank
+
+// bpe.py:210-238 on one word whose symbols S[0..n) and pair values V[0..n) (V[n-1] = kNoRank) live in LDS: every round merges
+// ALL occurrences of the best pair left to right, compacts the word and probes only the pairs that changed.
+template <bool Packed>
+__device__ void slow_word(uint32_t *S, uint32_t *V, const uint32_t n0, const BpeSlot *__restrict__ slots, uint32_t sh,
+                          const uint32_t *__restrict__ merged_of_rank) {
+  uint32_t n = n0;
+  for (;;) {
+    uint32_t m = kNoRank;
+    for (uint32_t i = 0; i + 1 < n; i++) m = min(m, V[i]);
+    if (m == kNoRank) break;
+    const uint32_t mg = Packed ? (SWT_SYM_BASE + (m & 0xFFFFu)) : merged_of_rank[m];
+    uint32_t i = 0, j = 0;
+    while (i < n) {
+      const uint32_t vi = V[i];
+      const bool take = i + 1 < n && vi == m;
+      const uint32_t s = take ? mg : (S[i] & ~SWT_BPE_CONT);
+      if (take && j) V[j - 1] = kDirtyVal;
+      S[j] = j ? (s | SWT_BPE_CONT) : s;
+      V[j] = take ? kDirtyVal : vi;
+      i += take ? 2u : 1u;
+      j++;
+    }
+    n = j;
+    V[n - 1] = kNoRank;
+    for (uint32_t k = 0; k + 1 < n; k++)
+      if (V[k] == kDirtyVal) V[k] = slot_value(slots, sh, S[k] & ~SWT_BPE_CONT, S[k + 1] & ~SWT_BPE_CONT);
+  }
+  for (uint32_t k = n; k < n0; k++) S[k] = kInvalidTok;
+}
+
+template <bool Packed, bool Proper, int Cap, int Mode>
+__global__ __launch_bounds__(64) void bpe_lane_kernel(
+    const uint8_t *__restrict__ text, uint64_t n_bytes, const uint64_t *__restrict__ sent_off,
+    const uint64_t *__restrict__ plan, const uint8_t *__restrict__ cls_tab, const BpeSlot *__restrict__ slots,
+    uint32_t sh, const uint32_t *__restrict__ merged_of_rank, uint32_t *__restrict__ scratch,
+    uint32_t *__restrict__ sent_local, uint32_t *__restrict__ tile_tok, const uint32_t *__restrict__ uslot,
+    unsigned long long *__restrict__ rec, unsigned long long *__restrict__ drec, DirectOut direct) {
+  constexpr bool kDirect = Mode == 2, kRec = Mode == 1;
+  constexpr int Blocks = Cap / 64;
+  __shared__ LaneLds<Cap> L;
+  const int lane = threadIdx.x;
+  const unsigned long long lt = (1ull << lane) - 1ull;  // lanes below me
+  const unsigned long long le = (2ull << lane) - 1ull;  // me and below
+  const uint64_t t = blockIdx.x;
+  const uint64_t s_lo = kDirect ? 0 : plan[t], s_hi = kDirect ? direct.n_sent : plan[t + 1];
+  if (s_lo == s_hi) {
+    if (Mode == 0 && lane == 0) tile_tok[t] = 0;
+    return;
+  }
+  {
+    // classes of the first 1,024 code points: 16 per lane, two bits each (SWT_CLS_BERT_WS | SWT_CLS_BERT_PUNCT)
+    uint32_t w = 0;
+    if (cls_tab) {
+      const uint4 v = reinterpret_cast<const uint4 *>(cls_tab)[lane];
+      auto pk = [](uint32_t d) {
+        uint32_t x = d & 0x03030303u;
+        x = (x | (x >> 6)) & 0x000F000Fu;
+        return (x | (x >> 12)) & 0xFFu;
+      };
+      w = pk(v.x) | (pk(v.y) << 8) | (pk(v.z) << 16) | (pk(v.w) << 24);
+    }
+    L.cls2[lane] = w;
+  }
+  const uint64_t span_base = sent_off[s_lo], span_end = sent_off[s_hi];
+  uint32_t *const tile_out = scratch + span_base;
+  uint32_t run = 0;        // tokens emitted by this tile so far
+  uint64_t s_next = s_lo;  // first sentence whose local offset is not recorded yet
+  uint64_t cb = span_base;
+
+  for (;;) {
+    const uint64_t abase = cb & ~15ull;
+    const uint32_t off0 = (uint32_t)(cb - abase);
+    const uint64_t avail = span_end - abase;
+    const bool last = avail <= (uint64_t)Cap;
+    const uint32_t staged = last ? (uint32_t)avail : (uint32_t)Cap;
+    const uint32_t nblk = (staged + 63) >> 6;
+
+    // ---- A. stage [abase, abase+staged): one dwordx4 per lane
+    for (uint32_t c = lane * 16; c < staged; c += 64 * 16) {
+      const uint64_t g = abase + c;
+      if (g + 16 <= n_bytes && ((reinterpret_cast<uintptr_t>(text + g) & 15) == 0)) {
+        *reinterpret_cast<uint4 *>(&L.txt[c]) = *reinterpret_cast<const uint4 *>(text + g);
+      } else {
+        for (int i = 0; i < 16; i++) L.txt[c + i] = (g + i < n_bytes) ? text[g + i] : (uint8_t)' ';
+      }
+    }
+    if (lane <= Blocks) L.sbits[lane] = 0ull;
+    __syncthreads();
+    for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
+      const uint64_t o = sent_off[s];
+      if (o >= abase + staged) break;
+      if (o >= cb) atomicOr(&L.sbits[(o - abase) >> 6], 1ull << ((o - abase) & 63));
+    }
+    __syncthreads();
+
+    // ---- B/C. 64 bytes per step: classes, word structure from ballot masks (as in the kernel above), and the table value of
+    // every adjacent pair of a word.  Scalars carried from block to block:
+    uint32_t nsym = 0, nw = 0;  // symbols and words so far
+    bool prev_wb = true;        // the byte before this block belongs to a whitespace/punctuation char (or chunk start)
+    bool pend_open = false;     // the last symbol of the previous block may have its successor in this one
+    uint32_t pend_cp = 0;
+    int cut = -1;               // last word boundary (for a span longer than the chunk)
+    for (uint32_t blk = 0; blk < nblk; blk++) {
+      const uint32_t p = blk * 64 + lane;
+      const bool inr = p >= off0 && p < staged;
+      const uint8_t b = inr ? L.txt[p] : (uint8_t)' ';
+      const bool lead = !utf8_is_cont(b);
+      uint32_t cp = b;
+      if (b >= 0xC0) {
+        int len = utf8_len(b);
+        if (p + len > staged) len = (int)(staged - p);
+        if (len > 1) {
+          cp = b & (0xFF >> (len + 1));
+          for (int i = 1; i < len; i++) cp = (cp << 6) | (L.txt[p + i] & 0x3F);
+        }
+      }
+      uint32_t c = kClsWs;  // bytes outside the chunk behave as whitespace
+      if (inr && lead)
+        c = cp < 1024u ? ((L.cls2[cp >> 4] >> ((cp & 15u) << 1)) & 3u) : ((cls_tab && cp < kNumCodePoints) ? (cls_tab[cp] & 3u) : 0u);
+      const unsigned long long INR = __ballot(inr);
+      const unsigned long long LEAD = __ballot(lead);
+      const unsigned long long WSm = __ballot(lead && (c & kClsWs));
+      const unsigned long long PNm = __ballot(lead && (c & kClsPunct));
+      const unsigned long long CONT = ~LEAD;
+      unsigned long long WB = WSm | PNm | ((prev_wb && (CONT & 1ull)) ? 1ull : 0ull);
+      WB |= (WB << 1) & CONT;
+      WB |= (WB << 1) & CONT;
+      WB |= (WB << 1) & CONT;
+      const unsigned long long SS = L.sbits[blk];
+      const unsigned long long first_bit = blk == 0 ? (1ull << off0) : 0ull;  // off0 < 16
+      const unsigned long long before = (WB << 1) | (prev_wb ? 1ull : 0ull) | SS | first_bit;
+      const unsigned long long SYM = LEAD & ~WSm & INR;
+      const unsigned long long WSTART = SYM & (PNm | before);
+      {
+        const unsigned long long CUT = LEAD & (WSm | PNm | SS) & __ballot(inr && p > off0 && p + 4 <= staged);
+        if (CUT) cut = (int)(blk * 64 + 63 - __builtin_clzll(CUT));
+      }
+      const bool is_sym = (SYM >> lane) & 1ull;
+      const bool wstart = (WSTART >> lane) & 1ull;
+      const unsigned long long after = SYM & ~le;
+      const uint32_t q = after ? (uint32_t)__builtin_ctzll(after) : 64u;
+      const bool hasnext = is_sym && q < 64 && !((WSTART >> (q & 63)) & 1ull);
+      const uint32_t f = SYM ? (uint32_t)__builtin_ctzll(SYM) : 64u;
+      const bool joins = pend_open && f < 64 && !((WSTART >> (f & 63)) & 1ull);
+      const uint32_t si = nsym + (uint32_t)__popcll(SYM & lt);
+      const uint32_t cpn = __shfl(cp, (int)(q & 63));
+      // lane 63 never has a successor inside the block: it probes the pair that straddles the block boundary
+      const bool jp = joins && lane == 63;
+      const uint32_t cpf = __builtin_amdgcn_readlane(cp, (int)(f & 63));
+      const bool want = hasnext || jp;
+      uint32_t v = kNoRank;
+      if (want) v = slot_value(slots, sh, jp ? pend_cp : cp, jp ? cpf : cpn);
+      if (is_sym) {
+        L.sym[si] = wstart ? cp : (cp | SWT_BPE_CONT);
+        if (!hasnext) L.val[si] = kNoRank;
+      }
+      if (want) L.val[jp ? nsym - 1 : si] = v;
+      if (wstart) L.wl[nw + (uint32_t)__popcll(WSTART & lt)] = (uint16_t)si;
+      if (lane == 0) { L.symmask[blk] = SYM; L.sympre[blk] = nsym; }
+      nw += (uint32_t)__popcll(WSTART);
+      nsym += (uint32_t)__popcll(SYM);
+      if (SYM) {
+        const int li = 63 - __builtin_clzll(SYM);
+        const unsigned long long tail = li == 63 ? 0ull : ~((2ull << li) - 1ull);
+        pend_open = ((WSm | PNm | SS) & tail) == 0ull && !((PNm >> li) & 1ull);
+        pend_cp = __builtin_amdgcn_readlane(cp, li);
+      } else {
+        pend_open = false;  // a block without symbols holds whitespace: every word ended
+      }
+      prev_wb = (WB >> 63) & 1ull;
+    }
+    __syncthreads();
+
+    // ---- chunk end
+    uint32_t ce = staged;
+    if (!last) {
+      if (cut < 0) {
+        // a single word longer than the LDS chunk: one lane, global memory
+        if (lane == 0) {
+          uint64_t s = s_next;
+          while (s < s_hi && sent_off[s] <= cb) s++;
+          const uint64_t send = sent_off[s];  // s <= s_hi and sent_off[s_hi] = span_end > cb
+          L.giant = giant_word(text, cb, send, cls_tab, slots, sh, tile_out + run);
+        }
+        __syncthreads();
+        const GiantResult g = L.giant;
+        uint32_t mine = 0;
+        for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
+          if (sent_off[s] >= g.end) break;
+          if (kDirect) direct.off[s] = run; else if (Mode == 0) sent_local[s] = run;
+          if (kRec) {
+            drec[s] = (unsigned long long)(span_base + run) | ((unsigned long long)g.ntok << 32);
+            rec[uslot[s]] = (unsigned long long)s | ((unsigned long long)g.ntok << 32);
+          }
+          mine++;
+        }
+        for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+        s_next += mine;
+        run += g.ntok;
+        cb = g.end;
+        __syncthreads();
+        continue;
+      }
+      // the cut is a word boundary: symbols and words at or beyond it are staged again by the next chunk
+      ce = (uint32_t)cut;
+      nsym = L.sympre[ce >> 6] + (uint32_t)__popcll(L.symmask[ce >> 6] & ((1ull << (ce & 63)) - 1ull));
+      uint32_t keep = 0;
+      for (uint32_t k0 = 0; k0 < nw; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        keep += (uint32_t)__popcll(__ballot(k < nw && L.wl[k] < nsym));
+      }
+      nw = keep;
+    }
+    if (lane == 0) L.wl[nw] = (uint16_t)nsym;
+    __syncthreads();
+
+    // ---- W. the words with two symbols or more, by length class (2-4, 5-8, 9+): first symbol | symbols << 16
+    uint32_t nw2 = 0;
+    {
+      uint32_t c0 = 0, c1 = 0, c2 = 0;
+      for (uint32_t k0 = 0; k0 < nw; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        const uint32_t n = k < nw ? (uint32_t)L.wl[k + 1] - (uint32_t)L.wl[k] : 0u;
+        c0 += (uint32_t)__popcll(__ballot(n >= 2 && n <= 4));
+        c1 += (uint32_t)__popcll(__ballot(n >= 5 && n <= 8));
+        c2 += (uint32_t)__popcll(__ballot(n >= 9));
+      }
+      uint32_t o0 = 0, o1 = c0, o2 = c0 + c1;
+      nw2 = c0 + c1 + c2;
+      for (uint32_t k0 = 0; k0 < nw; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        const uint32_t base = k < nw ? (uint32_t)L.wl[k] : 0u;
+        const uint32_t n = k < nw ? (uint32_t)L.wl[k + 1] - base : 0u;
+        const unsigned long long M0 = __ballot(n >= 2 && n <= 4), M1 = __ballot(n >= 5 && n <= 8), M2 = __ballot(n >= 9);
+        const uint32_t e = base | (n << 16);
+        if (n >= 9) L.wl2[o2 + (uint32_t)__popcll(M2 & lt)] = e;
+        else if (n >= 5) L.wl2[o1 + (uint32_t)__popcll(M1 & lt)] = e;
+        else if (n >= 2) L.wl2[o0 + (uint32_t)__popcll(M0 & lt)] = e;
+        o0 += (uint32_t)__popcll(M0);
+        o1 += (uint32_t)__popcll(M1);
+        o2 += (uint32_t)__popcll(M2);
+      }
+    }
+    __syncthreads();
+
+    // ---- D. merge rounds (bpe.py:210-238), one lane per word, 64 words per batch
+    for (uint32_t b0 = 0; b0 < nw2; b0 += 64) {
+      const uint32_t k = b0 + lane;
+      const uint32_t e = k < nw2 ? L.wl2[k] : 0u;
+      const uint32_t n = e >> 16;  // 0: idle lane
+      uint32_t *const S = &L.sym[e & 0xFFFFu], *const V = &L.val[e & 0xFFFFu];
+      if (Proper && n >= 2 && n <= 32) {
+        uint32_t alive = n == 32 ? 0xFFFFFFFFu : (1u << n) - 1u;  // bit i: slot i still holds a symbol
+        for (;;) {
+          // leftmost minimum over the live slots' pair values, four slots per step (slots past the word read as dead)
+          uint32_t m = kNoRank, im = 0;
+          for (uint32_t i0 = 0; i0 < n; i0 += 4) {
+            const uint32_t a = alive >> i0;
+            uint32_t v0 = V[i0], v1 = V[i0 + 1], v2 = V[i0 + 2], v3 = V[i0 + 3];  // the arrays are padded by four
+            v0 = (a & 1u) ? v0 : kNoRank;
+            v1 = (a & 2u) ? v1 : kNoRank;
+            v2 = (a & 4u) ? v2 : kNoRank;
+            v3 = (a & 8u) ? v3 : kNoRank;
+            if (v0 < m) { m = v0; im = i0; }
+            if (v1 < m) { m = v1; im = i0 + 1; }
+            if (v2 < m) { m = v2; im = i0 + 2; }
+            if (v3 < m) { m = v3; im = i0 + 3; }
+          }
+          if (m == kNoRank) break;
+          // slot im merges with the next live slot r; pl / rr = the live slots either side of the pair
+          const uint32_t hi = alive & (0xFFFFFFFEu << im);
+          if (hi == 0u) { V[im] = kNoRank; continue; }     // cannot happen (a slot with a pair value has a live successor): never spin
+          const uint32_t r = (uint32_t)__builtin_ctz(hi);
+          const uint32_t hi2 = hi & (hi - 1u);
+          const uint32_t lo = alive & ((1u << im) - 1u);
+          const bool has_rr = hi2 != 0u, has_pl = lo != 0u;
+          const uint32_t rr = has_rr ? (uint32_t)__builtin_ctz(hi2) : 0u, pl = has_pl ? 31u - (uint32_t)__builtin_clz(lo) : 0u;
+          alive &= ~(1u << r);
+          const uint32_t mg = Packed ? (SWT_SYM_BASE + (m & 0xFFFFu)) : merged_of_rank[m];
+          const uint32_t sl = S[pl] & ~SWT_BPE_CONT, sr = S[rr] & ~SWT_BPE_CONT;
+          S[im] = im ? (mg | SWT_BPE_CONT) : mg;
+          S[r] = kInvalidTok;
+          const uint32_t v1 = slot_value(slots, sh, sl, mg), v2 = slot_value(slots, sh, mg, sr);
+          if (has_pl) V[pl] = v1;
+          V[im] = has_rr ? v2 : kNoRank;
+        }
+      } else if (n >= 2) {
+        slow_word<Packed>(S, V, n, slots, sh, merged_of_rank);
+      }
+    }
+    __syncthreads();
+
+    // ---- E. order-preserving compaction of the live symbols into the tile's output run
+    uint32_t total = 0;
+    for (uint32_t j0 = 0; j0 < nsym; j0 += 64) {
+      const uint32_t j = j0 + lane;
+      const uint32_t sv = j < nsym ? L.sym[j] : kInvalidTok;
+      const unsigned long long m = __ballot(sv != kInvalidTok);
+      if (lane == 0) { L.vmask[j0 >> 6] = m; L.blkpre[j0 >> 6] = total; }
+      if (sv != kInvalidTok) tile_out[run + total + (uint32_t)__popcll(m & lt)] = sv;
+      total += (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    // ---- F. tile-local token offset of every sentence starting in [cb, ce) (and == ce on the last chunk): byte -> symbol
+    // through the split's masks, symbol -> token through phase E's
+    auto tokens_before = [&](uint64_t rel) -> uint32_t {
+      if (rel >= ce || (rel >> 6) >= nblk) return total;
+      const uint32_t sidx = L.sympre[rel >> 6] + (uint32_t)__popcll(L.symmask[rel >> 6] & ((1ull << (rel & 63)) - 1ull));
+      if (sidx >= nsym) return total;
+      return L.blkpre[sidx >> 6] + (uint32_t)__popcll(L.vmask[sidx >> 6] & ((1ull << (sidx & 63)) - 1ull));
+    };
+    uint32_t mine = 0;
+    for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
+      const uint64_t rel = sent_off[s] - abase;
+      if (rel > ce || (rel == ce && !last)) break;
+      const uint32_t e = tokens_before(rel);
+      if (kDirect) direct.off[s] = run + e; else if (Mode == 0) sent_local[s] = run + e;
+      if (kRec && rel < ce) {  // a word never straddles the cut, so its end lies in this chunk too
+        const uint32_t e2 = tokens_before(sent_off[s + 1] - abase);
+        drec[s] = (unsigned long long)(span_base + run + e) | ((unsigned long long)(e2 - e) << 32);
+        rec[uslot[s]] = (unsigned long long)s | ((unsigned long long)(e2 - e) << 32);
+      }
+      mine++;
+    }
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    s_next += mine;
+    run += total;
+    if (last) break;
+    cb = abase + ce;
+    __syncthreads();
+  }
+  if (lane == 0) {
+    if (kDirect) { direct.off[s_hi] = run; *direct.n_tokens = run; }
+    else if (Mode == 0) tile_tok[t] = run;
+  }
+}
+
+
 }  // namespace swt
 
 using namespace swt;
@@ -617,6 +1011,8 @@ struct swt_bpe_table {
   std::vector<BpeSlot> h_slots;    // built on the host at create; uploaded on first encode
   std::vector<uint32_t> h_merged;  // merged symbol id by rank
   bool packed = false;             // slot value = rank << 16 | (merged - SWT_SYM_BASE)
+  bool proper = false;             // every pair ranks above the merges that produce its symbols (any trained table)
+  bool lane_kernel = true;         // bpe_lane_kernel (default) or the byte-lane kernel of rounds 1-2 (SWT_BPE_KERNEL=bytes)
   BpeSlot *d_slots = nullptr;
   uint32_t *d_merged = nullptr;
   uint32_t bits = 0;
@@ -647,16 +1043,33 @@ template <bool Packed, int Cap>
 static void launch_encode_kernel_as(swt_bpe_table *t, uint64_t n_tiles, const TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes,
                                     const uint64_t *d_sent_off, const uint8_t *d_cls, const uint32_t *d_uslot,
                                     unsigned long long *d_rec, unsigned long long *d_drec, hipStream_t st) {
+  const uint32_t sh = 32u - t->bits;
   if (d_rec)
     hipLaunchKernelGGL((bpe_encode_kernel<Packed, Cap, 1>), dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
-                       ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, ws.scratch.as<uint32_t>(),
+                       ws.plan.as<uint64_t>(), d_cls, t->d_slots, sh, t->d_merged, ws.scratch.as<uint32_t>(),
                        ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, DirectOut{nullptr, nullptr, 0},
                        (uint32_t)ablation_knob(0));
   else
     hipLaunchKernelGGL((bpe_encode_kernel<Packed, Cap, 0>), dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
-                       ws.plan.as<uint64_t>(), d_cls, t->d_slots, t->bits, t->d_merged, ws.scratch.as<uint32_t>(),
+                       ws.plan.as<uint64_t>(), d_cls, t->d_slots, sh, t->d_merged, ws.scratch.as<uint32_t>(),
                        ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, DirectOut{nullptr, nullptr, 0},
                        (uint32_t)ablation_knob(0));
+}
+
+// the word-lane kernel: Mode 0 (running text) or 1 (the unique words of the dedup path), by d_rec
+template <bool Packed, bool Proper, int Cap>
+static void launch_lane_kernel_as(swt_bpe_table *t, uint64_t n_tiles, const TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes,
+                                  const uint64_t *d_sent_off, const uint8_t *d_cls, const uint32_t *d_uslot,
+                                  unsigned long long *d_rec, unsigned long long *d_drec, hipStream_t st) {
+  const uint32_t sh = 32u - t->bits;
+  if (d_rec)
+    hipLaunchKernelGGL((bpe_lane_kernel<Packed, Proper, Cap, 1>), dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
+                       ws.plan.as<uint64_t>(), d_cls, t->d_slots, sh, t->d_merged, ws.scratch.as<uint32_t>(),
+                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, DirectOut{nullptr, nullptr, 0});
+  else
+    hipLaunchKernelGGL((bpe_lane_kernel<Packed, Proper, Cap, 0>), dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
+                       ws.plan.as<uint64_t>(), d_cls, t->d_slots, sh, t->d_merged, ws.scratch.as<uint32_t>(),
+                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, DirectOut{nullptr, nullptr, 0});
 }
 
 extern "C" {
@@ -664,36 +1077,69 @@ extern "C" {
 // diagnostics (not part of include/swt.h): resident workgroups per CU the runtime grants the encode kernel
 int swt_debug_occupancy(int which) try {
   int n = -1;
-  hipError_t e = which ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<false, kBpeCap, 0>, 64, 0)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<true, kBpeCap, 0>, 64, 0);
+  hipError_t e = which == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_lane_kernel<true, true, kLaneCap, 0>, 64, 0)
+                 : which  ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<false, kBpeCap, 0>, 64, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<true, kBpeCap, 0>, 64, 0);
   return e == hipSuccess ? n : -(int)e;
 } SWT_API_CATCH
 
 int swt_bpe_table_create(const uint32_t *left, const uint32_t *right, const uint32_t *merged, uint32_t n_merges,
                          swt_bpe_table **out) try {
   if (!out || (n_merges && (!left || !right || !merged))) return fail(SWT_ERR_INVALID, "null argument");
+  for (uint32_t i = 0; i < n_merges; i++)
+    if ((left[i] | right[i] | merged[i]) & SWT_BPE_CONT) return fail(SWT_ERR_INVALID, "symbol id out of range at merge %u", i);
+  // {pair: i} (bpe.py:257): a later duplicate overwrites, so only the LAST index of a pair goes into the table
+  std::unordered_map<uint64_t, uint32_t> last;
+  last.reserve((size_t)n_merges * 2 + 16);
+  for (uint32_t i = 0; i < n_merges; i++) last[pair_key(left[i], right[i])] = i;
   uint32_t bits = 4;
   while ((1ull << bits) < 2ull * n_merges + 2) bits++;
-  const size_t cap = (size_t)1 << bits;
   auto *t = new swt_bpe_table();
+  std::vector<BpeSlot> &slots = t->h_slots;
+  // two-choice cuckoo placement (see slot_lookup); a table that does not settle gets twice the slots
+  for (;; bits++) {
+    if (bits > 28) { delete t; return fail(SWT_ERR_UNSUPPORTED, "the rank table could not be placed"); }
+    const uint32_t sh = 32u - bits;
+    slots.assign((size_t)1 << bits, BpeSlot{kEmptyKey, 0u, 0u});
+    bool ok = true;
+    for (uint32_t i = 0; i < n_merges && ok; i++) {
+      if (last[pair_key(left[i], right[i])] != i) continue;
+      BpeSlot cur{pair_key(left[i], right[i]), i, merged[i]};
+      uint32_t avoid = 0xFFFFFFFFu;
+      ok = false;
+      for (int kick = 0; kick < 2000; kick++) {
+        const uint32_t l = (uint32_t)(cur.key >> 32), r = (uint32_t)cur.key;
+        const uint32_t h1 = bpe_hash(l, r, sh, kHash1), h2 = bpe_hash(l, r, sh, kHash2);
+        if (slots[h1].key == kEmptyKey) { slots[h1] = cur; ok = true; break; }
+        if (slots[h2].key == kEmptyKey) { slots[h2] = cur; ok = true; break; }
+        const uint32_t j = h1 == avoid ? h2 : h1;  // evict, but not from the slot this entry was just evicted from
+        std::swap(cur, slots[j]);
+        avoid = j;
+      }
+    }
+    if (ok) break;
+  }
   t->bits = bits;
   t->n_merges = n_merges;
-  std::vector<BpeSlot> &slots = t->h_slots;
-  slots.resize(cap);
-  for (auto &s : slots) { s.key = kEmptyKey; s.rank = 0; s.merged = 0; }
-  const uint32_t mask = (uint32_t)cap - 1;
-  for (uint32_t i = 0; i < n_merges; i++) {
-    if ((left[i] | right[i] | merged[i]) & SWT_BPE_CONT) {
-      delete t;
-      return fail(SWT_ERR_INVALID, "symbol id out of range at merge %u", i);
-    }
-    const uint64_t key = pair_key(left[i], right[i]);
-    uint32_t h = hash_slot(key, bits);
-    while (slots[h].key != kEmptyKey && slots[h].key != key) h = (h + 1) & mask;
-    slots[h].key = key;  // {pair: i}: a later duplicate overwrites (bpe.py:257)
-    slots[h].rank = i;
-    slots[h].merged = merged[i];
+  // proper: every pair ranks above every merge that produces one of its symbols, so the pairs a merge creates rank above it
+  // and "one occurrence of the best pair per round" equals the reference's "all occurrences" (bpe_lane_kernel)
+  {
+    std::unordered_map<uint32_t, uint32_t> maxprod;
+    for (const auto &sl : slots)
+      if (sl.key != kEmptyKey) {
+        auto it = maxprod.find(sl.merged);
+        if (it == maxprod.end()) maxprod[sl.merged] = sl.rank; else if (sl.rank > it->second) it->second = sl.rank;
+      }
+    t->proper = true;
+    for (const auto &sl : slots)
+      if (sl.key != kEmptyKey) {
+        for (uint32_t sy : {(uint32_t)(sl.key >> 32), (uint32_t)sl.key}) {
+          auto it = maxprod.find(sy);
+          if (it != maxprod.end() && it->second >= sl.rank) t->proper = false;
+        }
+      }
   }
+  if (const char *e = getenv("SWT_BPE_KERNEL")) t->lane_kernel = strcmp(e, "bytes") != 0;
   t->h_merged.assign(merged, merged + n_merges);
   // packed values when every rank and every merged-symbol index fits 16 bits (any realistic table below 65k merges)
   t->packed = n_merges < 0xFFFEu;
@@ -745,18 +1191,28 @@ static void launch_encode_kernel(swt_bpe_table *t, uint64_t n_tiles, const TileW
                                  const uint64_t *d_sent_off, const uint8_t *d_cls, const uint32_t *d_uslot, unsigned long long *d_rec,
                                  unsigned long long *d_drec, hipStream_t st, int cap = kBpeCap) {
 #define SWT_ENC(P, C) launch_encode_kernel_as<P, C>(t, n_tiles, ws, d_text, n_bytes, d_sent_off, d_cls, d_uslot, d_rec, d_drec, st)
+#define SWT_LANE(P, R, C) launch_lane_kernel_as<P, R, C>(t, n_tiles, ws, d_text, n_bytes, d_sent_off, d_cls, d_uslot, d_rec, d_drec, st)
+#define SWT_LANE_CAPS(P, R) do { if (cap == 128) SWT_LANE(P, R, 128); else if (cap == 256) SWT_LANE(P, R, 256); else SWT_LANE(P, R, 512); } while (0)
+  if (t->lane_kernel) {
+    if (t->packed) { if (t->proper) SWT_LANE_CAPS(true, true); else SWT_LANE_CAPS(true, false); }
+    else { if (t->proper) SWT_LANE_CAPS(false, true); else SWT_LANE_CAPS(false, false); }
+    return;
+  }
   if (t->packed) {
     if (cap == 128) SWT_ENC(true, 128); else if (cap == 256) SWT_ENC(true, 256); else SWT_ENC(true, 512);
   } else {
     if (cap == 128) SWT_ENC(false, 128); else if (cap == 256) SWT_ENC(false, 256); else SWT_ENC(false, 512);
   }
+#undef SWT_LANE_CAPS
+#undef SWT_LANE
 #undef SWT_ENC
 }
 
 static int bpe_encode_direct(swt_bpe_table *t, TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent_off,
                              uint64_t n_sent, uint32_t *d_out_ids, uint64_t *d_out_off, uint64_t *d_n_tokens, const uint8_t *d_cls,
                              hipStream_t st) {
-  const uint64_t n_tiles = tile_count(n_bytes, kBpeTile);
+  const uint32_t tile = t->lane_kernel ? (uint32_t)kLaneTile : (uint32_t)kBpeTile;
+  const uint64_t n_tiles = tile_count(n_bytes, tile);
   if (n_tiles > 0x7FFFFFFFull)
     return fail(SWT_ERR_UNSUPPORTED, "text too large for one call (%llu bytes)", (unsigned long long)n_bytes);
   int rc;
@@ -764,22 +1220,31 @@ static int bpe_encode_direct(swt_bpe_table *t, TileWorkspace &ws, const uint8_t 
     // a sentence or a few: one workgroup, one launch, the caller's arrays written by the kernel (DirectOut)
     if ((rc = ws.reserve(64, 0, 1))) return rc;
     const DirectOut direct{d_out_off, d_n_tokens, n_sent};
-    if (t->packed)
-      hipLaunchKernelGGL((bpe_encode_kernel<true, kBpeCap, 2>), dim3(1), dim3(64), 0, st, d_text, n_bytes, d_sent_off, (const uint64_t *)nullptr, d_cls,
-                         t->d_slots, t->bits, t->d_merged, d_out_ids, ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(),
-                         (const uint32_t *)nullptr, (unsigned long long *)nullptr, (unsigned long long *)nullptr, direct, 0u);
-    else
-      hipLaunchKernelGGL((bpe_encode_kernel<false, kBpeCap, 2>), dim3(1), dim3(64), 0, st, d_text, n_bytes, d_sent_off, (const uint64_t *)nullptr, d_cls,
-                         t->d_slots, t->bits, t->d_merged, d_out_ids, ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(),
-                         (const uint32_t *)nullptr, (unsigned long long *)nullptr, (unsigned long long *)nullptr, direct, 0u);
+    const uint32_t sh = 32u - t->bits;
+    auto one_lane = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, dim3(1), dim3(64), 0, st, d_text, n_bytes, d_sent_off, (const uint64_t *)nullptr, d_cls, t->d_slots, sh,
+                         t->d_merged, d_out_ids, ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), (const uint32_t *)nullptr,
+                         (unsigned long long *)nullptr, (unsigned long long *)nullptr, direct);
+    };
+    auto one_bytes = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, dim3(1), dim3(64), 0, st, d_text, n_bytes, d_sent_off, (const uint64_t *)nullptr, d_cls, t->d_slots, sh,
+                         t->d_merged, d_out_ids, ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), (const uint32_t *)nullptr,
+                         (unsigned long long *)nullptr, (unsigned long long *)nullptr, direct, 0u);
+    };
+    if (t->lane_kernel) {
+      if (t->packed) { if (t->proper) one_lane(bpe_lane_kernel<true, true, kLaneCap, 2>); else one_lane(bpe_lane_kernel<true, false, kLaneCap, 2>); }
+      else { if (t->proper) one_lane(bpe_lane_kernel<false, true, kLaneCap, 2>); else one_lane(bpe_lane_kernel<false, false, kLaneCap, 2>); }
+    } else {
+      if (t->packed) one_bytes(bpe_encode_kernel<true, kBpeCap, 2>); else one_bytes(bpe_encode_kernel<false, kBpeCap, 2>);
+    }
     SWT_HIP(hipGetLastError());
     return SWT_OK;
   }
   if ((rc = ws.reserve(n_bytes, n_sent, n_tiles))) return rc;
   prof_begin(st, 2);
-  launch_plan(d_sent_off, n_sent, n_tiles, kBpeTile, ws.plan.as<uint64_t>(), st);
+  launch_plan(d_sent_off, n_sent, n_tiles, tile, ws.plan.as<uint64_t>(), st);
   prof_begin(st);
-  launch_encode_kernel(t, n_tiles, ws, d_text, n_bytes, d_sent_off, d_cls, nullptr, nullptr, nullptr, st);
+  launch_encode_kernel(t, n_tiles, ws, d_text, n_bytes, d_sent_off, d_cls, nullptr, nullptr, nullptr, st, t->lane_kernel ? kLaneCap : kBpeCap);
   prof_end(st);
   launch_scan_gather(d_sent_off, n_sent, n_tiles, ws, d_out_ids, d_out_off, d_n_tokens, st);
   prof_end(st, 2);
