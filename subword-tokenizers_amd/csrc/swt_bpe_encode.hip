@@ -652,8 +652,8 @@ struct LaneLds {
   __attribute__((aligned(16))) uint8_t txt[Cap + 16];
   uint32_t sym[Cap + 4];      // per symbol: id (| SWT_BPE_CONT unless it opens its word), kInvalidTok once consumed
   uint32_t val[Cap + 4];      // per symbol: table value of (this symbol, next live symbol of the word), kNoRank when none
-  uint32_t wl2[Cap / 2 + 1];  // multi-symbol words by length class: first symbol | symbols << 16
   uint16_t wl[Cap + 2];       // first symbol of every word, in text order
+  // (the multi-symbol words by length class -- 16-bit indices into wl[] -- reuse txt[] once the split is done)
   unsigned long long sbits[Blocks + 1];    // sentence-start bit per byte
   unsigned long long symmask[Blocks + 1];  // symbol bit per byte
   unsigned long long vmask[Blocks + 1];    // phase E: live-token bit per symbol
@@ -661,6 +661,16 @@ struct LaneLds {
   uint32_t blkpre[Blocks + 1];             // tokens before each block of 64 symbols
   uint32_t cls2[64];                       // classes of U+0000..U+03FF, two bits each
   GiantResult giant;
+};
+
+// Mode 3 of bpe_lane_kernel: the tile places its own output (tile_lookback, swt_tile.h) -- no scan and no gather launch
+struct FusedOut {
+  unsigned long long *state;  // one look-back word per tile
+  uint32_t epoch;
+  uint32_t *err;
+  uint32_t *out_ids;
+  uint64_t *out_off, *n_tokens;
+  uint64_t n_sent, n_tiles;
 };
 
 constexpr uint32_t kDirtyVal = 0xFFFFFFFEu;  // above every table value (ranks stay below 2^32 - 2), below kNoRank
@@ -701,8 +711,8 @@ __global__ __launch_bounds__(64) void bpe_lane_kernel(
     const uint64_t *__restrict__ plan, const uint8_t *__restrict__ cls_tab, const BpeSlot *__restrict__ slots,
     uint32_t sh, const uint32_t *__restrict__ merged_of_rank, uint32_t *__restrict__ scratch,
     uint32_t *__restrict__ sent_local, uint32_t *__restrict__ tile_tok, const uint32_t *__restrict__ uslot,
-    unsigned long long *__restrict__ rec, unsigned long long *__restrict__ drec, DirectOut direct) {
-  constexpr bool kDirect = Mode == 2, kRec = Mode == 1;
+    unsigned long long *__restrict__ rec, unsigned long long *__restrict__ drec, DirectOut direct, FusedOut fused) {
+  constexpr bool kDirect = Mode == 2, kRec = Mode == 1, kFused = Mode == 3;
   constexpr int Blocks = Cap / 64;
   __shared__ LaneLds<Cap> L;
   const int lane = threadIdx.x;
@@ -712,6 +722,15 @@ __global__ __launch_bounds__(64) void bpe_lane_kernel(
   const uint64_t s_lo = kDirect ? 0 : plan[t], s_hi = kDirect ? direct.n_sent : plan[t + 1];
   if (s_lo == s_hi) {
     if (Mode == 0 && lane == 0) tile_tok[t] = 0;
+    if (kFused) {
+      if (t + 1 == fused.n_tiles) {  // the last tile closes the output even when it holds no sentence
+        const uint32_t before = tile_lookback(fused.state, t, fused.epoch, 0u, lane, fused.err);
+        if (lane == 0) { fused.out_off[fused.n_sent] = before; *fused.n_tokens = before; }
+      } else if (lane == 0) {
+        __hip_atomic_store(&fused.state[t], ((unsigned long long)fused.epoch << 34) | (t == 0 ? kLbIncl : kLbAgg), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     return;
   }
   {
@@ -733,6 +752,10 @@ __global__ __launch_bounds__(64) void bpe_lane_kernel(
   uint32_t run = 0;        // tokens emitted by this tile so far
   uint64_t s_next = s_lo;  // first sentence whose local offset is not recorded yet
   uint64_t cb = span_base;
+  // fused form: a tile whose span fits one chunk (nearly all) keeps its tokens in LDS until it knows where they go; a longer
+  // span goes through its scratch run as in mode 0 and is copied at the end
+  const bool single = kFused && span_end - (span_base & ~15ull) <= (uint64_t)Cap;
+  uint32_t before = 0;     // fused form: tokens of all tiles before this one
 
   for (;;) {
     const uint64_t abase = cb & ~15ull;
@@ -767,7 +790,11 @@ __global__ __launch_bounds__(64) void bpe_lane_kernel(
     bool pend_open = false;     // the last symbol of the previous block may have its successor in this one
     uint32_t pend_cp = 0;
     int cut = -1;               // last word boundary (for a span longer than the chunk)
+#if defined(SWT_LANE_ABL) && SWT_LANE_ABL >= 4
+    for (uint32_t blk = 0; blk < 0; blk++) {
+#else
     for (uint32_t blk = 0; blk < nblk; blk++) {
+#endif
       const uint32_t p = blk * 64 + lane;
       const bool inr = p >= off0 && p < staged;
       const uint8_t b = inr ? L.txt[p] : (uint8_t)' ';
@@ -816,7 +843,9 @@ __global__ __launch_bounds__(64) void bpe_lane_kernel(
       const uint32_t cpf = __builtin_amdgcn_readlane(cp, (int)(f & 63));
       const bool want = hasnext || jp;
       uint32_t v = kNoRank;
+#if !defined(SWT_LANE_ABL) || SWT_LANE_ABL < 3
       if (want) v = slot_value(slots, sh, jp ? pend_cp : cp, jp ? cpf : cpn);
+#endif
       if (is_sym) {
         L.sym[si] = wstart ? cp : (cp | SWT_BPE_CONT);
         if (!hasnext) L.val[si] = kNoRank;
@@ -854,7 +883,7 @@ __global__ __launch_bounds__(64) void bpe_lane_kernel(
         uint32_t mine = 0;
         for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
           if (sent_off[s] >= g.end) break;
-          if (kDirect) direct.off[s] = run; else if (Mode == 0) sent_local[s] = run;
+          if (kDirect) direct.off[s] = run; else if (Mode == 0 || kFused) sent_local[s] = run;
           if (kRec) {
             drec[s] = (unsigned long long)(span_base + run) | ((unsigned long long)g.ntok << 32);
             rec[uslot[s]] = (unsigned long long)s | ((unsigned long long)g.ntok << 32);
@@ -881,8 +910,12 @@ __global__ __launch_bounds__(64) void bpe_lane_kernel(
     if (lane == 0) L.wl[nw] = (uint16_t)nsym;
     __syncthreads();
 
-    // ---- W. the words with two symbols or more, by length class (2-4, 5-8, 9+): first symbol | symbols << 16
+    // ---- W. the words with two symbols or more, longest class first (9+, 5-8, 2-4 symbols): their indices in wl[]
+    uint16_t *const wl2 = reinterpret_cast<uint16_t *>(L.txt);  // the staged bytes are not read again (at most Cap / 2 entries)
     uint32_t nw2 = 0;
+#if defined(SWT_LANE_ABL) && SWT_LANE_ABL >= 2
+    if (false)
+#endif
     {
       uint32_t c0 = 0, c1 = 0, c2 = 0;
       for (uint32_t k0 = 0; k0 < nw; k0 += 64) {
@@ -892,17 +925,15 @@ __global__ __launch_bounds__(64) void bpe_lane_kernel(
         c1 += (uint32_t)__popcll(__ballot(n >= 5 && n <= 8));
         c2 += (uint32_t)__popcll(__ballot(n >= 9));
       }
-      uint32_t o0 = 0, o1 = c0, o2 = c0 + c1;
+      uint32_t o2 = 0, o1 = c2, o0 = c2 + c1;
       nw2 = c0 + c1 + c2;
       for (uint32_t k0 = 0; k0 < nw; k0 += 64) {
         const uint32_t k = k0 + lane;
-        const uint32_t base = k < nw ? (uint32_t)L.wl[k] : 0u;
-        const uint32_t n = k < nw ? (uint32_t)L.wl[k + 1] - base : 0u;
+        const uint32_t n = k < nw ? (uint32_t)L.wl[k + 1] - (uint32_t)L.wl[k] : 0u;
         const unsigned long long M0 = __ballot(n >= 2 && n <= 4), M1 = __ballot(n >= 5 && n <= 8), M2 = __ballot(n >= 9);
-        const uint32_t e = base | (n << 16);
-        if (n >= 9) L.wl2[o2 + (uint32_t)__popcll(M2 & lt)] = e;
-        else if (n >= 5) L.wl2[o1 + (uint32_t)__popcll(M1 & lt)] = e;
-        else if (n >= 2) L.wl2[o0 + (uint32_t)__popcll(M0 & lt)] = e;
+        if (n >= 9) wl2[o2 + (uint32_t)__popcll(M2 & lt)] = (uint16_t)k;
+        else if (n >= 5) wl2[o1 + (uint32_t)__popcll(M1 & lt)] = (uint16_t)k;
+        else if (n >= 2) wl2[o0 + (uint32_t)__popcll(M0 & lt)] = (uint16_t)k;
         o0 += (uint32_t)__popcll(M0);
         o1 += (uint32_t)__popcll(M1);
         o2 += (uint32_t)__popcll(M2);
@@ -910,62 +941,120 @@ __global__ __launch_bounds__(64) void bpe_lane_kernel(
     }
     __syncthreads();
 
-    // ---- D. merge rounds (bpe.py:210-238), one lane per word, 64 words per batch
-    for (uint32_t b0 = 0; b0 < nw2; b0 += 64) {
-      const uint32_t k = b0 + lane;
-      const uint32_t e = k < nw2 ? L.wl2[k] : 0u;
-      const uint32_t n = e >> 16;  // 0: idle lane
-      uint32_t *const S = &L.sym[e & 0xFFFFu], *const V = &L.val[e & 0xFFFFu];
-      if (Proper && n >= 2 && n <= 32) {
-        uint32_t alive = n == 32 ? 0xFFFFFFFFu : (1u << n) - 1u;  // bit i: slot i still holds a symbol
-        for (;;) {
-          // leftmost minimum over the live slots' pair values, four slots per step (slots past the word read as dead)
-          uint32_t m = kNoRank, im = 0;
-          for (uint32_t i0 = 0; i0 < n; i0 += 4) {
-            const uint32_t a = alive >> i0;
-            uint32_t v0 = V[i0], v1 = V[i0 + 1], v2 = V[i0 + 2], v3 = V[i0 + 3];  // the arrays are padded by four
-            v0 = (a & 1u) ? v0 : kNoRank;
-            v1 = (a & 2u) ? v1 : kNoRank;
-            v2 = (a & 4u) ? v2 : kNoRank;
-            v3 = (a & 8u) ? v3 : kNoRank;
-            if (v0 < m) { m = v0; im = i0; }
-            if (v1 < m) { m = v1; im = i0 + 1; }
-            if (v2 < m) { m = v2; im = i0 + 2; }
-            if (v3 < m) { m = v3; im = i0 + 3; }
+    // ---- D. merge rounds (bpe.py:210-238), one lane per word.  A lane whose word is finished takes the next one of the list,
+    // so the wave goes through about as many rounds as its longest word needs -- the short words fill the lanes beside it
+#if defined(SWT_LANE_ABL) && SWT_LANE_ABL >= 1   // diagnostic builds (tools/gpu_r03_p.sh): results are WRONG
+    nw2 = 0;
+#endif
+    {
+      uint32_t next = 0;  // first word of the list no lane has taken (the same in every lane)
+      uint32_t n = 0, alive = 0;  // this lane's word: symbols (0: none), live slots
+      uint32_t *S = L.sym, *V = L.val;
+      for (;;) {
+        const unsigned long long IDLE = __ballot(n == 0u);
+        if (IDLE && next < nw2) {
+          const uint32_t k = next + (uint32_t)__popcll(IDLE & lt);
+          if (n == 0u && k < nw2) {
+            const uint32_t w = wl2[k];
+            const uint32_t base = L.wl[w];
+            n = (uint32_t)L.wl[w + 1] - base;
+            S = &L.sym[base];
+            V = &L.val[base];
+            alive = n >= 32u ? 0xFFFFFFFFu : (1u << n) - 1u;  // bit i: slot i still holds a symbol
+            if (!Proper || n > 32u) {
+              slow_word<Packed>(S, V, n, slots, sh, merged_of_rank);
+              n = 0u;
+            }
           }
-          if (m == kNoRank) break;
+          next += (uint32_t)__popcll(IDLE);
+        }
+        if (__ballot(n != 0u) == 0ull) {
+          if (next >= nw2) break;
+          continue;
+        }
+        if (n != 0u) {
+          // one round: leftmost minimum over the live slots' pair values, four slots per step
+          uint32_t m = kNoRank, im = 0;
+          if (Packed) {
+            // a packed value is rank:16 | merged:16 and a dead slot's value is all ones (written when the slot dies), so the key
+            // rank:16 | slot:5 finds minimum and place with one min per slot; slots past the word read slot n-1, which never
+            // has a pair; the merged symbol comes from the winning slot afterwards
+            const uint32_t nm1 = n - 1u;
+            uint32_t key = 0xFFFFFFFFu;
+            for (uint32_t i0 = 0; i0 < nm1; i0 += 4) {
+              const uint32_t i1 = min(i0 + 1u, nm1), i2 = min(i0 + 2u, nm1), i3 = min(i0 + 3u, nm1);
+              const uint32_t k0 = (V[i0] & 0xFFFF0000u) | i0, k1 = (V[i1] & 0xFFFF0000u) | i1;
+              const uint32_t k2 = (V[i2] & 0xFFFF0000u) | i2, k3 = (V[i3] & 0xFFFF0000u) | i3;
+              key = min(min(key, k0), min(min(k1, k2), k3));
+            }
+            if (key < 0xFFFF0000u) { im = key & 31u; m = V[im]; }
+          } else {
+            for (uint32_t i0 = 0; i0 < n; i0 += 4) {
+              const uint32_t a = alive >> i0;
+              uint32_t v0 = V[i0], v1 = V[i0 + 1], v2 = V[i0 + 2], v3 = V[i0 + 3];  // the arrays are padded by four
+              v0 = (a & 1u) ? v0 : kNoRank;
+              v1 = (a & 2u) ? v1 : kNoRank;
+              v2 = (a & 4u) ? v2 : kNoRank;
+              v3 = (a & 8u) ? v3 : kNoRank;
+              if (v0 < m) { m = v0; im = i0; }
+              if (v1 < m) { m = v1; im = i0 + 1; }
+              if (v2 < m) { m = v2; im = i0 + 2; }
+              if (v3 < m) { m = v3; im = i0 + 3; }
+            }
+          }
           // slot im merges with the next live slot r; pl / rr = the live slots either side of the pair
           const uint32_t hi = alive & (0xFFFFFFFEu << im);
-          if (hi == 0u) { V[im] = kNoRank; continue; }     // cannot happen (a slot with a pair value has a live successor): never spin
-          const uint32_t r = (uint32_t)__builtin_ctz(hi);
-          const uint32_t hi2 = hi & (hi - 1u);
-          const uint32_t lo = alive & ((1u << im) - 1u);
-          const bool has_rr = hi2 != 0u, has_pl = lo != 0u;
-          const uint32_t rr = has_rr ? (uint32_t)__builtin_ctz(hi2) : 0u, pl = has_pl ? 31u - (uint32_t)__builtin_clz(lo) : 0u;
-          alive &= ~(1u << r);
-          const uint32_t mg = Packed ? (SWT_SYM_BASE + (m & 0xFFFFu)) : merged_of_rank[m];
-          const uint32_t sl = S[pl] & ~SWT_BPE_CONT, sr = S[rr] & ~SWT_BPE_CONT;
-          S[im] = im ? (mg | SWT_BPE_CONT) : mg;
-          S[r] = kInvalidTok;
-          const uint32_t v1 = slot_value(slots, sh, sl, mg), v2 = slot_value(slots, sh, mg, sr);
-          if (has_pl) V[pl] = v1;
-          V[im] = has_rr ? v2 : kNoRank;
+          if (m == kNoRank || hi == 0u) {
+            n = 0u;  // the word is finished (hi == 0 cannot happen: a slot with a pair value has a live successor)
+          } else {
+            const uint32_t r = (uint32_t)__builtin_ctz(hi);
+            const uint32_t hi2 = hi & (hi - 1u);
+            const uint32_t lo = alive & ((1u << im) - 1u);
+            const bool has_rr = hi2 != 0u, has_pl = lo != 0u;
+            const uint32_t rr = has_rr ? (uint32_t)__builtin_ctz(hi2) : 0u, pl = has_pl ? 31u - (uint32_t)__builtin_clz(lo) : 0u;
+            alive &= ~(1u << r);
+            const uint32_t mg = Packed ? (SWT_SYM_BASE + (m & 0xFFFFu)) : merged_of_rank[m];
+            const uint32_t sl = S[pl] & ~SWT_BPE_CONT, sr = S[rr] & ~SWT_BPE_CONT;
+            S[im] = im ? (mg | SWT_BPE_CONT) : mg;
+            S[r] = kInvalidTok;
+            V[r] = kNoRank;
+            const uint32_t v1 = slot_value(slots, sh, sl, mg), v2 = slot_value(slots, sh, mg, sr);
+            if (has_pl) V[pl] = v1;
+            V[im] = has_rr ? v2 : kNoRank;
+          }
         }
-      } else if (n >= 2) {
-        slow_word<Packed>(S, V, n, slots, sh, merged_of_rank);
       }
     }
     __syncthreads();
 
     // ---- E. order-preserving compaction of the live symbols into the tile's output run
     uint32_t total = 0;
-    for (uint32_t j0 = 0; j0 < nsym; j0 += 64) {
-      const uint32_t j = j0 + lane;
-      const uint32_t sv = j < nsym ? L.sym[j] : kInvalidTok;
-      const unsigned long long m = __ballot(sv != kInvalidTok);
-      if (lane == 0) { L.vmask[j0 >> 6] = m; L.blkpre[j0 >> 6] = total; }
-      if (sv != kInvalidTok) tile_out[run + total + (uint32_t)__popcll(m & lt)] = sv;
-      total += (uint32_t)__popcll(m);
+    if (single) {
+      // count, find this tile's place (tile_lookback), then write the tokens where they belong
+      for (uint32_t j0 = 0; j0 < nsym; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        const unsigned long long m = __ballot(j < nsym && L.sym[j] != kInvalidTok);
+        if (lane == 0) { L.vmask[j0 >> 6] = m; L.blkpre[j0 >> 6] = total; }
+        total += (uint32_t)__popcll(m);
+      }
+      before = tile_lookback(fused.state, t, fused.epoch, total, lane, fused.err);
+      uint32_t at = 0;
+      for (uint32_t j0 = 0; j0 < nsym; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        const uint32_t sv = j < nsym ? L.sym[j] : kInvalidTok;
+        const unsigned long long m = __ballot(sv != kInvalidTok);
+        if (sv != kInvalidTok) fused.out_ids[(uint64_t)before + at + (uint32_t)__popcll(m & lt)] = sv;
+        at += (uint32_t)__popcll(m);
+      }
+    } else {
+      for (uint32_t j0 = 0; j0 < nsym; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        const uint32_t sv = j < nsym ? L.sym[j] : kInvalidTok;
+        const unsigned long long m = __ballot(sv != kInvalidTok);
+        if (lane == 0) { L.vmask[j0 >> 6] = m; L.blkpre[j0 >> 6] = total; }
+        if (sv != kInvalidTok) tile_out[run + total + (uint32_t)__popcll(m & lt)] = sv;
+        total += (uint32_t)__popcll(m);
+      }
     }
     __syncthreads();
     // ---- F. tile-local token offset of every sentence starting in [cb, ce) (and == ce on the last chunk): byte -> symbol
@@ -981,7 +1070,9 @@ __global__ __launch_bounds__(64) void bpe_lane_kernel(
       const uint64_t rel = sent_off[s] - abase;
       if (rel > ce || (rel == ce && !last)) break;
       const uint32_t e = tokens_before(rel);
-      if (kDirect) direct.off[s] = run + e; else if (Mode == 0) sent_local[s] = run + e;
+      if (kDirect) direct.off[s] = run + e;
+      else if (single) fused.out_off[s] = (uint64_t)before + e;
+      else if (Mode == 0 || kFused) sent_local[s] = run + e;
       if (kRec && rel < ce) {  // a word never straddles the cut, so its end lies in this chunk too
         const uint32_t e2 = tokens_before(sent_off[s + 1] - abase);
         drec[s] = (unsigned long long)(span_base + run + e) | ((unsigned long long)(e2 - e) << 32);
@@ -996,9 +1087,17 @@ __global__ __launch_bounds__(64) void bpe_lane_kernel(
     cb = abase + ce;
     __syncthreads();
   }
+  if (kFused && !single) {
+    // a span of several chunks: its tokens lie in the tile's scratch run and its sentence offsets in sent_local
+    __syncthreads();
+    before = tile_lookback(fused.state, t, fused.epoch, run, lane, fused.err);
+    for (uint32_t i = lane; i < run; i += 64) fused.out_ids[(uint64_t)before + i] = tile_out[i];
+    for (uint64_t s = s_lo + lane; s < s_hi; s += 64) fused.out_off[s] = (uint64_t)before + sent_local[s];
+  }
   if (lane == 0) {
     if (kDirect) { direct.off[s_hi] = run; *direct.n_tokens = run; }
     else if (Mode == 0) tile_tok[t] = run;
+    else if (kFused && t + 1 == fused.n_tiles) { fused.out_off[fused.n_sent] = (uint64_t)before + run; *fused.n_tokens = (uint64_t)before + run; }
   }
 }
 
@@ -1013,6 +1112,9 @@ struct swt_bpe_table {
   bool packed = false;             // slot value = rank << 16 | (merged - SWT_SYM_BASE)
   bool proper = false;             // every pair ranks above the merges that produce its symbols (any trained table)
   bool lane_kernel = true;         // bpe_lane_kernel (default) or the byte-lane kernel of rounds 1-2 (SWT_BPE_KERNEL=bytes)
+  bool fused = false;              // SWT_BPE_FUSED=1: the tiles place their own output (tile_lookback) instead of the scan + gather launches.
+                                   // Measured and left off: 22 k single-wave tiles with ~6,000 of them in flight make the look-back
+                                   // long (S85k-open: 0.367 ms against 0.200 ms per call, profiles/r03_experiments/)
   BpeSlot *d_slots = nullptr;
   uint32_t *d_merged = nullptr;
   uint32_t bits = 0;
@@ -1060,16 +1162,20 @@ static void launch_encode_kernel_as(swt_bpe_table *t, uint64_t n_tiles, const Ti
 template <bool Packed, bool Proper, int Cap>
 static void launch_lane_kernel_as(swt_bpe_table *t, uint64_t n_tiles, const TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes,
                                   const uint64_t *d_sent_off, const uint8_t *d_cls, const uint32_t *d_uslot,
-                                  unsigned long long *d_rec, unsigned long long *d_drec, hipStream_t st) {
+                                  unsigned long long *d_rec, unsigned long long *d_drec, hipStream_t st, const FusedOut *fused = nullptr) {
   const uint32_t sh = 32u - t->bits;
   if (d_rec)
     hipLaunchKernelGGL((bpe_lane_kernel<Packed, Proper, Cap, 1>), dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
                        ws.plan.as<uint64_t>(), d_cls, t->d_slots, sh, t->d_merged, ws.scratch.as<uint32_t>(),
-                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, DirectOut{nullptr, nullptr, 0});
+                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, DirectOut{nullptr, nullptr, 0}, FusedOut{});
+  else if (fused)
+    hipLaunchKernelGGL((bpe_lane_kernel<Packed, Proper, Cap, 3>), dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
+                       ws.plan.as<uint64_t>(), d_cls, t->d_slots, sh, t->d_merged, ws.scratch.as<uint32_t>(),
+                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, DirectOut{nullptr, nullptr, 0}, *fused);
   else
     hipLaunchKernelGGL((bpe_lane_kernel<Packed, Proper, Cap, 0>), dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
                        ws.plan.as<uint64_t>(), d_cls, t->d_slots, sh, t->d_merged, ws.scratch.as<uint32_t>(),
-                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, DirectOut{nullptr, nullptr, 0});
+                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, DirectOut{nullptr, nullptr, 0}, FusedOut{});
 }
 
 extern "C" {
@@ -1140,6 +1246,8 @@ int swt_bpe_table_create(const uint32_t *left, const uint32_t *right, const uint
       }
   }
   if (const char *e = getenv("SWT_BPE_KERNEL")) t->lane_kernel = strcmp(e, "bytes") != 0;
+  if (const char *e = getenv("SWT_BPE_FUSED")) t->fused = strcmp(e, "0") != 0;
+  if (const char *e = getenv("SWT_BPE_UTILE")) t->opt_unique_tile = atoi(e);  // measurement knob, as SWT_OPT_UNIQUE_TILE
   t->h_merged.assign(merged, merged + n_merges);
   // packed values when every rank and every merged-symbol index fits 16 bits (any realistic table below 65k merges)
   t->packed = n_merges < 0xFFFEu;
@@ -1189,10 +1297,15 @@ void swt_bpe_table_destroy(swt_bpe_table *t) try {
 // cap = staged bytes per chunk (LDS footprint ~ 20 B per byte): 512 for running text, less for the unique-word pass
 static void launch_encode_kernel(swt_bpe_table *t, uint64_t n_tiles, const TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes,
                                  const uint64_t *d_sent_off, const uint8_t *d_cls, const uint32_t *d_uslot, unsigned long long *d_rec,
-                                 unsigned long long *d_drec, hipStream_t st, int cap = kBpeCap) {
+                                 unsigned long long *d_drec, hipStream_t st, int cap = kBpeCap, const FusedOut *fused = nullptr) {
 #define SWT_ENC(P, C) launch_encode_kernel_as<P, C>(t, n_tiles, ws, d_text, n_bytes, d_sent_off, d_cls, d_uslot, d_rec, d_drec, st)
-#define SWT_LANE(P, R, C) launch_lane_kernel_as<P, R, C>(t, n_tiles, ws, d_text, n_bytes, d_sent_off, d_cls, d_uslot, d_rec, d_drec, st)
+#define SWT_LANE(P, R, C) launch_lane_kernel_as<P, R, C>(t, n_tiles, ws, d_text, n_bytes, d_sent_off, d_cls, d_uslot, d_rec, d_drec, st, fused)
 #define SWT_LANE_CAPS(P, R) do { if (cap == 128) SWT_LANE(P, R, 128); else if (cap == 256) SWT_LANE(P, R, 256); else SWT_LANE(P, R, 512); } while (0)
+  if (t->lane_kernel && !d_rec) {  // running text: the one chunk size the tile was chosen for
+    if (t->packed) { if (t->proper) SWT_LANE(true, true, kLaneCap); else SWT_LANE(true, false, kLaneCap); }
+    else { if (t->proper) SWT_LANE(false, true, kLaneCap); else SWT_LANE(false, false, kLaneCap); }
+    return;
+  }
   if (t->lane_kernel) {
     if (t->packed) { if (t->proper) SWT_LANE_CAPS(true, true); else SWT_LANE_CAPS(true, false); }
     else { if (t->proper) SWT_LANE_CAPS(false, true); else SWT_LANE_CAPS(false, false); }
@@ -1224,7 +1337,7 @@ static int bpe_encode_direct(swt_bpe_table *t, TileWorkspace &ws, const uint8_t 
     auto one_lane = [&](auto kernel) {
       hipLaunchKernelGGL(kernel, dim3(1), dim3(64), 0, st, d_text, n_bytes, d_sent_off, (const uint64_t *)nullptr, d_cls, t->d_slots, sh,
                          t->d_merged, d_out_ids, ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), (const uint32_t *)nullptr,
-                         (unsigned long long *)nullptr, (unsigned long long *)nullptr, direct);
+                         (unsigned long long *)nullptr, (unsigned long long *)nullptr, direct, FusedOut{});
     };
     auto one_bytes = [&](auto kernel) {
       hipLaunchKernelGGL(kernel, dim3(1), dim3(64), 0, st, d_text, n_bytes, d_sent_off, (const uint64_t *)nullptr, d_cls, t->d_slots, sh,
@@ -1241,12 +1354,25 @@ static int bpe_encode_direct(swt_bpe_table *t, TileWorkspace &ws, const uint8_t 
     return SWT_OK;
   }
   if ((rc = ws.reserve(n_bytes, n_sent, n_tiles))) return rc;
+  // the fused form: every tile places its own output (tile_lookback); left for good should a look-back ever give up
+  bool fused_on = t->lane_kernel && t->fused && n_bytes < 0xFFFFFFFFull;
+  if (fused_on && ws.lb_err.p && *ws.lb_err.as<volatile uint32_t>()) {
+    t->fused = false;
+    *ws.lb_err.as<volatile uint32_t>() = 0u;
+    return fail(SWT_ERR_INTERNAL, "a tile look-back of the previous call gave up (its output is not valid); this table uses the scan + gather form from now on");
+  }
+  FusedOut fo{};
+  if (fused_on) {
+    if ((rc = ws.reserve_state(n_tiles))) return rc;
+    fo = FusedOut{ws.state.as<unsigned long long>(), ws.epoch, ws.lb_err.as<uint32_t>(), d_out_ids, d_out_off, d_n_tokens, n_sent, n_tiles};
+  }
   prof_begin(st, 2);
   launch_plan(d_sent_off, n_sent, n_tiles, tile, ws.plan.as<uint64_t>(), st);
   prof_begin(st);
-  launch_encode_kernel(t, n_tiles, ws, d_text, n_bytes, d_sent_off, d_cls, nullptr, nullptr, nullptr, st, t->lane_kernel ? kLaneCap : kBpeCap);
+  launch_encode_kernel(t, n_tiles, ws, d_text, n_bytes, d_sent_off, d_cls, nullptr, nullptr, nullptr, st, t->lane_kernel ? kLaneCap : kBpeCap,
+                       fused_on ? &fo : nullptr);
   prof_end(st);
-  launch_scan_gather(d_sent_off, n_sent, n_tiles, ws, d_out_ids, d_out_off, d_n_tokens, st);
+  if (!fused_on) launch_scan_gather(d_sent_off, n_sent, n_tiles, ws, d_out_ids, d_out_off, d_n_tokens, st);
   prof_end(st, 2);
   SWT_HIP(hipGetLastError());
   return SWT_OK;
