@@ -627,33 +627,34 @@ __global__ __launch_bounds__(64) void bpe_encode_kernel(
 
 
 // ======================================================================================================================
-// bpe_lane_kernel -- the word-lane form of the same call (round 3; the default).
+// The word-lane form of the same call (round 3; the default): bpe_lane_kernel.
 //
 // The kernel above keeps one lane per BYTE through the merge rounds: a round costs the wave the same ~170 instructions
 // whether 64 symbols take part or three, and a tile goes through as many rounds as its longest word has merges (the SQ
 // counters of round 2: 19.7 scalar + 14 vector instructions per input byte, the scalar pipe bound).  Here the split stays
 // byte-parallel (ballots), but it leaves the symbols DENSE (indexed by symbol, not by byte) together with the table value of
 // every adjacent pair (probed right there, all lanes at once), and then one lane owns one WORD:
-//   W    the multi-symbol words of the chunk, sorted into three length classes so that the 64 words of a batch run a
-//        similar number of rounds
+//   W    the multi-symbol words of the chunk, longest class first (9+, 5-8, 2-4 symbols)
 //   D    lane = word.  The word's slots stay where the split put them; a 32-bit mask says which are still live.  A round =
 //        leftmost minimum over the live slots' cached pair values (four slots per step) -> the pair merges in place, its
-//        right slot dies, and the two pairs next to the merged symbol are probed again (two lookups in flight).  On a
-//        PROPER table (every pair ranks above the merges that produce its symbols: any trained table) merging one
-//        occurrence per round is the reference's "all occurrences of the best pair, left to right" (bpe.py:221-235) --
-//        what is left of the pair is still the minimum and is found leftmost-first in the next round.  Tables without that
-//        property, and words beyond 32 symbols, take slow_word(): the same loop in its literal form (all occurrences per
-//        round, compaction), one lane per word.
+//        right slot dies, and the two pairs next to the merged symbol are probed again (four loads in flight).  A lane whose
+//        word is finished takes the next word of the list.  On a PROPER table (every pair ranks above the merges that produce
+//        its symbols: any trained table) merging one occurrence per round is the reference's "all occurrences of the best
+//        pair, left to right" (bpe.py:221-235) -- what is left of the pair is still the minimum and is found leftmost-first
+//        in the next round.  Tables without that property, and words beyond 32 symbols, take slow_word(): the same loop in
+//        its literal form (all occurrences per round, compaction), one lane per word.
 //   E/F  ballot compaction over the SYMBOL space, sentence offsets through the split's symbol masks.
+// Measured and dropped (profiles/r03_experiments/bpe_lane_*.txt): one wave running the rounds for the words of four tiles
+// (fewer instructions, but three waves of four idle meanwhile: 0.229 against 0.200 ms), tiles that place their own output by a
+// decoupled look-back, and tiles that plan themselves (two launches instead of four).
 // Token ids, offsets and the launches around the kernel (plan, scan, gather / the dedup records) are those of the kernel above.
 template <int Cap>
 struct LaneLds {
   static constexpr int Blocks = Cap / 64;
-  __attribute__((aligned(16))) uint8_t txt[Cap + 16];
+  __attribute__((aligned(16))) uint8_t txt[Cap + 16];  // staged bytes; once the split is done, a single-wave kernel's word list
   uint32_t sym[Cap + 4];      // per symbol: id (| SWT_BPE_CONT unless it opens its word), kInvalidTok once consumed
   uint32_t val[Cap + 4];      // per symbol: table value of (this symbol, next live symbol of the word), kNoRank when none
   uint16_t wl[Cap + 2];       // first symbol of every word, in text order
-  // (the multi-symbol words by length class -- 16-bit indices into wl[] -- reuse txt[] once the split is done)
   unsigned long long sbits[Blocks + 1];    // sentence-start bit per byte
   unsigned long long symmask[Blocks + 1];  // symbol bit per byte
   unsigned long long vmask[Blocks + 1];    // phase E: live-token bit per symbol
@@ -663,15 +664,31 @@ struct LaneLds {
   GiantResult giant;
 };
 
-// Mode 3 of bpe_lane_kernel: the tile places its own output (tile_lookback, swt_tile.h) -- no scan and no gather launch
-struct FusedOut {
-  unsigned long long *state;  // one look-back word per tile
-  uint32_t epoch;
-  uint32_t *err;
-  uint32_t *out_ids;
-  uint64_t *out_off, *n_tokens;
-  uint64_t n_sent, n_tiles;
+// What a wave carries from chunk to chunk of its tile, and what it knows about the chunk at hand.
+struct LaneTile {
+  uint64_t s_lo, s_hi;           // the tile's sentences
+  uint64_t span_base, span_end;  // their bytes
+  uint64_t s_next;               // first sentence whose local offset is not recorded yet
+  uint64_t cb;                   // first byte not encoded yet
+  uint32_t *tile_out;            // the tile's run in scratch
+  uint32_t run;                  // tokens emitted so far
 };
+struct LaneChunk {
+  uint64_t abase;                // 16-byte aligned base of the staged bytes
+  uint32_t off0, staged, nblk;   // first byte of the chunk inside the staged bytes, staged bytes, 64-byte blocks
+  uint32_t ce;                   // end of the chunk (the cut, or staged)
+  uint32_t nsym, nw;             // symbols and words of the chunk
+  int cut;                       // last word boundary (for a span longer than the chunk), -1 when none
+  bool last, giant;              // the tile ends with this chunk; the chunk was one word longer than the staged bytes
+};
+
+// LDS traffic between the lanes of ONE wave needs no hardware barrier (a wave's LDS instructions execute in order); the
+// compiler must not move accesses across the point, that is all.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 constexpr uint32_t kDirtyVal = 0xFFFFFFFEu;  // above every table value (ranks stay below 2^32 - 2), below kNoRank
 
@@ -705,402 +722,407 @@ __device__ void slow_word(uint32_t *S, uint32_t *V, const uint32_t n0, const Bpe
   for (uint32_t k = n; k < n0; k++) S[k] = kInvalidTok;
 }
 
+// classes of the first 1,024 code points: 16 per lane, two bits each (SWT_CLS_BERT_WS | SWT_CLS_BERT_PUNCT)
+template <int Cap>
+__device__ __forceinline__ void lane_classes(LaneLds<Cap> &L, const uint8_t *__restrict__ cls_tab, int lane) {
+  uint32_t w = 0;
+  if (cls_tab) {
+    const uint4 v = reinterpret_cast<const uint4 *>(cls_tab)[lane];
+    auto pk = [](uint32_t d) {
+      uint32_t x = d & 0x03030303u;
+      x = (x | (x >> 6)) & 0x000F000Fu;
+      return (x | (x >> 12)) & 0xFFu;
+    };
+    w = pk(v.x) | (pk(v.y) << 8) | (pk(v.z) << 16) | (pk(v.w) << 24);
+  }
+  L.cls2[lane] = w;
+}
+
+// ---- A + B/C of one chunk: stage the bytes, then 64 bytes per step: classes, word structure from ballot masks (as in the
+// kernel above), the dense symbols, the list of word starts, and the table value of every adjacent pair of a word.
+template <int Cap>
+__device__ __forceinline__ void lane_split(LaneLds<Cap> &L, const uint8_t *__restrict__ text, uint64_t n_bytes,
+                                           const uint64_t *__restrict__ sent_off, const uint8_t *__restrict__ cls_tab,
+                                           const BpeSlot *__restrict__ slots, uint32_t sh, const LaneTile &T, LaneChunk &C, int lane) {
+  constexpr int Blocks = Cap / 64;
+  const unsigned long long lt = (1ull << lane) - 1ull;  // lanes below me
+  const unsigned long long le = (2ull << lane) - 1ull;  // me and below
+  const uint64_t abase = T.cb & ~15ull;
+  const uint32_t off0 = (uint32_t)(T.cb - abase);
+  const uint64_t avail = T.span_end - abase;
+  const bool last = avail <= (uint64_t)Cap;
+  const uint32_t staged = last ? (uint32_t)avail : (uint32_t)Cap;
+  const uint32_t nblk = (staged + 63) >> 6;
+
+  // ---- A. stage [abase, abase+staged): one dwordx4 per lane
+  for (uint32_t c = lane * 16; c < staged; c += 64 * 16) {
+    const uint64_t g = abase + c;
+    if (g + 16 <= n_bytes && ((reinterpret_cast<uintptr_t>(text + g) & 15) == 0)) {
+      *reinterpret_cast<uint4 *>(&L.txt[c]) = *reinterpret_cast<const uint4 *>(text + g);
+    } else {
+      for (int i = 0; i < 16; i++) L.txt[c + i] = (g + i < n_bytes) ? text[g + i] : (uint8_t)' ';
+    }
+  }
+  if (lane <= Blocks) L.sbits[lane] = 0ull;
+  wave_sync();
+  for (uint64_t s = T.s_next + lane; s < T.s_hi; s += 64) {
+    const uint64_t o = sent_off[s];
+    if (o >= abase + staged) break;
+    if (o >= T.cb) atomicOr(&L.sbits[(o - abase) >> 6], 1ull << ((o - abase) & 63));
+  }
+  wave_sync();
+
+  // ---- B/C.  Scalars carried from block to block:
+  uint32_t nsym = 0, nw = 0;  // symbols and words so far
+  bool prev_wb = true;        // the byte before this block belongs to a whitespace/punctuation char (or chunk start)
+  bool pend_open = false;     // the last symbol of the previous block may have its successor in this one
+  uint32_t pend_cp = 0;
+  int cut = -1;               // last word boundary (for a span longer than the chunk)
+  for (uint32_t blk = 0; blk < nblk; blk++) {
+    const uint32_t p = blk * 64 + lane;
+    const bool inr = p >= off0 && p < staged;
+    const uint8_t b = inr ? L.txt[p] : (uint8_t)' ';
+    const bool lead = !utf8_is_cont(b);
+    uint32_t cp = b;
+    if (b >= 0xC0) {
+      int len = utf8_len(b);
+      if (p + len > staged) len = (int)(staged - p);
+      if (len > 1) {
+        cp = b & (0xFF >> (len + 1));
+        for (int i = 1; i < len; i++) cp = (cp << 6) | (L.txt[p + i] & 0x3F);
+      }
+    }
+    uint32_t c = kClsWs;  // bytes outside the chunk behave as whitespace
+    if (inr && lead)
+      c = cp < 1024u ? ((L.cls2[cp >> 4] >> ((cp & 15u) << 1)) & 3u) : ((cls_tab && cp < kNumCodePoints) ? (cls_tab[cp] & 3u) : 0u);
+    const unsigned long long INR = __ballot(inr);
+    const unsigned long long LEAD = __ballot(lead);
+    const unsigned long long WSm = __ballot(lead && (c & kClsWs));
+    const unsigned long long PNm = __ballot(lead && (c & kClsPunct));
+    const unsigned long long CONT = ~LEAD;
+    unsigned long long WB = WSm | PNm | ((prev_wb && (CONT & 1ull)) ? 1ull : 0ull);
+    WB |= (WB << 1) & CONT;
+    WB |= (WB << 1) & CONT;
+    WB |= (WB << 1) & CONT;
+    const unsigned long long SS = L.sbits[blk];
+    const unsigned long long first_bit = blk == 0 ? (1ull << off0) : 0ull;  // off0 < 16
+    const unsigned long long before = (WB << 1) | (prev_wb ? 1ull : 0ull) | SS | first_bit;
+    const unsigned long long SYM = LEAD & ~WSm & INR;
+    const unsigned long long WSTART = SYM & (PNm | before);
+    {
+      const unsigned long long CUT = LEAD & (WSm | PNm | SS) & __ballot(inr && p > off0 && p + 4 <= staged);
+      if (CUT) cut = (int)(blk * 64 + 63 - __builtin_clzll(CUT));
+    }
+    const bool is_sym = (SYM >> lane) & 1ull;
+    const bool wstart = (WSTART >> lane) & 1ull;
+    const unsigned long long after = SYM & ~le;
+    const uint32_t q = after ? (uint32_t)__builtin_ctzll(after) : 64u;
+    const bool hasnext = is_sym && q < 64 && !((WSTART >> (q & 63)) & 1ull);
+    const uint32_t f = SYM ? (uint32_t)__builtin_ctzll(SYM) : 64u;
+    const bool joins = pend_open && f < 64 && !((WSTART >> (f & 63)) & 1ull);
+    const uint32_t si = nsym + (uint32_t)__popcll(SYM & lt);
+    const uint32_t cpn = __shfl(cp, (int)(q & 63));
+    // lane 63 never has a successor inside the block: it probes the pair that straddles the block boundary
+    const bool jp = joins && lane == 63;
+    const uint32_t cpf = __builtin_amdgcn_readlane(cp, (int)(f & 63));
+    const bool want = hasnext || jp;
+    uint32_t v = kNoRank;
+    if (want) v = slot_value(slots, sh, jp ? pend_cp : cp, jp ? cpf : cpn);
+    if (is_sym) {
+      L.sym[si] = wstart ? cp : (cp | SWT_BPE_CONT);
+      if (!hasnext) L.val[si] = kNoRank;
+    }
+    if (want) L.val[jp ? nsym - 1 : si] = v;
+    if (wstart) L.wl[nw + (uint32_t)__popcll(WSTART & lt)] = (uint16_t)si;
+    if (lane == 0) { L.symmask[blk] = SYM; L.sympre[blk] = nsym; }
+    nw += (uint32_t)__popcll(WSTART);
+    nsym += (uint32_t)__popcll(SYM);
+    if (SYM) {
+      const int li = 63 - __builtin_clzll(SYM);
+      const unsigned long long tail = li == 63 ? 0ull : ~((2ull << li) - 1ull);
+      pend_open = ((WSm | PNm | SS) & tail) == 0ull && !((PNm >> li) & 1ull);
+      pend_cp = __builtin_amdgcn_readlane(cp, li);
+    } else {
+      pend_open = false;  // a block without symbols holds whitespace: every word ended
+    }
+    prev_wb = (WB >> 63) & 1ull;
+  }
+  wave_sync();
+  C.abase = abase;
+  C.off0 = off0;
+  C.staged = staged;
+  C.nblk = nblk;
+  C.ce = staged;
+  C.nsym = nsym;
+  C.nw = nw;
+  C.cut = cut;
+  C.last = last;
+  C.giant = false;
+}
+
+// ---- the end of a chunk that does not end the tile: one word longer than the staged bytes goes to the one-lane walker (and the
+// chunk is done: C.giant), anything else is cut at its last word boundary.  Closes the word list either way.
+template <int Cap, int Mode>
+__device__ __forceinline__ void lane_chunk_end(LaneLds<Cap> &L, const uint8_t *__restrict__ text, const uint64_t *__restrict__ sent_off,
+                                               const uint8_t *__restrict__ cls_tab, const BpeSlot *__restrict__ slots, uint32_t sh,
+                                               LaneTile &T, LaneChunk &C, int lane, uint32_t *__restrict__ sent_local,
+                                               const uint32_t *__restrict__ uslot, unsigned long long *__restrict__ rec,
+                                               unsigned long long *__restrict__ drec, const DirectOut &direct) {
+  constexpr bool kDirect = Mode == 2, kRec = Mode == 1;
+  if (!C.last) {
+    if (C.cut < 0) {
+      // a single word longer than the LDS chunk: one lane, global memory
+      if (lane == 0) {
+        uint64_t s = T.s_next;
+        while (s < T.s_hi && sent_off[s] <= T.cb) s++;
+        const uint64_t send = sent_off[s];  // s <= s_hi and sent_off[s_hi] = span_end > cb
+        L.giant = giant_word(text, T.cb, send, cls_tab, slots, sh, T.tile_out + T.run);
+      }
+      wave_sync();
+      const GiantResult g = L.giant;
+      uint32_t mine = 0;
+      for (uint64_t s = T.s_next + lane; s < T.s_hi; s += 64) {
+        if (sent_off[s] >= g.end) break;
+        if (kDirect) direct.off[s] = T.run; else if (Mode == 0) sent_local[s] = T.run;
+        if (kRec) {
+          drec[s] = (unsigned long long)(T.span_base + T.run) | ((unsigned long long)g.ntok << 32);
+          rec[uslot[s]] = (unsigned long long)s | ((unsigned long long)g.ntok << 32);
+        }
+        mine++;
+      }
+      for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+      T.s_next += mine;
+      T.run += g.ntok;
+      T.cb = g.end;
+      C.giant = true;
+      C.nw = 0;
+      C.nsym = 0;
+      wave_sync();
+      return;
+    }
+    // the cut is a word boundary: symbols and words at or beyond it are staged again by the next chunk
+    C.ce = (uint32_t)C.cut;
+    C.nsym = L.sympre[C.ce >> 6] + (uint32_t)__popcll(L.symmask[C.ce >> 6] & ((1ull << (C.ce & 63)) - 1ull));
+    uint32_t keep = 0;
+    for (uint32_t k0 = 0; k0 < C.nw; k0 += 64) {
+      const uint32_t k = k0 + lane;
+      keep += (uint32_t)__popcll(__ballot(k < C.nw && L.wl[k] < C.nsym));
+    }
+    C.nw = keep;
+  }
+  if (lane == 0) L.wl[C.nw] = (uint16_t)C.nsym;
+  wave_sync();
+}
+
+// ---- W. the words with two symbols or more by length class: how many, then their entries (tag | index in wl[]) into a list
+// that holds all 9+ words first, then the 5-8, then the 2-4 (o2 / o1 / o0 = where this wave's share of each class begins)
+template <int Cap>
+__device__ __forceinline__ void lane_words_count(const LaneLds<Cap> &L, uint32_t nw, int lane, uint32_t &c2, uint32_t &c1, uint32_t &c0) {
+  c0 = c1 = c2 = 0;
+  for (uint32_t k0 = 0; k0 < nw; k0 += 64) {
+    const uint32_t k = k0 + lane;
+    const uint32_t n = k < nw ? (uint32_t)L.wl[k + 1] - (uint32_t)L.wl[k] : 0u;
+    c0 += (uint32_t)__popcll(__ballot(n >= 2 && n <= 4));
+    c1 += (uint32_t)__popcll(__ballot(n >= 5 && n <= 8));
+    c2 += (uint32_t)__popcll(__ballot(n >= 9));
+  }
+}
+template <int Cap>
+__device__ __forceinline__ void lane_words_write(const LaneLds<Cap> &L, uint32_t nw, int lane, uint16_t *list, uint32_t o2, uint32_t o1,
+                                                 uint32_t o0, uint32_t tag) {
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (uint32_t k0 = 0; k0 < nw; k0 += 64) {
+    const uint32_t k = k0 + lane;
+    const uint32_t n = k < nw ? (uint32_t)L.wl[k + 1] - (uint32_t)L.wl[k] : 0u;
+    const unsigned long long M0 = __ballot(n >= 2 && n <= 4), M1 = __ballot(n >= 5 && n <= 8), M2 = __ballot(n >= 9);
+    if (n >= 9) list[o2 + (uint32_t)__popcll(M2 & lt)] = (uint16_t)(tag | k);
+    else if (n >= 5) list[o1 + (uint32_t)__popcll(M1 & lt)] = (uint16_t)(tag | k);
+    else if (n >= 2) list[o0 + (uint32_t)__popcll(M0 & lt)] = (uint16_t)(tag | k);
+    o0 += (uint32_t)__popcll(M0);
+    o1 += (uint32_t)__popcll(M1);
+    o2 += (uint32_t)__popcll(M2);
+  }
+}
+
+// ---- D. merge rounds (bpe.py:210-238) over a list of words, one lane per word.  A lane whose word is finished takes the next
+// one of the list, so the wave goes through about as many rounds as its longest word needs -- the short words fill the lanes
+// beside it.  An entry is tile:4 | index:12 into that tile's wl[] (LL = the tiles of the workgroup).
+template <bool Packed, bool Proper, int Cap>
+__device__ __forceinline__ void lane_rounds(LaneLds<Cap> *LL, const uint16_t *list, uint32_t n_list, int lane,
+                                            const BpeSlot *__restrict__ slots, uint32_t sh, const uint32_t *__restrict__ merged_of_rank) {
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  uint32_t next = 0;          // first word of the list no lane has taken (the same in every lane)
+  uint32_t n = 0, alive = 0;  // this lane's word: symbols (0: none), live slots
+  uint32_t *S = LL[0].sym, *V = LL[0].val;
+  for (;;) {
+    const unsigned long long IDLE = __ballot(n == 0u);
+    if (IDLE && next < n_list) {
+      const uint32_t k = next + (uint32_t)__popcll(IDLE & lt);
+      if (n == 0u && k < n_list) {
+        const uint32_t e = list[k];
+        LaneLds<Cap> &L = LL[e >> 12];
+        const uint32_t base = L.wl[e & 0xFFFu];
+        n = (uint32_t)L.wl[(e & 0xFFFu) + 1] - base;
+        S = &L.sym[base];
+        V = &L.val[base];
+        alive = n >= 32u ? 0xFFFFFFFFu : (1u << n) - 1u;  // bit i: slot i still holds a symbol
+        if (!Proper || n > 32u) {
+          slow_word<Packed>(S, V, n, slots, sh, merged_of_rank);
+          n = 0u;
+        }
+      }
+      next += (uint32_t)__popcll(IDLE);
+    }
+    if (__ballot(n != 0u) == 0ull) {
+      if (next >= n_list) break;
+      continue;
+    }
+    if (n != 0u) {
+      // one round: leftmost minimum over the live slots' pair values, four slots per step
+      uint32_t m = kNoRank, im = 0;
+      if (Packed) {
+        // a packed value is rank:16 | merged:16 and a dead slot's value is all ones (written when the slot dies), so the key
+        // rank:16 | slot:5 finds minimum and place with one min per slot; slots past the word read slot n-1, which never
+        // has a pair; the merged symbol comes from the winning slot afterwards
+        const uint32_t nm1 = n - 1u;
+        uint32_t key = 0xFFFFFFFFu;
+        for (uint32_t i0 = 0; i0 < nm1; i0 += 4) {
+          const uint32_t i1 = min(i0 + 1u, nm1), i2 = min(i0 + 2u, nm1), i3 = min(i0 + 3u, nm1);
+          const uint32_t k0 = (V[i0] & 0xFFFF0000u) | i0, k1 = (V[i1] & 0xFFFF0000u) | i1;
+          const uint32_t k2 = (V[i2] & 0xFFFF0000u) | i2, k3 = (V[i3] & 0xFFFF0000u) | i3;
+          key = min(min(key, k0), min(min(k1, k2), k3));
+        }
+        if (key < 0xFFFF0000u) { im = key & 31u; m = V[im]; }
+      } else {
+        for (uint32_t i0 = 0; i0 < n; i0 += 4) {
+          const uint32_t a = alive >> i0;
+          uint32_t v0 = V[i0], v1 = V[i0 + 1], v2 = V[i0 + 2], v3 = V[i0 + 3];  // the arrays are padded by four
+          v0 = (a & 1u) ? v0 : kNoRank;
+          v1 = (a & 2u) ? v1 : kNoRank;
+          v2 = (a & 4u) ? v2 : kNoRank;
+          v3 = (a & 8u) ? v3 : kNoRank;
+          if (v0 < m) { m = v0; im = i0; }
+          if (v1 < m) { m = v1; im = i0 + 1; }
+          if (v2 < m) { m = v2; im = i0 + 2; }
+          if (v3 < m) { m = v3; im = i0 + 3; }
+        }
+      }
+      // slot im merges with the next live slot r; pl / rr = the live slots either side of the pair
+      const uint32_t hi = alive & (0xFFFFFFFEu << im);
+      if (m == kNoRank || hi == 0u) {
+        n = 0u;  // the word is finished (hi == 0 cannot happen: a slot with a pair value has a live successor)
+      } else {
+        const uint32_t r = (uint32_t)__builtin_ctz(hi);
+        const uint32_t hi2 = hi & (hi - 1u);
+        const uint32_t lo = alive & ((1u << im) - 1u);
+        const bool has_rr = hi2 != 0u, has_pl = lo != 0u;
+        const uint32_t rr = has_rr ? (uint32_t)__builtin_ctz(hi2) : 0u, pl = has_pl ? 31u - (uint32_t)__builtin_clz(lo) : 0u;
+        alive &= ~(1u << r);
+        const uint32_t mg = Packed ? (SWT_SYM_BASE + (m & 0xFFFFu)) : merged_of_rank[m];
+        const uint32_t sl = S[pl] & ~SWT_BPE_CONT, sr = S[rr] & ~SWT_BPE_CONT;
+        S[im] = im ? (mg | SWT_BPE_CONT) : mg;
+        S[r] = kInvalidTok;
+        V[r] = kNoRank;
+        const uint32_t v1 = slot_value(slots, sh, sl, mg), v2 = slot_value(slots, sh, mg, sr);
+        if (has_pl) V[pl] = v1;
+        V[im] = has_rr ? v2 : kNoRank;
+      }
+    }
+  }
+}
+
+// ---- E + F of one chunk: order-preserving compaction of the live symbols into the tile's output run, then the tile-local
+// token offset of every sentence starting in [cb, ce) (and == ce on the last chunk): byte -> symbol through the split's
+// masks, symbol -> token through phase E's.  Advances the tile.
+template <int Cap, int Mode>
+__device__ __forceinline__ void lane_emit(LaneLds<Cap> &L, const uint64_t *__restrict__ sent_off, LaneTile &T, const LaneChunk &C, int lane,
+                                          uint32_t *__restrict__ sent_local, const uint32_t *__restrict__ uslot,
+                                          unsigned long long *__restrict__ rec, unsigned long long *__restrict__ drec,
+                                          const DirectOut &direct) {
+  constexpr bool kDirect = Mode == 2, kRec = Mode == 1;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  uint32_t total = 0;
+  for (uint32_t j0 = 0; j0 < C.nsym; j0 += 64) {
+    const uint32_t j = j0 + lane;
+    const uint32_t sv = j < C.nsym ? L.sym[j] : kInvalidTok;
+    const unsigned long long m = __ballot(sv != kInvalidTok);
+    if (lane == 0) { L.vmask[j0 >> 6] = m; L.blkpre[j0 >> 6] = total; }
+    if (sv != kInvalidTok) T.tile_out[T.run + total + (uint32_t)__popcll(m & lt)] = sv;
+    total += (uint32_t)__popcll(m);
+  }
+  wave_sync();
+  auto tokens_before = [&](uint64_t rel) -> uint32_t {
+    if (rel >= C.ce || (rel >> 6) >= C.nblk) return total;
+    const uint32_t sidx = L.sympre[rel >> 6] + (uint32_t)__popcll(L.symmask[rel >> 6] & ((1ull << (rel & 63)) - 1ull));
+    if (sidx >= C.nsym) return total;
+    return L.blkpre[sidx >> 6] + (uint32_t)__popcll(L.vmask[sidx >> 6] & ((1ull << (sidx & 63)) - 1ull));
+  };
+  uint32_t mine = 0;
+  for (uint64_t s = T.s_next + lane; s < T.s_hi; s += 64) {
+    const uint64_t rel = sent_off[s] - C.abase;
+    if (rel > C.ce || (rel == C.ce && !C.last)) break;
+    const uint32_t e = tokens_before(rel);
+    if (kDirect) direct.off[s] = T.run + e; else if (Mode == 0) sent_local[s] = T.run + e;
+    if (kRec && rel < C.ce) {  // a word never straddles the cut, so its end lies in this chunk too
+      const uint32_t e2 = tokens_before(sent_off[s + 1] - C.abase);
+      drec[s] = (unsigned long long)(T.span_base + T.run + e) | ((unsigned long long)(e2 - e) << 32);
+      rec[uslot[s]] = (unsigned long long)s | ((unsigned long long)(e2 - e) << 32);
+    }
+    mine++;
+  }
+  for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+  T.s_next += mine;
+  T.run += total;
+  T.cb = C.abase + C.ce;
+  wave_sync();
+}
+
+// One wave per tile: running text (Mode 0), the unique words of the dedup path (Mode 1), the single-workgroup call (Mode 2).
 template <bool Packed, bool Proper, int Cap, int Mode>
 __global__ __launch_bounds__(64) void bpe_lane_kernel(
     const uint8_t *__restrict__ text, uint64_t n_bytes, const uint64_t *__restrict__ sent_off,
     const uint64_t *__restrict__ plan, const uint8_t *__restrict__ cls_tab, const BpeSlot *__restrict__ slots,
     uint32_t sh, const uint32_t *__restrict__ merged_of_rank, uint32_t *__restrict__ scratch,
     uint32_t *__restrict__ sent_local, uint32_t *__restrict__ tile_tok, const uint32_t *__restrict__ uslot,
-    unsigned long long *__restrict__ rec, unsigned long long *__restrict__ drec, DirectOut direct, FusedOut fused) {
-  constexpr bool kDirect = Mode == 2, kRec = Mode == 1, kFused = Mode == 3;
-  constexpr int Blocks = Cap / 64;
+    unsigned long long *__restrict__ rec, unsigned long long *__restrict__ drec, DirectOut direct) {
+  constexpr bool kDirect = Mode == 2;
   __shared__ LaneLds<Cap> L;
   const int lane = threadIdx.x;
-  const unsigned long long lt = (1ull << lane) - 1ull;  // lanes below me
-  const unsigned long long le = (2ull << lane) - 1ull;  // me and below
   const uint64_t t = blockIdx.x;
-  const uint64_t s_lo = kDirect ? 0 : plan[t], s_hi = kDirect ? direct.n_sent : plan[t + 1];
-  if (s_lo == s_hi) {
+  LaneTile T;
+  T.s_lo = kDirect ? 0 : plan[t];
+  T.s_hi = kDirect ? direct.n_sent : plan[t + 1];
+  if (T.s_lo == T.s_hi) {
     if (Mode == 0 && lane == 0) tile_tok[t] = 0;
-    if (kFused) {
-      if (t + 1 == fused.n_tiles) {  // the last tile closes the output even when it holds no sentence
-        const uint32_t before = tile_lookback(fused.state, t, fused.epoch, 0u, lane, fused.err);
-        if (lane == 0) { fused.out_off[fused.n_sent] = before; *fused.n_tokens = before; }
-      } else if (lane == 0) {
-        __hip_atomic_store(&fused.state[t], ((unsigned long long)fused.epoch << 34) | (t == 0 ? kLbIncl : kLbAgg), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
     return;
   }
-  {
-    // classes of the first 1,024 code points: 16 per lane, two bits each (SWT_CLS_BERT_WS | SWT_CLS_BERT_PUNCT)
-    uint32_t w = 0;
-    if (cls_tab) {
-      const uint4 v = reinterpret_cast<const uint4 *>(cls_tab)[lane];
-      auto pk = [](uint32_t d) {
-        uint32_t x = d & 0x03030303u;
-        x = (x | (x >> 6)) & 0x000F000Fu;
-        return (x | (x >> 12)) & 0xFFu;
-      };
-      w = pk(v.x) | (pk(v.y) << 8) | (pk(v.z) << 16) | (pk(v.w) << 24);
-    }
-    L.cls2[lane] = w;
-  }
-  const uint64_t span_base = sent_off[s_lo], span_end = sent_off[s_hi];
-  uint32_t *const tile_out = scratch + span_base;
-  uint32_t run = 0;        // tokens emitted by this tile so far
-  uint64_t s_next = s_lo;  // first sentence whose local offset is not recorded yet
-  uint64_t cb = span_base;
-  // fused form: a tile whose span fits one chunk (nearly all) keeps its tokens in LDS until it knows where they go; a longer
-  // span goes through its scratch run as in mode 0 and is copied at the end
-  const bool single = kFused && span_end - (span_base & ~15ull) <= (uint64_t)Cap;
-  uint32_t before = 0;     // fused form: tokens of all tiles before this one
-
+  lane_classes(L, cls_tab, lane);
+  T.span_base = sent_off[T.s_lo];
+  T.span_end = sent_off[T.s_hi];
+  T.tile_out = scratch + T.span_base;
+  T.run = 0;
+  T.s_next = T.s_lo;
+  T.cb = T.span_base;
+  uint16_t *const list = reinterpret_cast<uint16_t *>(L.txt);  // the staged bytes are not read again once the split is done
   for (;;) {
-    const uint64_t abase = cb & ~15ull;
-    const uint32_t off0 = (uint32_t)(cb - abase);
-    const uint64_t avail = span_end - abase;
-    const bool last = avail <= (uint64_t)Cap;
-    const uint32_t staged = last ? (uint32_t)avail : (uint32_t)Cap;
-    const uint32_t nblk = (staged + 63) >> 6;
-
-    // ---- A. stage [abase, abase+staged): one dwordx4 per lane
-    for (uint32_t c = lane * 16; c < staged; c += 64 * 16) {
-      const uint64_t g = abase + c;
-      if (g + 16 <= n_bytes && ((reinterpret_cast<uintptr_t>(text + g) & 15) == 0)) {
-        *reinterpret_cast<uint4 *>(&L.txt[c]) = *reinterpret_cast<const uint4 *>(text + g);
-      } else {
-        for (int i = 0; i < 16; i++) L.txt[c + i] = (g + i < n_bytes) ? text[g + i] : (uint8_t)' ';
-      }
-    }
-    if (lane <= Blocks) L.sbits[lane] = 0ull;
-    __syncthreads();
-    for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
-      const uint64_t o = sent_off[s];
-      if (o >= abase + staged) break;
-      if (o >= cb) atomicOr(&L.sbits[(o - abase) >> 6], 1ull << ((o - abase) & 63));
-    }
-    __syncthreads();
-
-    // ---- B/C. 64 bytes per step: classes, word structure from ballot masks (as in the kernel above), and the table value of
-    // every adjacent pair of a word.  Scalars carried from block to block:
-    uint32_t nsym = 0, nw = 0;  // symbols and words so far
-    bool prev_wb = true;        // the byte before this block belongs to a whitespace/punctuation char (or chunk start)
-    bool pend_open = false;     // the last symbol of the previous block may have its successor in this one
-    uint32_t pend_cp = 0;
-    int cut = -1;               // last word boundary (for a span longer than the chunk)
-#if defined(SWT_LANE_ABL) && SWT_LANE_ABL >= 4
-    for (uint32_t blk = 0; blk < 0; blk++) {
-#else
-    for (uint32_t blk = 0; blk < nblk; blk++) {
-#endif
-      const uint32_t p = blk * 64 + lane;
-      const bool inr = p >= off0 && p < staged;
-      const uint8_t b = inr ? L.txt[p] : (uint8_t)' ';
-      const bool lead = !utf8_is_cont(b);
-      uint32_t cp = b;
-      if (b >= 0xC0) {
-        int len = utf8_len(b);
-        if (p + len > staged) len = (int)(staged - p);
-        if (len > 1) {
-          cp = b & (0xFF >> (len + 1));
-          for (int i = 1; i < len; i++) cp = (cp << 6) | (L.txt[p + i] & 0x3F);
-        }
-      }
-      uint32_t c = kClsWs;  // bytes outside the chunk behave as whitespace
-      if (inr && lead)
-        c = cp < 1024u ? ((L.cls2[cp >> 4] >> ((cp & 15u) << 1)) & 3u) : ((cls_tab && cp < kNumCodePoints) ? (cls_tab[cp] & 3u) : 0u);
-      const unsigned long long INR = __ballot(inr);
-      const unsigned long long LEAD = __ballot(lead);
-      const unsigned long long WSm = __ballot(lead && (c & kClsWs));
-      const unsigned long long PNm = __ballot(lead && (c & kClsPunct));
-      const unsigned long long CONT = ~LEAD;
-      unsigned long long WB = WSm | PNm | ((prev_wb && (CONT & 1ull)) ? 1ull : 0ull);
-      WB |= (WB << 1) & CONT;
-      WB |= (WB << 1) & CONT;
-      WB |= (WB << 1) & CONT;
-      const unsigned long long SS = L.sbits[blk];
-      const unsigned long long first_bit = blk == 0 ? (1ull << off0) : 0ull;  // off0 < 16
-      const unsigned long long before = (WB << 1) | (prev_wb ? 1ull : 0ull) | SS | first_bit;
-      const unsigned long long SYM = LEAD & ~WSm & INR;
-      const unsigned long long WSTART = SYM & (PNm | before);
-      {
-        const unsigned long long CUT = LEAD & (WSm | PNm | SS) & __ballot(inr && p > off0 && p + 4 <= staged);
-        if (CUT) cut = (int)(blk * 64 + 63 - __builtin_clzll(CUT));
-      }
-      const bool is_sym = (SYM >> lane) & 1ull;
-      const bool wstart = (WSTART >> lane) & 1ull;
-      const unsigned long long after = SYM & ~le;
-      const uint32_t q = after ? (uint32_t)__builtin_ctzll(after) : 64u;
-      const bool hasnext = is_sym && q < 64 && !((WSTART >> (q & 63)) & 1ull);
-      const uint32_t f = SYM ? (uint32_t)__builtin_ctzll(SYM) : 64u;
-      const bool joins = pend_open && f < 64 && !((WSTART >> (f & 63)) & 1ull);
-      const uint32_t si = nsym + (uint32_t)__popcll(SYM & lt);
-      const uint32_t cpn = __shfl(cp, (int)(q & 63));
-      // lane 63 never has a successor inside the block: it probes the pair that straddles the block boundary
-      const bool jp = joins && lane == 63;
-      const uint32_t cpf = __builtin_amdgcn_readlane(cp, (int)(f & 63));
-      const bool want = hasnext || jp;
-      uint32_t v = kNoRank;
-#if !defined(SWT_LANE_ABL) || SWT_LANE_ABL < 3
-      if (want) v = slot_value(slots, sh, jp ? pend_cp : cp, jp ? cpf : cpn);
-#endif
-      if (is_sym) {
-        L.sym[si] = wstart ? cp : (cp | SWT_BPE_CONT);
-        if (!hasnext) L.val[si] = kNoRank;
-      }
-      if (want) L.val[jp ? nsym - 1 : si] = v;
-      if (wstart) L.wl[nw + (uint32_t)__popcll(WSTART & lt)] = (uint16_t)si;
-      if (lane == 0) { L.symmask[blk] = SYM; L.sympre[blk] = nsym; }
-      nw += (uint32_t)__popcll(WSTART);
-      nsym += (uint32_t)__popcll(SYM);
-      if (SYM) {
-        const int li = 63 - __builtin_clzll(SYM);
-        const unsigned long long tail = li == 63 ? 0ull : ~((2ull << li) - 1ull);
-        pend_open = ((WSm | PNm | SS) & tail) == 0ull && !((PNm >> li) & 1ull);
-        pend_cp = __builtin_amdgcn_readlane(cp, li);
-      } else {
-        pend_open = false;  // a block without symbols holds whitespace: every word ended
-      }
-      prev_wb = (WB >> 63) & 1ull;
-    }
-    __syncthreads();
-
-    // ---- chunk end
-    uint32_t ce = staged;
-    if (!last) {
-      if (cut < 0) {
-        // a single word longer than the LDS chunk: one lane, global memory
-        if (lane == 0) {
-          uint64_t s = s_next;
-          while (s < s_hi && sent_off[s] <= cb) s++;
-          const uint64_t send = sent_off[s];  // s <= s_hi and sent_off[s_hi] = span_end > cb
-          L.giant = giant_word(text, cb, send, cls_tab, slots, sh, tile_out + run);
-        }
-        __syncthreads();
-        const GiantResult g = L.giant;
-        uint32_t mine = 0;
-        for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
-          if (sent_off[s] >= g.end) break;
-          if (kDirect) direct.off[s] = run; else if (Mode == 0 || kFused) sent_local[s] = run;
-          if (kRec) {
-            drec[s] = (unsigned long long)(span_base + run) | ((unsigned long long)g.ntok << 32);
-            rec[uslot[s]] = (unsigned long long)s | ((unsigned long long)g.ntok << 32);
-          }
-          mine++;
-        }
-        for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
-        s_next += mine;
-        run += g.ntok;
-        cb = g.end;
-        __syncthreads();
-        continue;
-      }
-      // the cut is a word boundary: symbols and words at or beyond it are staged again by the next chunk
-      ce = (uint32_t)cut;
-      nsym = L.sympre[ce >> 6] + (uint32_t)__popcll(L.symmask[ce >> 6] & ((1ull << (ce & 63)) - 1ull));
-      uint32_t keep = 0;
-      for (uint32_t k0 = 0; k0 < nw; k0 += 64) {
-        const uint32_t k = k0 + lane;
-        keep += (uint32_t)__popcll(__ballot(k < nw && L.wl[k] < nsym));
-      }
-      nw = keep;
-    }
-    if (lane == 0) L.wl[nw] = (uint16_t)nsym;
-    __syncthreads();
-
-    // ---- W. the words with two symbols or more, longest class first (9+, 5-8, 2-4 symbols): their indices in wl[]
-    uint16_t *const wl2 = reinterpret_cast<uint16_t *>(L.txt);  // the staged bytes are not read again (at most Cap / 2 entries)
-    uint32_t nw2 = 0;
-#if defined(SWT_LANE_ABL) && SWT_LANE_ABL >= 2
-    if (false)
-#endif
-    {
-      uint32_t c0 = 0, c1 = 0, c2 = 0;
-      for (uint32_t k0 = 0; k0 < nw; k0 += 64) {
-        const uint32_t k = k0 + lane;
-        const uint32_t n = k < nw ? (uint32_t)L.wl[k + 1] - (uint32_t)L.wl[k] : 0u;
-        c0 += (uint32_t)__popcll(__ballot(n >= 2 && n <= 4));
-        c1 += (uint32_t)__popcll(__ballot(n >= 5 && n <= 8));
-        c2 += (uint32_t)__popcll(__ballot(n >= 9));
-      }
-      uint32_t o2 = 0, o1 = c2, o0 = c2 + c1;
-      nw2 = c0 + c1 + c2;
-      for (uint32_t k0 = 0; k0 < nw; k0 += 64) {
-        const uint32_t k = k0 + lane;
-        const uint32_t n = k < nw ? (uint32_t)L.wl[k + 1] - (uint32_t)L.wl[k] : 0u;
-        const unsigned long long M0 = __ballot(n >= 2 && n <= 4), M1 = __ballot(n >= 5 && n <= 8), M2 = __ballot(n >= 9);
-        if (n >= 9) wl2[o2 + (uint32_t)__popcll(M2 & lt)] = (uint16_t)k;
-        else if (n >= 5) wl2[o1 + (uint32_t)__popcll(M1 & lt)] = (uint16_t)k;
-        else if (n >= 2) wl2[o0 + (uint32_t)__popcll(M0 & lt)] = (uint16_t)k;
-        o0 += (uint32_t)__popcll(M0);
-        o1 += (uint32_t)__popcll(M1);
-        o2 += (uint32_t)__popcll(M2);
-      }
-    }
-    __syncthreads();
-
-    // ---- D. merge rounds (bpe.py:210-238), one lane per word.  A lane whose word is finished takes the next one of the list,
-    // so the wave goes through about as many rounds as its longest word needs -- the short words fill the lanes beside it
-#if defined(SWT_LANE_ABL) && SWT_LANE_ABL >= 1   // diagnostic builds (tools/gpu_r03_p.sh): results are WRONG
-    nw2 = 0;
-#endif
-    {
-      uint32_t next = 0;  // first word of the list no lane has taken (the same in every lane)
-      uint32_t n = 0, alive = 0;  // this lane's word: symbols (0: none), live slots
-      uint32_t *S = L.sym, *V = L.val;
-      for (;;) {
-        const unsigned long long IDLE = __ballot(n == 0u);
-        if (IDLE && next < nw2) {
-          const uint32_t k = next + (uint32_t)__popcll(IDLE & lt);
-          if (n == 0u && k < nw2) {
-            const uint32_t w = wl2[k];
-            const uint32_t base = L.wl[w];
-            n = (uint32_t)L.wl[w + 1] - base;
-            S = &L.sym[base];
-            V = &L.val[base];
-            alive = n >= 32u ? 0xFFFFFFFFu : (1u << n) - 1u;  // bit i: slot i still holds a symbol
-            if (!Proper || n > 32u) {
-              slow_word<Packed>(S, V, n, slots, sh, merged_of_rank);
-              n = 0u;
-            }
-          }
-          next += (uint32_t)__popcll(IDLE);
-        }
-        if (__ballot(n != 0u) == 0ull) {
-          if (next >= nw2) break;
-          continue;
-        }
-        if (n != 0u) {
-          // one round: leftmost minimum over the live slots' pair values, four slots per step
-          uint32_t m = kNoRank, im = 0;
-          if (Packed) {
-            // a packed value is rank:16 | merged:16 and a dead slot's value is all ones (written when the slot dies), so the key
-            // rank:16 | slot:5 finds minimum and place with one min per slot; slots past the word read slot n-1, which never
-            // has a pair; the merged symbol comes from the winning slot afterwards
-            const uint32_t nm1 = n - 1u;
-            uint32_t key = 0xFFFFFFFFu;
-            for (uint32_t i0 = 0; i0 < nm1; i0 += 4) {
-              const uint32_t i1 = min(i0 + 1u, nm1), i2 = min(i0 + 2u, nm1), i3 = min(i0 + 3u, nm1);
-              const uint32_t k0 = (V[i0] & 0xFFFF0000u) | i0, k1 = (V[i1] & 0xFFFF0000u) | i1;
-              const uint32_t k2 = (V[i2] & 0xFFFF0000u) | i2, k3 = (V[i3] & 0xFFFF0000u) | i3;
-              key = min(min(key, k0), min(min(k1, k2), k3));
-            }
-            if (key < 0xFFFF0000u) { im = key & 31u; m = V[im]; }
-          } else {
-            for (uint32_t i0 = 0; i0 < n; i0 += 4) {
-              const uint32_t a = alive >> i0;
-              uint32_t v0 = V[i0], v1 = V[i0 + 1], v2 = V[i0 + 2], v3 = V[i0 + 3];  // the arrays are padded by four
-              v0 = (a & 1u) ? v0 : kNoRank;
-              v1 = (a & 2u) ? v1 : kNoRank;
-              v2 = (a & 4u) ? v2 : kNoRank;
-              v3 = (a & 8u) ? v3 : kNoRank;
-              if (v0 < m) { m = v0; im = i0; }
-              if (v1 < m) { m = v1; im = i0 + 1; }
-              if (v2 < m) { m = v2; im = i0 + 2; }
-              if (v3 < m) { m = v3; im = i0 + 3; }
-            }
-          }
-          // slot im merges with the next live slot r; pl / rr = the live slots either side of the pair
-          const uint32_t hi = alive & (0xFFFFFFFEu << im);
-          if (m == kNoRank || hi == 0u) {
-            n = 0u;  // the word is finished (hi == 0 cannot happen: a slot with a pair value has a live successor)
-          } else {
-            const uint32_t r = (uint32_t)__builtin_ctz(hi);
-            const uint32_t hi2 = hi & (hi - 1u);
-            const uint32_t lo = alive & ((1u << im) - 1u);
-            const bool has_rr = hi2 != 0u, has_pl = lo != 0u;
-            const uint32_t rr = has_rr ? (uint32_t)__builtin_ctz(hi2) : 0u, pl = has_pl ? 31u - (uint32_t)__builtin_clz(lo) : 0u;
-            alive &= ~(1u << r);
-            const uint32_t mg = Packed ? (SWT_SYM_BASE + (m & 0xFFFFu)) : merged_of_rank[m];
-            const uint32_t sl = S[pl] & ~SWT_BPE_CONT, sr = S[rr] & ~SWT_BPE_CONT;
-            S[im] = im ? (mg | SWT_BPE_CONT) : mg;
-            S[r] = kInvalidTok;
-            V[r] = kNoRank;
-            const uint32_t v1 = slot_value(slots, sh, sl, mg), v2 = slot_value(slots, sh, mg, sr);
-            if (has_pl) V[pl] = v1;
-            V[im] = has_rr ? v2 : kNoRank;
-          }
-        }
-      }
-    }
-    __syncthreads();
-
-    // ---- E. order-preserving compaction of the live symbols into the tile's output run
-    uint32_t total = 0;
-    if (single) {
-      // count, find this tile's place (tile_lookback), then write the tokens where they belong
-      for (uint32_t j0 = 0; j0 < nsym; j0 += 64) {
-        const uint32_t j = j0 + lane;
-        const unsigned long long m = __ballot(j < nsym && L.sym[j] != kInvalidTok);
-        if (lane == 0) { L.vmask[j0 >> 6] = m; L.blkpre[j0 >> 6] = total; }
-        total += (uint32_t)__popcll(m);
-      }
-      before = tile_lookback(fused.state, t, fused.epoch, total, lane, fused.err);
-      uint32_t at = 0;
-      for (uint32_t j0 = 0; j0 < nsym; j0 += 64) {
-        const uint32_t j = j0 + lane;
-        const uint32_t sv = j < nsym ? L.sym[j] : kInvalidTok;
-        const unsigned long long m = __ballot(sv != kInvalidTok);
-        if (sv != kInvalidTok) fused.out_ids[(uint64_t)before + at + (uint32_t)__popcll(m & lt)] = sv;
-        at += (uint32_t)__popcll(m);
-      }
-    } else {
-      for (uint32_t j0 = 0; j0 < nsym; j0 += 64) {
-        const uint32_t j = j0 + lane;
-        const uint32_t sv = j < nsym ? L.sym[j] : kInvalidTok;
-        const unsigned long long m = __ballot(sv != kInvalidTok);
-        if (lane == 0) { L.vmask[j0 >> 6] = m; L.blkpre[j0 >> 6] = total; }
-        if (sv != kInvalidTok) tile_out[run + total + (uint32_t)__popcll(m & lt)] = sv;
-        total += (uint32_t)__popcll(m);
-      }
-    }
-    __syncthreads();
-    // ---- F. tile-local token offset of every sentence starting in [cb, ce) (and == ce on the last chunk): byte -> symbol
-    // through the split's masks, symbol -> token through phase E's
-    auto tokens_before = [&](uint64_t rel) -> uint32_t {
-      if (rel >= ce || (rel >> 6) >= nblk) return total;
-      const uint32_t sidx = L.sympre[rel >> 6] + (uint32_t)__popcll(L.symmask[rel >> 6] & ((1ull << (rel & 63)) - 1ull));
-      if (sidx >= nsym) return total;
-      return L.blkpre[sidx >> 6] + (uint32_t)__popcll(L.vmask[sidx >> 6] & ((1ull << (sidx & 63)) - 1ull));
-    };
-    uint32_t mine = 0;
-    for (uint64_t s = s_next + lane; s < s_hi; s += 64) {
-      const uint64_t rel = sent_off[s] - abase;
-      if (rel > ce || (rel == ce && !last)) break;
-      const uint32_t e = tokens_before(rel);
-      if (kDirect) direct.off[s] = run + e;
-      else if (single) fused.out_off[s] = (uint64_t)before + e;
-      else if (Mode == 0 || kFused) sent_local[s] = run + e;
-      if (kRec && rel < ce) {  // a word never straddles the cut, so its end lies in this chunk too
-        const uint32_t e2 = tokens_before(sent_off[s + 1] - abase);
-        drec[s] = (unsigned long long)(span_base + run + e) | ((unsigned long long)(e2 - e) << 32);
-        rec[uslot[s]] = (unsigned long long)s | ((unsigned long long)(e2 - e) << 32);
-      }
-      mine++;
-    }
-    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
-    s_next += mine;
-    run += total;
-    if (last) break;
-    cb = abase + ce;
-    __syncthreads();
-  }
-  if (kFused && !single) {
-    // a span of several chunks: its tokens lie in the tile's scratch run and its sentence offsets in sent_local
-    __syncthreads();
-    before = tile_lookback(fused.state, t, fused.epoch, run, lane, fused.err);
-    for (uint32_t i = lane; i < run; i += 64) fused.out_ids[(uint64_t)before + i] = tile_out[i];
-    for (uint64_t s = s_lo + lane; s < s_hi; s += 64) fused.out_off[s] = (uint64_t)before + sent_local[s];
+    LaneChunk C;
+    lane_split(L, text, n_bytes, sent_off, cls_tab, slots, sh, T, C, lane);
+    lane_chunk_end<Cap, Mode>(L, text, sent_off, cls_tab, slots, sh, T, C, lane, sent_local, uslot, rec, drec, direct);
+    if (C.giant) continue;
+    uint32_t c2, c1, c0;
+    lane_words_count(L, C.nw, lane, c2, c1, c0);
+    lane_words_write(L, C.nw, lane, list, 0u, c2, c2 + c1, 0u);
+    wave_sync();
+    lane_rounds<Packed, Proper, Cap>(&L, list, c2 + c1 + c0, lane, slots, sh, merged_of_rank);
+    wave_sync();
+    lane_emit<Cap, Mode>(L, sent_off, T, C, lane, sent_local, uslot, rec, drec, direct);
+    if (C.last) break;
   }
   if (lane == 0) {
-    if (kDirect) { direct.off[s_hi] = run; *direct.n_tokens = run; }
-    else if (Mode == 0) tile_tok[t] = run;
-    else if (kFused && t + 1 == fused.n_tiles) { fused.out_off[fused.n_sent] = (uint64_t)before + run; *fused.n_tokens = (uint64_t)before + run; }
+    if (kDirect) { direct.off[T.s_hi] = T.run; *direct.n_tokens = T.run; }
+    else if (Mode == 0) tile_tok[t] = T.run;
   }
 }
-
 
 }  // namespace swt
 
@@ -1112,9 +1134,6 @@ struct swt_bpe_table {
   bool packed = false;             // slot value = rank << 16 | (merged - SWT_SYM_BASE)
   bool proper = false;             // every pair ranks above the merges that produce its symbols (any trained table)
   bool lane_kernel = true;         // bpe_lane_kernel (default) or the byte-lane kernel of rounds 1-2 (SWT_BPE_KERNEL=bytes)
-  bool fused = false;              // SWT_BPE_FUSED=1: the tiles place their own output (tile_lookback) instead of the scan + gather launches.
-                                   // Measured and left off: 22 k single-wave tiles with ~6,000 of them in flight make the look-back
-                                   // long (S85k-open: 0.367 ms against 0.200 ms per call, profiles/r03_experiments/)
   BpeSlot *d_slots = nullptr;
   uint32_t *d_merged = nullptr;
   uint32_t bits = 0;
@@ -1158,24 +1177,20 @@ static void launch_encode_kernel_as(swt_bpe_table *t, uint64_t n_tiles, const Ti
                        (uint32_t)ablation_knob(0));
 }
 
-// the word-lane kernel: Mode 0 (running text) or 1 (the unique words of the dedup path), by d_rec
+// the word-lane kernel: running text, or the unique words of the dedup path (d_rec)
 template <bool Packed, bool Proper, int Cap>
 static void launch_lane_kernel_as(swt_bpe_table *t, uint64_t n_tiles, const TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes,
                                   const uint64_t *d_sent_off, const uint8_t *d_cls, const uint32_t *d_uslot,
-                                  unsigned long long *d_rec, unsigned long long *d_drec, hipStream_t st, const FusedOut *fused = nullptr) {
+                                  unsigned long long *d_rec, unsigned long long *d_drec, hipStream_t st) {
   const uint32_t sh = 32u - t->bits;
   if (d_rec)
     hipLaunchKernelGGL((bpe_lane_kernel<Packed, Proper, Cap, 1>), dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
                        ws.plan.as<uint64_t>(), d_cls, t->d_slots, sh, t->d_merged, ws.scratch.as<uint32_t>(),
-                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, DirectOut{nullptr, nullptr, 0}, FusedOut{});
-  else if (fused)
-    hipLaunchKernelGGL((bpe_lane_kernel<Packed, Proper, Cap, 3>), dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
-                       ws.plan.as<uint64_t>(), d_cls, t->d_slots, sh, t->d_merged, ws.scratch.as<uint32_t>(),
-                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, DirectOut{nullptr, nullptr, 0}, *fused);
+                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, DirectOut{nullptr, nullptr, 0});
   else
     hipLaunchKernelGGL((bpe_lane_kernel<Packed, Proper, Cap, 0>), dim3((unsigned)n_tiles), dim3(64), 0, st, d_text, n_bytes, d_sent_off,
                        ws.plan.as<uint64_t>(), d_cls, t->d_slots, sh, t->d_merged, ws.scratch.as<uint32_t>(),
-                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, DirectOut{nullptr, nullptr, 0}, FusedOut{});
+                       ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), d_uslot, d_rec, d_drec, DirectOut{nullptr, nullptr, 0});
 }
 
 extern "C" {
@@ -1187,6 +1202,29 @@ int swt_debug_occupancy(int which) try {
                  : which  ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<false, kBpeCap, 0>, 64, 0)
                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bpe_encode_kernel<true, kBpeCap, 0>, 64, 0);
   return e == hipSuccess ? n : -(int)e;
+} SWT_API_CATCH
+
+// diagnostics (not part of include/swt.h): what swt_bpe_table_create decided.  0: log2 of the slots, 1: packed values,
+// 2: proper (every pair ranks above the merges producing its symbols), 3: entries in the table, 4: every entry is found where
+// a device lookup looks for it (its first or its second slot) and nowhere else
+int swt_debug_bpe_table_info(const swt_bpe_table *t, int which) try {
+  if (!t) return -1;
+  if (which == 0) return (int)t->bits;
+  if (which == 1) return t->packed ? 1 : 0;
+  if (which == 2) return t->proper ? 1 : 0;
+  uint32_t n = 0;
+  bool placed = true;
+  const uint32_t sh = 32u - t->bits;
+  for (size_t i = 0; i < t->h_slots.size(); i++) {
+    const BpeSlot &sl = t->h_slots[i];
+    if (sl.key == kEmptyKey) continue;
+    n++;
+    const uint32_t l = (uint32_t)(sl.key >> 32), r = (uint32_t)sl.key;
+    const uint32_t h1 = bpe_hash(l, r, sh, kHash1), h2 = bpe_hash(l, r, sh, kHash2);
+    if (i != h1 && i != h2) placed = false;
+    if (h1 != h2 && t->h_slots[i == h1 ? h2 : h1].key == sl.key) placed = false;
+  }
+  return which == 3 ? (int)n : (placed ? 1 : 0);
 } SWT_API_CATCH
 
 int swt_bpe_table_create(const uint32_t *left, const uint32_t *right, const uint32_t *merged, uint32_t n_merges,
@@ -1246,7 +1284,6 @@ int swt_bpe_table_create(const uint32_t *left, const uint32_t *right, const uint
       }
   }
   if (const char *e = getenv("SWT_BPE_KERNEL")) t->lane_kernel = strcmp(e, "bytes") != 0;
-  if (const char *e = getenv("SWT_BPE_FUSED")) t->fused = strcmp(e, "0") != 0;
   if (const char *e = getenv("SWT_BPE_UTILE")) t->opt_unique_tile = atoi(e);  // measurement knob, as SWT_OPT_UNIQUE_TILE
   t->h_merged.assign(merged, merged + n_merges);
   // packed values when every rank and every merged-symbol index fits 16 bits (any realistic table below 65k merges)
@@ -1297,9 +1334,9 @@ void swt_bpe_table_destroy(swt_bpe_table *t) try {
 // cap = staged bytes per chunk (LDS footprint ~ 20 B per byte): 512 for running text, less for the unique-word pass
 static void launch_encode_kernel(swt_bpe_table *t, uint64_t n_tiles, const TileWorkspace &ws, const uint8_t *d_text, uint64_t n_bytes,
                                  const uint64_t *d_sent_off, const uint8_t *d_cls, const uint32_t *d_uslot, unsigned long long *d_rec,
-                                 unsigned long long *d_drec, hipStream_t st, int cap = kBpeCap, const FusedOut *fused = nullptr) {
+                                 unsigned long long *d_drec, hipStream_t st, int cap = kBpeCap) {
 #define SWT_ENC(P, C) launch_encode_kernel_as<P, C>(t, n_tiles, ws, d_text, n_bytes, d_sent_off, d_cls, d_uslot, d_rec, d_drec, st)
-#define SWT_LANE(P, R, C) launch_lane_kernel_as<P, R, C>(t, n_tiles, ws, d_text, n_bytes, d_sent_off, d_cls, d_uslot, d_rec, d_drec, st, fused)
+#define SWT_LANE(P, R, C) launch_lane_kernel_as<P, R, C>(t, n_tiles, ws, d_text, n_bytes, d_sent_off, d_cls, d_uslot, d_rec, d_drec, st)
 #define SWT_LANE_CAPS(P, R) do { if (cap == 128) SWT_LANE(P, R, 128); else if (cap == 256) SWT_LANE(P, R, 256); else SWT_LANE(P, R, 512); } while (0)
   if (t->lane_kernel && !d_rec) {  // running text: the one chunk size the tile was chosen for
     if (t->packed) { if (t->proper) SWT_LANE(true, true, kLaneCap); else SWT_LANE(true, false, kLaneCap); }
@@ -1337,7 +1374,7 @@ static int bpe_encode_direct(swt_bpe_table *t, TileWorkspace &ws, const uint8_t 
     auto one_lane = [&](auto kernel) {
       hipLaunchKernelGGL(kernel, dim3(1), dim3(64), 0, st, d_text, n_bytes, d_sent_off, (const uint64_t *)nullptr, d_cls, t->d_slots, sh,
                          t->d_merged, d_out_ids, ws.sent_local.as<uint32_t>(), ws.tile_tok.as<uint32_t>(), (const uint32_t *)nullptr,
-                         (unsigned long long *)nullptr, (unsigned long long *)nullptr, direct, FusedOut{});
+                         (unsigned long long *)nullptr, (unsigned long long *)nullptr, direct);
     };
     auto one_bytes = [&](auto kernel) {
       hipLaunchKernelGGL(kernel, dim3(1), dim3(64), 0, st, d_text, n_bytes, d_sent_off, (const uint64_t *)nullptr, d_cls, t->d_slots, sh,
@@ -1354,25 +1391,12 @@ static int bpe_encode_direct(swt_bpe_table *t, TileWorkspace &ws, const uint8_t 
     return SWT_OK;
   }
   if ((rc = ws.reserve(n_bytes, n_sent, n_tiles))) return rc;
-  // the fused form: every tile places its own output (tile_lookback); left for good should a look-back ever give up
-  bool fused_on = t->lane_kernel && t->fused && n_bytes < 0xFFFFFFFFull;
-  if (fused_on && ws.lb_err.p && *ws.lb_err.as<volatile uint32_t>()) {
-    t->fused = false;
-    *ws.lb_err.as<volatile uint32_t>() = 0u;
-    return fail(SWT_ERR_INTERNAL, "a tile look-back of the previous call gave up (its output is not valid); this table uses the scan + gather form from now on");
-  }
-  FusedOut fo{};
-  if (fused_on) {
-    if ((rc = ws.reserve_state(n_tiles))) return rc;
-    fo = FusedOut{ws.state.as<unsigned long long>(), ws.epoch, ws.lb_err.as<uint32_t>(), d_out_ids, d_out_off, d_n_tokens, n_sent, n_tiles};
-  }
   prof_begin(st, 2);
   launch_plan(d_sent_off, n_sent, n_tiles, tile, ws.plan.as<uint64_t>(), st);
   prof_begin(st);
-  launch_encode_kernel(t, n_tiles, ws, d_text, n_bytes, d_sent_off, d_cls, nullptr, nullptr, nullptr, st, t->lane_kernel ? kLaneCap : kBpeCap,
-                       fused_on ? &fo : nullptr);
+  launch_encode_kernel(t, n_tiles, ws, d_text, n_bytes, d_sent_off, d_cls, nullptr, nullptr, nullptr, st, t->lane_kernel ? kLaneCap : kBpeCap);
   prof_end(st);
-  if (!fused_on) launch_scan_gather(d_sent_off, n_sent, n_tiles, ws, d_out_ids, d_out_off, d_n_tokens, st);
+  launch_scan_gather(d_sent_off, n_sent, n_tiles, ws, d_out_ids, d_out_off, d_n_tokens, st);
   prof_end(st, 2);
   SWT_HIP(hipGetLastError());
   return SWT_OK;

@@ -29,60 +29,9 @@ struct DirectOut {
 // Per-call workspaces shared by both encoders (grow-only).
 struct TileWorkspace {
   DevBuf plan, scratch, sent_local, tile_tok, tile_base, blk;
-  DevBuf state;        // look-back words of the fused form (tile_lookback): one per tile
-  PinnedBuf lb_err;    // [0] != 0: a look-back gave up (never observed); the owner leaves the fused form for good
-  uint32_t epoch = 0;  // tag of the current call in the look-back words (they are never cleared between calls)
   int reserve(uint64_t n_bytes, uint64_t n_sent, uint64_t n_tiles);
-  int reserve_state(uint64_t n_tiles);  // also advances the epoch
   void release();
 };
-
-// ---- single-pass output placement ("decoupled look-back") ------------------------------------------------------------
-// A tile that knows its token count publishes it, finds the number of tokens of all tiles before it by looking back over
-// its predecessors' words, and then writes its tokens and sentence offsets straight to their final place: no scratch run, no
-// scan launch, no gather launch.  One 64-bit word per tile: epoch:30 | flag:2 | value:32, flag 1 = value is the tile's own
-// count, 2 = value is the count of all tiles up to and including it.  The word carries everything that is handed over, so
-// relaxed device-scope loads and stores are enough (no fence: an acquire fence invalidates the XCD's L2).  Workgroups are
-// dispatched in index order, so every predecessor is resident or finished when a tile waits for it; the wait is bounded
-// all the same (err is set and the host leaves this form) -- a wrong assumption must not hang the GPU.
-constexpr unsigned long long kLbAgg = 1ull << 32, kLbIncl = 2ull << 32;
-constexpr uint32_t kLbSpinLimit = 1u << 22;
-
-__device__ __forceinline__ uint32_t tile_lookback(unsigned long long *__restrict__ state, uint64_t t, uint32_t epoch, uint32_t count,
-                                                  int lane, uint32_t *__restrict__ err) {
-  const unsigned long long tag = (unsigned long long)epoch << 34;
-  if (t == 0) {
-    if (lane == 0) __hip_atomic_store(&state[0], tag | kLbIncl | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return 0;
-  }
-  if (lane == 0) __hip_atomic_store(&state[t], tag | kLbAgg | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  uint32_t before = 0;
-  int64_t j = (int64_t)t - 1;  // nearest tile not yet accounted for
-  uint32_t spins = 0;
-  for (;;) {
-    const int64_t idx = j - lane;
-    unsigned long long v = tag | kLbIncl;  // "tile -1": nothing before the first tile
-    if (idx >= 0) v = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t flag = (v >> 34) == (unsigned long long)epoch ? (uint32_t)(v >> 32) & 3u : 0u;
-    const unsigned long long READY = __ballot(flag != 0u), INCL = __ballot(flag == 2u);
-    const uint32_t run = ~READY ? (uint32_t)__builtin_ctzll(~READY) : 64u;  // lanes 0 .. run-1 have published
-    if (run == 0) {
-      if (++spins > kLbSpinLimit) { if (lane == 0) *err = 1u; return 0; }
-      __builtin_amdgcn_s_sleep(1);
-      continue;
-    }
-    const unsigned long long in_run = run == 64 ? ~0ull : (1ull << run) - 1ull;
-    const bool closed = (INCL & in_run) != 0ull;
-    const uint32_t last = closed ? (uint32_t)__builtin_ctzll(INCL & in_run) : run - 1;  // sum lanes 0 .. last
-    uint32_t x = (uint32_t)lane <= last ? (uint32_t)v : 0u;
-    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
-    before += x;
-    if (closed) break;
-    j -= run;
-  }
-  if (lane == 0) __hip_atomic_store(&state[t], tag | kLbIncl | (unsigned long long)(before + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return before;
-}
 
 inline uint64_t tile_count(uint64_t n_bytes, uint32_t tile) { return n_bytes ? (n_bytes + tile - 1) / tile : 1; }
 

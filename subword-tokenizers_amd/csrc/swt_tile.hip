@@ -113,27 +113,8 @@ int TileWorkspace::reserve(uint64_t n_bytes, uint64_t n_sent, uint64_t n_tiles) 
   return SWT_OK;
 }
 
-int TileWorkspace::reserve_state(uint64_t n_tiles) {
-  int rc;
-  const void *before = state.p;
-  if ((rc = state.reserve((n_tiles + 1) * 8))) return rc;
-  if (!lb_err.p) {
-    if ((rc = lb_err.reserve(64))) return rc;
-    *lb_err.as<volatile uint32_t>() = 0u;
-  }
-  if (state.p != before || epoch >= (1u << 30) - 1u) {  // a new buffer, or the tag would wrap: clear once, start over
-    SWT_HIP(hipDeviceSynchronize());
-    SWT_HIP(hipMemset(state.p, 0, state.cap));
-    SWT_HIP(hipDeviceSynchronize());
-    epoch = 0;
-  }
-  epoch++;
-  return SWT_OK;
-}
-
 void TileWorkspace::release() {
   plan.release(); scratch.release(); sent_local.release(); tile_tok.release(); tile_base.release(); blk.release();
-  state.release(); lb_err.release();
 }
 
 void launch_plan(const uint64_t *d_sent_off, uint64_t n_sent, uint64_t n_tiles, uint32_t tile, uint64_t *d_plan, hipStream_t st) {

@@ -602,3 +602,47 @@ def test_sharded_trainer_refuses_a_string_collision_and_a_repeated_pair(native):
     tr = ShardedBpeTrainer(Engine([(b, c), (a, base)]), 0, 2)
     assert tr.train(3 + 5) == [("b", "c"), ("a", "bc")] and tr.vocab == {"a", "b", "c", "bc", "abc"}
 
+
+
+def test_rank_table_placement_and_proper_flag(native, swt, ref_dir):
+    """swt_bpe_table_create on the host side (no GPU): the two-choice placement holds every distinct pair exactly once, in a slot
+    a device lookup reads (swt_debug_bpe_table_info 4), a later duplicate replaces the earlier entry (bpe.py:257), and the
+    'proper' flag -- which lets the word-lane kernel merge one occurrence per round -- is set for trained tables and cleared
+    for a table in which a pair ranks BELOW a merge that produces one of its symbols."""
+    import ctypes as C
+
+    lib = native.lib()
+    lib.swt_debug_bpe_table_info.restype = C.c_int
+    lib.swt_debug_bpe_table_info.argtypes = [C.c_void_p, C.c_int]
+
+    def info(tab):
+        return [lib.swt_debug_bpe_table_info(tab._h, w) for w in range(5)]
+
+    bpe = swt.FastBPE()
+    bpe.load_resources(os.path.join(ref_dir, "resources", "pretrained", "FastBPE"))
+    bits, packed, proper, entries, placed = info(bpe._table)
+    assert packed == 1 and proper == 1 and placed == 1
+    assert entries == len(set(bpe.merges_list)) and (1 << bits) >= 2 * entries
+    B = 0x110000
+    # (a, b) -> ab at rank 1, but (ab, c) already at rank 0: improper
+    t = native.BpeTable([B + 0, ord("a")], [ord("c"), ord("b")], [B + 1, B + 0])
+    assert info(t)[2:] == [0, 2, 1]
+    t.close()
+    # the same pair twice: one entry, the later rank
+    t = native.BpeTable([ord("a"), ord("x"), ord("a")], [ord("b"), ord("y"), ord("b")], [B + 0, B + 1, B + 0])
+    assert info(t)[2:] == [1, 2, 1]
+    t.close()
+    # many random pairs over a small alphabet: the placement settles (growing the table when it must) and stays exact
+    rng = np.random.default_rng(7)
+    n = 50000
+    pairs = np.unique(rng.integers(0, 3000, size=(n, 2), dtype=np.uint32), axis=0)
+    left = np.where(pairs[:, 0] < 200, pairs[:, 0] + 97, B + pairs[:, 0]).astype(np.uint32)
+    right = np.where(pairs[:, 1] < 200, pairs[:, 1] + 97, B + pairs[:, 1]).astype(np.uint32)
+    merged = (B + 3000 + np.arange(left.size)).astype(np.uint32)
+    t = native.BpeTable(left, right, merged)
+    bits, packed, proper, entries, placed = info(t)
+    assert entries == left.size and placed == 1 and (1 << bits) >= 2 * entries
+    t.close()
+    t = native.BpeTable(np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint32))
+    assert info(t)[3:] == [0, 1]
+    t.close()
