@@ -947,12 +947,36 @@ __device__ __forceinline__ void lane_words_write(const LaneLds<Cap> &L, uint32_t
 // ---- D. merge rounds (bpe.py:210-238) over a list of words, one lane per word.  A lane whose word is finished takes the next
 // one of the list, so the wave goes through about as many rounds as its longest word needs -- the short words fill the lanes
 // beside it.  An entry is tile:4 | index:12 into that tile's wl[] (LL = the tiles of the workgroup).
+//
+// The minimum of a round is found as a KEY = rank | slot (packed values: rank:16 | merged:16 -> rank:16 | 0:11 | slot:5; wide
+// values: rank << 5 | slot), so one min per slot yields the leftmost smallest rank and its place; a dead slot's value is all
+// ones (written when the slot dies) and slots past the word read slot n-1, which never has a pair.  (Scanning for the next
+// minimum WHILE the two lookups of a round are in flight -- their slots blanked first, their values joining the minimum on
+// arrival -- was measured and is not faster: 0.1905 against 0.1872 ms per call; the rounds are not waiting on the L2.)
+template <bool Packed>
+__device__ __forceinline__ uint32_t rank_key(uint32_t v, uint32_t slot) {
+  return Packed ? ((v & 0xFFFF0000u) | slot) : (v >= (1u << 27) ? (0xFFFFFFE0u | slot) : ((v << 5) | slot));
+}
+template <bool Packed>
+__device__ __forceinline__ uint32_t scan_key(const uint32_t *V, uint32_t n) {
+  const uint32_t nm1 = n - 1u;
+  uint32_t key = 0xFFFFFFFFu;
+  for (uint32_t i0 = 0; i0 < nm1; i0 += 4) {
+    const uint32_t i1 = min(i0 + 1u, nm1), i2 = min(i0 + 2u, nm1), i3 = min(i0 + 3u, nm1);
+    const uint32_t k0 = rank_key<Packed>(V[i0], i0), k1 = rank_key<Packed>(V[i1], i1);
+    const uint32_t k2 = rank_key<Packed>(V[i2], i2), k3 = rank_key<Packed>(V[i3], i3);
+    key = min(min(key, k0), min(min(k1, k2), k3));
+  }
+  return key;
+}
 template <bool Packed, bool Proper, int Cap>
 __device__ __forceinline__ void lane_rounds(LaneLds<Cap> *LL, const uint16_t *list, uint32_t n_list, int lane,
                                             const BpeSlot *__restrict__ slots, uint32_t sh, const uint32_t *__restrict__ merged_of_rank) {
+  constexpr uint32_t kNoKey = Packed ? 0xFFFF0000u : 0xFFFFFFE0u;  // keys from here up: no pair
   const unsigned long long lt = (1ull << lane) - 1ull;
   uint32_t next = 0;          // first word of the list no lane has taken (the same in every lane)
   uint32_t n = 0, alive = 0;  // this lane's word: symbols (0: none), live slots
+  uint32_t key = 0xFFFFFFFFu; // its smallest rank | the slot that holds it
   uint32_t *S = LL[0].sym, *V = LL[0].val;
   for (;;) {
     const unsigned long long IDLE = __ballot(n == 0u);
@@ -969,6 +993,8 @@ __device__ __forceinline__ void lane_rounds(LaneLds<Cap> *LL, const uint16_t *li
         if (!Proper || n > 32u) {
           slow_word<Packed>(S, V, n, slots, sh, merged_of_rank);
           n = 0u;
+        } else {
+          key = scan_key<Packed>(V, n);
         }
       }
       next += (uint32_t)__popcll(IDLE);
@@ -978,54 +1004,28 @@ __device__ __forceinline__ void lane_rounds(LaneLds<Cap> *LL, const uint16_t *li
       continue;
     }
     if (n != 0u) {
-      // one round: leftmost minimum over the live slots' pair values, four slots per step
-      uint32_t m = kNoRank, im = 0;
-      if (Packed) {
-        // a packed value is rank:16 | merged:16 and a dead slot's value is all ones (written when the slot dies), so the key
-        // rank:16 | slot:5 finds minimum and place with one min per slot; slots past the word read slot n-1, which never
-        // has a pair; the merged symbol comes from the winning slot afterwards
-        const uint32_t nm1 = n - 1u;
-        uint32_t key = 0xFFFFFFFFu;
-        for (uint32_t i0 = 0; i0 < nm1; i0 += 4) {
-          const uint32_t i1 = min(i0 + 1u, nm1), i2 = min(i0 + 2u, nm1), i3 = min(i0 + 3u, nm1);
-          const uint32_t k0 = (V[i0] & 0xFFFF0000u) | i0, k1 = (V[i1] & 0xFFFF0000u) | i1;
-          const uint32_t k2 = (V[i2] & 0xFFFF0000u) | i2, k3 = (V[i3] & 0xFFFF0000u) | i3;
-          key = min(min(key, k0), min(min(k1, k2), k3));
-        }
-        if (key < 0xFFFF0000u) { im = key & 31u; m = V[im]; }
-      } else {
-        for (uint32_t i0 = 0; i0 < n; i0 += 4) {
-          const uint32_t a = alive >> i0;
-          uint32_t v0 = V[i0], v1 = V[i0 + 1], v2 = V[i0 + 2], v3 = V[i0 + 3];  // the arrays are padded by four
-          v0 = (a & 1u) ? v0 : kNoRank;
-          v1 = (a & 2u) ? v1 : kNoRank;
-          v2 = (a & 4u) ? v2 : kNoRank;
-          v3 = (a & 8u) ? v3 : kNoRank;
-          if (v0 < m) { m = v0; im = i0; }
-          if (v1 < m) { m = v1; im = i0 + 1; }
-          if (v2 < m) { m = v2; im = i0 + 2; }
-          if (v3 < m) { m = v3; im = i0 + 3; }
-        }
-      }
       // slot im merges with the next live slot r; pl / rr = the live slots either side of the pair
+      const uint32_t im = key & 31u;
       const uint32_t hi = alive & (0xFFFFFFFEu << im);
-      if (m == kNoRank || hi == 0u) {
+      if (key >= kNoKey || hi == 0u) {
         n = 0u;  // the word is finished (hi == 0 cannot happen: a slot with a pair value has a live successor)
       } else {
+        const uint32_t m = V[im];
         const uint32_t r = (uint32_t)__builtin_ctz(hi);
         const uint32_t hi2 = hi & (hi - 1u);
         const uint32_t lo = alive & ((1u << im) - 1u);
         const bool has_rr = hi2 != 0u, has_pl = lo != 0u;
-        const uint32_t rr = has_rr ? (uint32_t)__builtin_ctz(hi2) : 0u, pl = has_pl ? 31u - (uint32_t)__builtin_clz(lo) : 0u;
+        const uint32_t rr = has_rr ? (uint32_t)__builtin_ctz(hi2) : 0u, pl = has_pl ? 31u - (uint32_t)__builtin_clz(lo) : im;
         alive &= ~(1u << r);
         const uint32_t mg = Packed ? (SWT_SYM_BASE + (m & 0xFFFFu)) : merged_of_rank[m];
         const uint32_t sl = S[pl] & ~SWT_BPE_CONT, sr = S[rr] & ~SWT_BPE_CONT;
         S[im] = im ? (mg | SWT_BPE_CONT) : mg;
         S[r] = kInvalidTok;
         V[r] = kNoRank;
-        const uint32_t v1 = slot_value(slots, sh, sl, mg), v2 = slot_value(slots, sh, mg, sr);
+        const uint32_t v1 = slot_value(slots, sh, sl, mg), v2 = has_rr ? slot_value(slots, sh, mg, sr) : kNoRank;
         if (has_pl) V[pl] = v1;
-        V[im] = has_rr ? v2 : kNoRank;
+        V[im] = v2;
+        key = scan_key<Packed>(V, n);
       }
     }
   }
@@ -1285,6 +1285,7 @@ int swt_bpe_table_create(const uint32_t *left, const uint32_t *right, const uint
   }
   if (const char *e = getenv("SWT_BPE_KERNEL")) t->lane_kernel = strcmp(e, "bytes") != 0;
   if (const char *e = getenv("SWT_BPE_UTILE")) t->opt_unique_tile = atoi(e);  // measurement knob, as SWT_OPT_UNIQUE_TILE
+  if (const char *e = getenv("SWT_BPE_DEDUP")) t->dd.opt_mode = atoi(e);       // measurement knob, as SWT_OPT_DEDUP (0 auto, 1 never, 2 always)
   t->h_merged.assign(merged, merged + n_merges);
   // packed values when every rank and every merged-symbol index fits 16 bits (any realistic table below 65k merges)
   t->packed = n_merges < 0xFFFEu;

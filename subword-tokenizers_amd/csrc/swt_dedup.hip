@@ -797,7 +797,7 @@ bool DedupEngine::pays(uint64_t n_bytes) {
   const unsigned long long total = h[0], of = h[1];
   if (!of || of * 2 < n_bytes || n_bytes * 2 < of) return true;  // nothing seen yet, or a batch of another size: look
   const unsigned long long ubytes = total & 0xFFFFFFFFull;
-  if (ubytes * 3 <= of) return true;
+  if (ubytes * pay_ratio <= of) return true;
   if (++skipped >= kDedupRetry) { skipped = 0; return true; }
   return false;
 }

@@ -15,4 +15,4 @@ d=json.load(open("gpurun_out/r03u_$1.json"))
 print("$1 $2:", d["value"], "MB/s", d["ms_per_step"], "ms", flush=True)
 PY
 }
-one group open && SWT_BPE_GROUP=0 one single open && one group_lex lex
+one piped open && one piped_lex lex
