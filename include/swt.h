@@ -106,7 +106,7 @@ int swt_utf8_lower_dev(uint8_t *d_text, uint64_t n_bytes, const uint64_t *d_sent
  *                             1: never; 2: always
  *   SWT_OPT_DEDUP_TABLE_BITS  log2 of the dedup word table's slots, 4..24; 0 (default): sized from the batch.  A tiny table
  *                             makes words overflow into their own slots; results stay exact
- *   SWT_OPT_UNIQUE_TILE       (FastBPE) tile size of the pass over the unique words: 0 (default), 64 or 256 */
+ *   SWT_OPT_UNIQUE_TILE       (FastBPE) tile size of the pass over the unique words: 0 (default), 64, 128 or 256 */
 #define SWT_OPT_DEDUP 1
 #define SWT_OPT_DEDUP_TABLE_BITS 2
 #define SWT_OPT_UNIQUE_TILE 3
