@@ -193,7 +193,8 @@ def encode_corpus_bench(args, torch, dist, rank, N, bpe, sents, merges, name, cp
                                     "sample": "the same batch, orc_bpe_tokenize_batch_mt over %d host threads" % cores}}
     # the call is a pipeline of short kernels and none of them touches all of the algorithmic bytes, so the roofline line is
     # that of the whole call: algorithmic bytes of the batch over first kernel start .. last kernel end (HIP events on the
-    # launch stream); the longest single kernel (bpe_encode_kernel over the unique words) is reported beside it
+    # launch stream); the longest single kernel (bpe_lane_kernel: over the text on the direct path, over the unique words behind
+    # the dedup) is reported beside it
     algo = n_bytes + 4.0 * n_tok + 8.0 * (n_sent + 1)
     per_call_s = call_ms / 1e3 / max(calls, 1)
     achieved = algo / per_call_s / 1e9
@@ -202,7 +203,7 @@ def encode_corpus_bench(args, torch, dist, rank, N, bpe, sents, merges, name, cp
         "traffic": traffic_from_profile("bpe_encode_" + name) or traffic_from_profile("bpe_encode"),
         "kernel": "whole call: the word-dedup pipeline, or the direct path while the text repeats too few of its words (the longest kernel beside it)", "kernel_us": round(per_call_s * 1e6, 2),
         "algorithmic_bytes_per_launch": int(algo), "launches_timed": int(calls),
-        "dominant_kernel": {"name": "bpe_encode_kernel", "us": round(kernel_ms * 1e3 / max(launches, 1), 2), "launches_timed": int(launches)}})
+        "dominant_kernel": {"name": "bpe_lane_kernel", "us": round(kernel_ms * 1e3 / max(launches, 1), 2), "launches_timed": int(launches)}})
     # what the dedup feeds on, exactly: the device's own split + Counter (bpe.py:73-77) of this batch
     tr = N.BpeTrainer.from_text(text, off)
     _ids, _woff, freq = tr.export()

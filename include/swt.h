@@ -68,7 +68,7 @@ int swt_device_count(void);
 /* multiprocessor count / name of the selected device (for launch sizing and reports) */
 int swt_device_info(int *n_cu, char *name, size_t name_cap);
 
-/* Kernel timing for bench.py's roofline line (state of the CALLING THREAD, like the error text).  on = 1: every launch of a path's DOMINANT kernel (bpe_encode_kernel,
+/* Kernel timing for bench.py's roofline line (state of the CALLING THREAD, like the error text).  on = 1: every launch of a path's DOMINANT kernel (bpe_lane_kernel,
  * wp_encode_kernel, the training apply/argmax pair) is bracketed by two HIP events on the stream it is launched on;
  * on = 2: the bracket spans all kernels of one call instead (first launch .. last launch); 0 = off.
  * swt_profile_read waits for the events, returns the summed elapsed milliseconds and the number of brackets since

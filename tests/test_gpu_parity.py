@@ -962,3 +962,49 @@ def test_sharded_training_over_rccl_world1(swt, oracle, dev, corpora, shard_mode
     finally:
         tr.engine.close()
         comm.close()
+
+
+@pytest.mark.gpu
+def test_bpe_word_lane_kernel_boundaries(swt, oracle, dev, bpe, bpe_orc):
+    """the shapes bpe_lane_kernel (csrc/swt_bpe_encode.hip) has of its own: words around the 32-slot live mask (longer ones take
+    slow_word), more multi-symbol words in a chunk than a wave has lanes (the lanes take a next word), words and multi-byte
+    characters straddling the 64-byte blocks of the split and the 512-byte chunks, pairs that recur inside a word, and the same
+    texts under a PROPER table (one occurrence of the best pair per round) and under tables that are not (every word through
+    slow_word: all occurrences per round, bpe.py:221-235)."""
+    def table(merges):
+        tok = swt.FastBPE()
+        tok.merges_list = list(merges)
+        tok._build_table()
+        return tok, oracle.OracleBPE(merges)
+
+    # proper: a chain that merges long words in many rounds, with recurring pairs and a twin
+    proper = [("a", "b"), ("c", "d"), ("ab", "cd"), ("e", "e"), ("ee", "e"), ("abcd", "ab"), ("x", "y"), ("xy", "xy"),
+              ("ab", "ab"), ("d", "a"), ("ż", "ó"), ("żó", "ł"), ("b", "c"), ("abcdab", "cd"), ("y", "x")]
+    # not proper: (ab, c) ranks BELOW the merge that makes ab, and (aa, a) below (a, a)
+    improper = [("ab", "c"), ("a", "b"), ("aa", "a"), ("a", "a"), ("c", "d"), ("x", "y"), ("b", "c")]
+    texts = []
+    for n in (30, 31, 32, 33, 34, 63, 64, 65, 100):                       # symbols per word around the live mask
+        texts.append("abcd" * (n // 4) + "abcd"[: n % 4] + " " + "e" * n + " " + "xy" * (n // 2))
+        texts.append(("żół" * n)[:n] + " ab " + "abab" * (n // 4))
+    texts.append(" ".join("ab cd abcd xyxy eee abab".split() * 40))      # ~240 multi-symbol words in one sentence: refill
+    texts.append(" ".join(["abcdabcd" * 3, "eeeeeeeeee", "xyxyxyxy"] * 30 + ["ab"] * 200))
+    for shift in range(0, 70, 7):                                        # word / multi-byte character across block and chunk ends
+        texts.append("q" * shift + " " + "abcdabcdab" * 6 + " żółżółżół " + "abab" * 3)
+        texts.append("ż" * (250 + shift) + " " + "abcd" * 70 + " e" * 40)
+        texts.append(("ab " * 170)[: 500 + shift] + "abcdabcd" * 5)
+    texts += ["ab", "a b", "ab.cd,ab!", "", " ", "abcdabcdabcdabcdabcdabcdabcdabcdabcdab" * 9]
+    for merges in (proper, improper):
+        tok, orc = table(merges)
+        same_bpe(tok, orc, texts)
+        for t in texts[:12]:
+            same_bpe(tok, orc, [t])
+        with dedup(dev, dev.DEDUP_ALWAYS, tok):
+            same_bpe(tok, orc, texts)
+    lib = dev.lib()
+    import ctypes as C
+    lib.swt_debug_bpe_table_info.restype = C.c_int
+    lib.swt_debug_bpe_table_info.argtypes = [C.c_void_p, C.c_int]
+    tp, _ = table(proper)
+    ti, _ = table(improper)
+    assert lib.swt_debug_bpe_table_info(tp._table._h, 2) == 1 and lib.swt_debug_bpe_table_info(ti._table._h, 2) == 0
+    same_bpe(bpe, bpe_orc, texts)  # and the pretrained table
