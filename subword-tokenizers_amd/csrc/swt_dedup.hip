@@ -852,6 +852,8 @@ int dedup_front(DedupEngine &E, TileWorkspace &ws, const uint8_t *d_text, uint64
   // (see DedupTab); never cleared (epoch).  rec[] = the table's slots, then the own slots of the words that overflowed.
   uint32_t bits = 16;
   while ((1ull << bits) < n_bytes / 32 && bits < 24) bits++;
+  static const int env_bits = getenv("SWT_DD_BITS") ? atoi(getenv("SWT_DD_BITS")) : 0;  // measurement knob
+  if (env_bits >= 4 && env_bits <= 24 && !E.opt_table_bits) bits = (uint32_t)env_bits;
   if (E.opt_table_bits) {  // SWT_OPT_DEDUP_TABLE_BITS (tests: a table so small that words overflow it)
     bits = E.opt_table_bits;
     if (bits != E.bits) E.bits = 0;
