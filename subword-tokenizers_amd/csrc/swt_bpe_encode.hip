@@ -1086,6 +1086,7 @@ __global__ __launch_bounds__(64) void bpe_lane_kernel(
     uint32_t *__restrict__ sent_local, uint32_t *__restrict__ tile_tok, const uint32_t *__restrict__ uslot,
     unsigned long long *__restrict__ rec, unsigned long long *__restrict__ drec, DirectOut direct) {
   constexpr bool kDirect = Mode == 2;
+  static_assert(Cap % 64 == 0 && Cap <= 4032, "an entry of the word list is tile:4 | word:12, and wl[] holds 16-bit symbol indices");
   __shared__ LaneLds<Cap> L;
   const int lane = threadIdx.x;
   const uint64_t t = blockIdx.x;
@@ -1241,8 +1242,9 @@ int swt_bpe_table_create(const uint32_t *left, const uint32_t *right, const uint
   auto *t = new swt_bpe_table();
   std::vector<BpeSlot> &slots = t->h_slots;
   // two-choice cuckoo placement (see slot_lookup); a table that does not settle gets twice the slots
+  const uint32_t bits0 = bits;
   for (;; bits++) {
-    if (bits > 28) { delete t; return fail(SWT_ERR_UNSUPPORTED, "the rank table could not be placed"); }
+    if (bits > 28 || bits > bits0 + 4) { delete t; return fail(SWT_ERR_UNSUPPORTED, "the rank table could not be placed (%u pairs)", n_merges); }
     const uint32_t sh = 32u - bits;
     slots.assign((size_t)1 << bits, BpeSlot{kEmptyKey, 0u, 0u});
     bool ok = true;

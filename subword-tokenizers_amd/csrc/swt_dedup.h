@@ -23,7 +23,7 @@ namespace swt {
 constexpr uint64_t kDedupMinBytes = 7u << 18;     // FastBPE: 1.75 MiB
 constexpr uint64_t kDedupMinBytesWp = 11u << 18;  // FastWP: 2.75 MiB
 constexpr uint64_t kDedupMaxBytes = 1ull << 30;  // 32-bit fields of the records
-constexpr uint32_t kDedupRetry = 64;             // direct calls between two looks at a text that repeats few of its words
+constexpr uint32_t kDedupRetry = 256;            // direct calls between two looks at a text that repeats few of its words
 constexpr uint32_t kRecFailed = 0xFFFFFFFFu;     // count field of rec[]: the word cannot be encoded (FastWP non-termination)
 
 enum DedupMode {
