@@ -662,8 +662,16 @@ __global__ __launch_bounds__(64) void refwrite_kernel(const uint64_t *__restrict
       }
       const uint32_t ex = run + x - n;
       if (j < k1) pre[j - k0] = ex;
-      if (n == 1 && !(v & kRefSlot)) out_ids[base + ex] = v;
-      else for (uint32_t i = 0; i < n; i++) out_ids[base + ex + i] = u_ids[src + i];
+      if (n == 1 && !(v & kRefSlot)) {
+        out_ids[base + ex] = v;
+      } else if (n) {
+        // the first tokens of the run together (most words have one to three), then the rest
+        const uint32_t t0 = u_ids[src], t1 = n > 1 ? u_ids[src + 1] : 0u, t2 = n > 2 ? u_ids[src + 2] : 0u;
+        out_ids[base + ex] = t0;
+        if (n > 1) out_ids[base + ex + 1] = t1;
+        if (n > 2) out_ids[base + ex + 2] = t2;
+        for (uint32_t i = 3; i < n; i++) out_ids[base + ex + i] = u_ids[src + i];
+      }
       run += __shfl(x, 63);
     }
     __syncthreads();
@@ -751,7 +759,27 @@ __global__ __launch_bounds__(64) void wp_refs_kernel(const uint64_t *__restrict_
   }
   bool any_bad = false;
   uint32_t my_sum = 0;
-  for (uint32_t k = lane; k < n_w; k += 64) {
+  // the records of a lane's first four words stay in registers for the copy below (a 1-KiB tile holds ~190 words): the write
+  // launch then gathers each word's record once, and the four gathers are in flight together
+  constexpr int kKeep = Write ? 4 : 0;  // (the counting launch has no second use for them: measured slower with)
+  unsigned long long keep[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+  for (int u = 0; u < kKeep; u++) {
+    const uint32_t k = (uint32_t)u * 64 + lane;
+    keep[u] = k < n_w ? rec[my_rec[k] & ~kRefSlot] : 0ull;
+  }
+#pragma unroll
+  for (int u = 0; u < kKeep; u++) {
+    const uint32_t k = (uint32_t)u * 64 + lane;
+    if (k < n_w) {
+      const unsigned long long r = keep[u];
+      const uint32_t c = (uint32_t)(r >> 32);
+      cnt[k] = c;
+      any_bad |= c == kRecFailed;
+      my_sum += c;
+    }
+  }
+  for (uint32_t k = kKeep * 64 + lane; k < n_w; k += 64) {
     const unsigned long long r = rec[my_rec[k] & ~kRefSlot];
     if (!Write) my_rec[k] = kRefSlot | (uint32_t)r;
     const uint32_t c = (uint32_t)(r >> 32);
@@ -793,8 +821,21 @@ __global__ __launch_bounds__(64) void wp_refs_kernel(const uint64_t *__restrict_
     const uint32_t ex = run + x - n;
     if (k < n_w) cnt[k] = ex;
     if (Write && n) {
-      const uint64_t src = rec[my_rec[k] & ~kRefSlot] & 0xFFFFFFFFull;
-      for (uint32_t i = 0; i < n; i++) out_ids[base + ex + i] = u_ids[src + i];
+      uint64_t src;
+      if (k0 < (uint32_t)kKeep * 64) {
+        unsigned long long r = keep[0];
+#pragma unroll
+        for (int u = 1; u < 4; u++) r = k0 == (uint32_t)u * 64 ? keep[u] : r;
+        src = r & 0xFFFFFFFFull;
+      } else {
+        src = rec[my_rec[k] & ~kRefSlot] & 0xFFFFFFFFull;
+      }
+      // the first tokens of the run together (most words have one to three), then the rest
+      const uint32_t t0 = u_ids[src], t1 = n > 1 ? u_ids[src + 1] : 0u, t2 = n > 2 ? u_ids[src + 2] : 0u;
+      out_ids[base + ex] = t0;
+      if (n > 1) out_ids[base + ex + 1] = t1;
+      if (n > 2) out_ids[base + ex + 2] = t2;
+      for (uint32_t i = 3; i < n; i++) out_ids[base + ex + i] = u_ids[src + i];
     }
     run += __shfl(x, 63);
   }
