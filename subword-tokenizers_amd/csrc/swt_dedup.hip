@@ -18,6 +18,9 @@ constexpr int kDCap = SWT_DCAP;  // staged bytes per chunk: a 1-KiB tile's span 
                              // (8.1 KB) left 4.9 waves per SIMD and the waves waited 57 % of their cycles -- 1536 (6.2 KB, 6.4
                              // waves per SIMD) made wordref 16 % faster on the 141 MB FastWP batch
 constexpr int kDBlocks = kDCap / 64;
+#ifndef SWT_WORDREF_WAVES
+#define SWT_WORDREF_WAVES 7  // waves per SIMD the register allocation of wordref_kernel aims at (5,600 bytes of LDS allow 7)
+#endif
 constexpr unsigned long long kDOffMask = (1ull << 40) - 1ull;
 constexpr uint32_t kRefSlot = 0x80000000u;
 
@@ -204,7 +207,7 @@ struct WordrefLds {
   uint16_t wl[kDCap];
   unsigned long long sbits[kDBlocks + 1];
   unsigned long long endm[kDBlocks + 1];
-  __attribute__((aligned(16))) uint8_t cls_lo[kClsLds];
+  uint32_t cls2[kClsLds / 16];  // classes of U+0000..U+03FF, two bits each: bit 0 = ends a word (the mode's whitespace), bit 1 = punctuation (BPE words)
   unsigned long long wst[kDBlocks + 1];  // word starts per 64-byte block, and how many came before the block
   uint32_t nwb[kDBlocks + 1];
   uint64_t giant_end;
@@ -216,7 +219,7 @@ struct WordrefLds {
 // every one of them goes through the table.
 // Lanes16: the split takes sixteen bytes per lane (an instance of its own, so that neither form pays the other's registers)
 template <int Mode, bool Lanes16 = false>
-__global__ __launch_bounds__(64) void wordref_kernel(const uint8_t *__restrict__ text, uint64_t n_bytes,
+__global__ __launch_bounds__(64, SWT_WORDREF_WAVES) void wordref_kernel(const uint8_t *__restrict__ text, uint64_t n_bytes,
                                                      const uint64_t *__restrict__ sent_off, const uint64_t *__restrict__ plan,
                                                      const uint8_t *__restrict__ cls_tab, DedupTab D, uint32_t *__restrict__ wref,
                                                      uint32_t *__restrict__ sent_word, uint32_t *__restrict__ tile_words,
@@ -232,7 +235,19 @@ __global__ __launch_bounds__(64) void wordref_kernel(const uint8_t *__restrict__
     if (lane == 0) { D.tile_new[t] = 0ull; tile_words[t] = 0u; }
     return;
   }
-  reinterpret_cast<uint4 *>(L.cls_lo)[lane] = reinterpret_cast<const uint4 *>(cls_tab)[lane];
+  {
+    // sixteen code points per lane, two bits each (the 1-KiB byte table cost a wave per SIMD: 6,368 -> 5,600 bytes of LDS)
+    const uint4 v = reinterpret_cast<const uint4 *>(cls_tab)[lane];
+    auto pk = [](uint32_t d) {
+      uint32_t ws = d & (0x01010101u * kWsBit), pn = kPunctSplits ? (d & (0x01010101u * kClsPunct)) : 0u;
+      ws = ws / kWsBit;                    // bit 0 of each byte
+      pn = (pn / kClsPunct) << 1;          // bit 1 of each byte
+      uint32_t x = ws | pn;                // two bits in each byte
+      x = (x | (x >> 6)) & 0x000F000Fu;
+      return (x | (x >> 12)) & 0xFFu;
+    };
+    L.cls2[lane] = pk(v.x) | (pk(v.y) << 8) | (pk(v.z) << 16) | (pk(v.w) << 24);
+  }
   const uint64_t span_base = sent_off[s_lo], span_end = sent_off[s_hi];
   uint64_t s_next = s_lo;
   uint64_t cb = span_base;
@@ -311,9 +326,15 @@ __global__ __launch_bounds__(64) void wordref_kernel(const uint8_t *__restrict__
             cp = b & (0xFF >> (len + 1));
             for (int i = 1; i < len; i++) cp = (cp << 6) | (L.txt[p + i] & 0x3F);
           }
-          const uint8_t c = cp < (uint32_t)kClsLds ? L.cls_lo[cp] : (cp < kNumCodePoints ? cls_tab[cp] : (uint8_t)0);
-          if (c & kWsBit) sp16 |= 1u << j;
-          if (kPunctSplits && (c & kClsPunct)) pn16 |= 1u << j;
+          uint32_t c2;  // bit 0: whitespace of the mode, bit 1: punctuation
+          if (cp < (uint32_t)kClsLds) {
+            c2 = (L.cls2[cp >> 4] >> ((cp & 15u) << 1)) & 3u;
+          } else {
+            const uint8_t c = cp < kNumCodePoints ? cls_tab[cp] : (uint8_t)0;
+            c2 = ((c & kWsBit) ? 1u : 0u) | ((kPunctSplits && (c & kClsPunct)) ? 2u : 0u);
+          }
+          if (c2 & 1u) sp16 |= 1u << j;
+          if (c2 & 2u) pn16 |= 1u << j;
         }
         const uint32_t wsm16 = (sp16 | ~inr16) & 0xFFFFu;  // bytes outside the chunk behave as whitespace
         const uint32_t lead16 = ~ct16 & 0xFFFFu;
@@ -375,12 +396,19 @@ __global__ __launch_bounds__(64) void wordref_kernel(const uint8_t *__restrict__
           for (int i = 1; i < len; i++) cp = (cp << 6) | (L.txt[p + i] & 0x3F);
         }
       }
-      uint8_t c = kWsBit;
-      if (inr && lead) c = cp < (uint32_t)kClsLds ? L.cls_lo[cp] : (cp < kNumCodePoints ? cls_tab[cp] : (uint8_t)0);
+      uint32_t c2 = 1u;  // bit 0: whitespace of the mode (bytes outside the chunk count as such), bit 1: punctuation
+      if (inr && lead) {
+        if (cp < (uint32_t)kClsLds) {
+          c2 = (L.cls2[cp >> 4] >> ((cp & 15u) << 1)) & 3u;
+        } else {
+          const uint8_t c = cp < kNumCodePoints ? cls_tab[cp] : (uint8_t)0;
+          c2 = ((c & kWsBit) ? 1u : 0u) | ((kPunctSplits && (c & kClsPunct)) ? 2u : 0u);
+        }
+      }
       const unsigned long long INR = __ballot(inr);
       const unsigned long long LEAD = __ballot(lead);
-      const unsigned long long WSm = __ballot(lead && (c & kWsBit));
-      const unsigned long long PNm = kPunctSplits ? __ballot(lead && (c & kClsPunct)) : 0ull;
+      const unsigned long long WSm = __ballot(lead && (c2 & 1u));
+      const unsigned long long PNm = kPunctSplits ? __ballot(lead && (c2 & 2u)) : 0ull;
       const unsigned long long CONT = ~LEAD;
       unsigned long long WB = WSm | PNm | ((prev_wb && (CONT & 1ull)) ? 1ull : 0ull);
       WB |= (WB << 1) & CONT;
