@@ -1,0 +1,17 @@
+#!/bin/bash
+# bpe_lane_kernel tail: lanes per word (rebuilds on the box)
+set -o pipefail
+export TMPDIR=/tmp
+for v in "-DSWT_TAIL_LANES=2" "-DSWT_TAIL_LANES=4"; do
+  export SWT_EXTRA_FLAGS="$v"
+  python -c "import importlib; importlib.import_module('subword-tokenizers_amd._build').build()" || exit 1
+  timeout -k 10 200 python -m pytest tests -m gpu -q -x -k "word_lane or twin or bpe_edge or bpe_fuzz" 2>&1 | tail -1
+  for c in open lex; do
+  SWT_BPE_DEDUP=1 timeout -k 10 300 python bench.py --workload bpe_encode --corpus $c --lean --steps 100 --warmup 10 > gpurun_out/r03ai.json 2> gpurun_out/r03ai.err || { tail -5 gpurun_out/r03ai.err; exit 1; }
+  python - <<PY
+import json
+d=json.load(open("gpurun_out/r03ai.json"))
+print("[$v] $c:", d["value"], "MB/s", d["ms_per_step"], flush=True)
+PY
+  done
+done
