@@ -56,10 +56,8 @@ constexpr int kBpeCap = SWT_BPE_CAP;    // staged bytes per chunk
 #ifndef SWT_LANE_TILE
 #define SWT_LANE_TILE 384
 #endif
-#ifndef SWT_TAIL_LANES
-#define SWT_TAIL_LANES 4  // measured on S85k-open: 2 -> 0.184, 4 -> 0.176, 8 -> 0.180 ms per call (no tail: 0.187)
-#endif
-constexpr uint32_t kTailLanes = SWT_TAIL_LANES;  // lanes per word once 64 / kTailLanes words are left in a chunk (4 or 8)
+// (the tail of the merge rounds, lane_tail: four lanes a word once 16 words are left in a chunk.  Measured on S85k-open, ms per call:
+// no tail 0.187; 2 lanes a word from 32 words 0.184; 4 from 16: 0.176; 8 from 8: 0.180; 4 from 16 and then 8 from 8: 0.1775)
 #ifndef SWT_LANE_CAP
 #define SWT_LANE_CAP 512
 #endif
@@ -973,6 +971,76 @@ __device__ __forceinline__ uint32_t scan_key(const uint32_t *V, uint32_t n) {
   }
   return key;
 }
+// ---- the tail of the rounds.  Two thirds of a tile's rounds run with a handful of words left -- the longest ones, which started
+// first -- and a round costs the wave the same whether 60 lanes take part or 5 (S85k-open, simulated from the oracle: 13.8 rounds per
+// tile, 8.8 of them with <= 16 words, 6.9 with <= 8).  So the last 64 / TL words get TL lanes each: lane j of a word scans its share
+// of the slots, a shuffle finds the word's minimum, every lane of the group follows the merge (same values, LDS broadcasts), lane 0
+// writes it and looks the left pair up while lane 1 looks up the right.  LEAD = the lanes that hold a word's state on entry; the
+// function returns when at most `stop` words are left, their state in the first lane of each group (and in all of its lanes).
+template <bool Packed, uint32_t TL>
+__device__ __forceinline__ void lane_tail(uint32_t *sym0, uint32_t *val0, uint32_t *&S, uint32_t *&V, uint32_t &n, uint32_t &alive,
+                                          unsigned long long LEAD, uint32_t stop, int lane, const BpeSlot *__restrict__ slots, uint32_t sh,
+                                          const uint32_t *__restrict__ merged_of_rank) {
+  constexpr uint32_t kNoKey = Packed ? 0xFFFF0000u : 0xFFFFFFE0u;
+  // group g of TL lanes takes over the g-th word
+  const uint32_t g = (uint32_t)lane / TL, j = (uint32_t)lane % TL;
+  unsigned long long mrest = LEAD;
+  for (uint32_t i = 0; i < g; i++) mrest &= mrest - 1ull;
+  const bool have = mrest != 0ull;
+  const int src = have ? __builtin_ctzll(mrest) : 0;
+  const uint32_t sidx = (uint32_t)(S - sym0), vidx = (uint32_t)(V - val0);
+  const uint32_t t_s = __shfl(sidx, src), t_v = __shfl(vidx, src), t_n = __shfl(n, src), t_alive = __shfl(alive, src);
+  S = sym0 + t_s;
+  V = val0 + t_v;
+  n = have ? t_n : 0u;
+  alive = t_alive;
+  for (;;) {
+    const unsigned long long BUSY = __ballot(n != 0u);
+    if ((uint32_t)__popcll(BUSY) <= stop * TL) break;
+    if (n != 0u) {
+      const uint32_t nm1 = n - 1u;
+      uint32_t k = 0xFFFFFFFFu;
+#pragma unroll
+      for (uint32_t q0 = 0; q0 < 32u / TL; q0 += 4) {  // this lane's share of the (at most 32) slots
+        const uint32_t i0 = (32u / TL) * j + q0;
+        if (i0 < nm1) {
+          const uint32_t i1 = min(i0 + 1u, nm1), i2 = min(i0 + 2u, nm1), i3 = min(i0 + 3u, nm1);
+          k = min(k, min(min(rank_key<Packed>(V[i0], i0), rank_key<Packed>(V[i1], i1)), min(rank_key<Packed>(V[i2], i2), rank_key<Packed>(V[i3], i3))));
+        }
+      }
+#pragma unroll
+      for (uint32_t d = 1; d < TL; d <<= 1) k = min(k, (uint32_t)__shfl_xor(k, (int)d));
+      const uint32_t im = k & 31u;
+      const uint32_t hi = alive & (0xFFFFFFFEu << im);
+      if (k >= kNoKey || hi == 0u) {
+        n = 0u;  // the same decision in all lanes of the group
+      } else {
+        const uint32_t m = V[im];
+        const uint32_t r = (uint32_t)__builtin_ctz(hi);
+        const uint32_t hi2 = hi & (hi - 1u);
+        const uint32_t lo = alive & ((1u << im) - 1u);
+        const bool has_rr = hi2 != 0u, has_pl = lo != 0u;
+        const uint32_t rr = has_rr ? (uint32_t)__builtin_ctz(hi2) : 0u, pl = has_pl ? 31u - (uint32_t)__builtin_clz(lo) : 0u;
+        alive &= ~(1u << r);
+        const uint32_t mg = Packed ? (SWT_SYM_BASE + (m & 0xFFFFu)) : merged_of_rank[m];
+        const uint32_t sl = S[pl] & ~SWT_BPE_CONT, sr = S[rr] & ~SWT_BPE_CONT;
+        wave_sync();  // every lane has read the old symbols before lane 0 changes them
+        const bool left = j == 0u && has_pl, right = j == 1u && has_rr;
+        uint32_t v = kNoRank;
+        if (left || right) v = slot_value(slots, sh, left ? sl : mg, left ? mg : sr);
+        if (j == 0u) {
+          S[im] = im ? (mg | SWT_BPE_CONT) : mg;
+          S[r] = kInvalidTok;
+          V[r] = kNoRank;
+          if (has_pl) V[pl] = v;
+        }
+        if (j == 1u) V[im] = v;  // kNoRank when nothing follows
+      }
+    }
+    wave_sync();
+  }
+}
+
 template <bool Packed, bool Proper, int Cap>
 __device__ __forceinline__ void lane_rounds(LaneLds<Cap> *LL, const uint16_t *list, uint32_t n_list, int lane,
                                             const BpeSlot *__restrict__ slots, uint32_t sh, const uint32_t *__restrict__ merged_of_rank) {
@@ -1008,7 +1076,7 @@ __device__ __forceinline__ void lane_rounds(LaneLds<Cap> *LL, const uint16_t *li
       if (next >= n_list) break;
       continue;
     }
-    if (next >= n_list && __popcll(BUSY) <= 64 / kTailLanes) break;  // the last few (long) words: several lanes each, below
+    if (next >= n_list && __popcll(BUSY) <= 16) break;  // the last few (long) words: several lanes each, below
     if (n != 0u) {
       // slot im merges with the next live slot r; pl / rr = the live slots either side of the pair
       const uint32_t im = key & 31u;
@@ -1035,70 +1103,10 @@ __device__ __forceinline__ void lane_rounds(LaneLds<Cap> *LL, const uint16_t *li
       }
     }
   }
-  // ---- the tail.  Two thirds of a tile's rounds run with a handful of words left -- the longest ones, which started first -- and
-  // a round costs the wave the same whether 60 lanes take part or 5 (S85k-open, simulated from the oracle: 13.8 rounds per tile,
-  // 8.8 of them with <= 16 words, 6.9 with <= 8).  So the last 64 / kTailLanes words get kTailLanes lanes each: lane j of a word
-  // scans its share of the slots (two steps instead of up to eight), a shuffle finds the word's minimum, every lane of the group
-  // follows the merge (same values, LDS broadcasts), lane 0 writes it and looks the left pair up while lane 1 looks up the right.
+  // ---- the tail (lane_tail above): four lanes a word once 16 words are left
   {
     const unsigned long long BUSY = __ballot(n != 0u);
-    if (BUSY == 0ull) return;
-    // group g of kTailLanes lanes takes over the g-th busy lane
-    const uint32_t g = (uint32_t)lane / kTailLanes, j = (uint32_t)lane % kTailLanes;
-    unsigned long long mrest = BUSY;
-    for (uint32_t i = 0; i < g; i++) mrest &= mrest - 1ull;
-    const bool have = mrest != 0ull;
-    const int src = have ? __builtin_ctzll(mrest) : 0;
-    const uint32_t sidx = (uint32_t)(S - LL[0].sym), vidx = (uint32_t)(V - LL[0].val);
-    const uint32_t t_s = __shfl(sidx, src), t_v = __shfl(vidx, src), t_n = __shfl(n, src), t_alive = __shfl(alive, src);
-    S = LL[0].sym + t_s;
-    V = LL[0].val + t_v;
-    n = have ? t_n : 0u;
-    alive = t_alive;
-    for (;;) {
-      if (__ballot(n != 0u) == 0ull) break;
-      if (n != 0u) {
-        const uint32_t nm1 = n - 1u;
-        uint32_t k = 0xFFFFFFFFu;
-#pragma unroll
-        for (uint32_t q0 = 0; q0 < 32u / kTailLanes; q0 += 4) {  // this lane's share of the (at most 32) slots
-          const uint32_t i0 = (32u / kTailLanes) * j + q0;
-          if (i0 < nm1) {
-            const uint32_t i1 = min(i0 + 1u, nm1), i2 = min(i0 + 2u, nm1), i3 = min(i0 + 3u, nm1);
-            k = min(k, min(min(rank_key<Packed>(V[i0], i0), rank_key<Packed>(V[i1], i1)), min(rank_key<Packed>(V[i2], i2), rank_key<Packed>(V[i3], i3))));
-          }
-        }
-#pragma unroll
-        for (uint32_t d = 1; d < kTailLanes; d <<= 1) k = min(k, (uint32_t)__shfl_xor(k, (int)d));
-        const uint32_t im = k & 31u;
-        const uint32_t hi = alive & (0xFFFFFFFEu << im);
-        if (k >= kNoKey || hi == 0u) {
-          n = 0u;  // the same decision in all eight lanes
-        } else {
-          const uint32_t m = V[im];
-          const uint32_t r = (uint32_t)__builtin_ctz(hi);
-          const uint32_t hi2 = hi & (hi - 1u);
-          const uint32_t lo = alive & ((1u << im) - 1u);
-          const bool has_rr = hi2 != 0u, has_pl = lo != 0u;
-          const uint32_t rr = has_rr ? (uint32_t)__builtin_ctz(hi2) : 0u, pl = has_pl ? 31u - (uint32_t)__builtin_clz(lo) : 0u;
-          alive &= ~(1u << r);
-          const uint32_t mg = Packed ? (SWT_SYM_BASE + (m & 0xFFFFu)) : merged_of_rank[m];
-          const uint32_t sl = S[pl] & ~SWT_BPE_CONT, sr = S[rr] & ~SWT_BPE_CONT;
-          wave_sync();  // every lane has read the old symbols before lane 0 changes them
-          const bool left = j == 0u && has_pl, right = j == 1u && has_rr;
-          uint32_t v = kNoRank;
-          if (left || right) v = slot_value(slots, sh, left ? sl : mg, left ? mg : sr);
-          if (j == 0u) {
-            S[im] = im ? (mg | SWT_BPE_CONT) : mg;
-            S[r] = kInvalidTok;
-            V[r] = kNoRank;
-            if (has_pl) V[pl] = v;
-          }
-          if (j == 1u) V[im] = v;  // kNoRank when nothing follows
-        }
-      }
-      wave_sync();
-    }
+    if (BUSY != 0ull) lane_tail<Packed, 4>(LL[0].sym, LL[0].val, S, V, n, alive, BUSY, 0u, lane, slots, sh, merged_of_rank);
   }
 }
 

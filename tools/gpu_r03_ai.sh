@@ -1,8 +1,8 @@
 #!/bin/bash
-# bpe_lane_kernel tail: lanes per word (rebuilds on the box)
+# bpe_lane_kernel tail: four lanes a word, then eight (SWT_TAIL_WIDE) -- rebuilds on the box
 set -o pipefail
 export TMPDIR=/tmp
-for v in "-DSWT_TAIL_LANES=2" "-DSWT_TAIL_LANES=4"; do
+for v in "-DSWT_TAIL_WIDE=1" "-DSWT_TAIL_WIDE=0"; do
   export SWT_EXTRA_FLAGS="$v"
   python -c "import importlib; importlib.import_module('subword-tokenizers_amd._build').build()" || exit 1
   timeout -k 10 200 python -m pytest tests -m gpu -q -x -k "word_lane or twin or bpe_edge or bpe_fuzz" 2>&1 | tail -1
