@@ -7,17 +7,20 @@
 //   the rank dict                    /root/reference/source/bpe.py:200,257
 //
 // One 64-lane wavefront per tile (workgroup = one wave, so every barrier is a wave-local fence):
-//   tile   = the sentences whose first byte lies in one kBpeTile-byte window of the text (whole sentences, no
-//            data-path atomics between workgroups, a tile's tokens are contiguous in the output)
-//   chunk  = up to kBpeCap bytes of the tile's span staged in LDS; longer spans are cut at word boundaries
-//   lane   = one BYTE POSITION in every phase -- including the merge loop:
+//   tile   = the sentences whose first byte lies in one window of the text (whole sentences, no data-path atomics between
+//            workgroups, a tile's tokens are contiguous in the output)
+//   chunk  = the part of the tile's span staged in LDS at a time; longer spans are cut at word boundaries
+// Two kernels share that skeleton and the two-choice rank table (slot_value):
+//   bpe_lane_kernel   (the default, round 3; described where it stands, below): the split stays byte-parallel and looks every
+//                     adjacent pair up on the way, then ONE LANE OWNS ONE WORD through the merge rounds (live-slot mask, a lane takes
+//                     the next word when its own is finished, four lanes a word once few words are left)
+//   bpe_encode_kernel (rounds 1-2, SWT_BPE_KERNEL=bytes: the comparison form): one lane per BYTE POSITION in every phase --
 //     B/C  64 bytes per step: decode the code point at each UTF-8 lead byte, class from an LDS copy of the table,
 //          then everything structural (word starts, next symbol of the word, head of the word) comes from 64-bit
-//          ballot masks and scalar bit arithmetic; the table value of every adjacent pair is probed here, all
-//          lanes at once (this is the whole first merge round of bpe.py:211-219)
-//     D    merge rounds over the list of symbols that still belong to an unfinished word: per-word minimum by
-//          LDS atomicMin, the winners merge in place (symbols are linked by a next-pointer, nothing is shifted),
-//          and only symbols next to a merge probe the table again -- one L2 round trip per round for the wave
+//          ballot masks and scalar bit arithmetic
+//     C2/D the table value of every adjacent pair, then merge rounds over the list of symbols that still belong to an
+//          unfinished word: per-word minimum by LDS atomicMin, the winners merge in place (symbols are linked by a
+//          next-pointer, nothing is shifted), and only symbols next to a merge look the table up again
 //     E/F  order-preserving ballot compaction to the tile's output run, per-sentence offsets
 // A word longer than a chunk falls to a one-lane global-memory path (correct, slow, pathological inputs only).
 #include <cstdlib>
