@@ -573,6 +573,10 @@ __global__ __launch_bounds__(64) void ureg_kernel(const uint8_t *__restrict__ te
                                                       uint64_t *__restrict__ plan2, uint64_t n_tiles2, uint32_t tile2_min) {
   const int lane = threadIdx.x;
   const uint64_t t = blockIdx.x;
+  // most tiles of running text table nothing new: they leave before anything else is loaded or divided (a tile without
+  // sentences has no new words either; workgroup 0 also writes the ends of the plan)
+  const uint32_t n_new = (uint32_t)(D.tile_new[t] >> 32);
+  if (!n_new && t != 0) return;
   const uint64_t s_lo = plan[t], s_hi = plan[t + 1];
   // The plan of the launch that encodes the unique words (plan2[tt] = first unique word that starts at or after byte
   // tt * tile2) is written here too: that launch has a fixed n_tiles2 workgroups, so the tile size follows from the
@@ -587,9 +591,7 @@ __global__ __launch_bounds__(64) void ureg_kernel(const uint8_t *__restrict__ te
       for (uint64_t tt = lane; tt <= n_tiles2; tt += 64)
         if (tt == 0 || tt * tile2 > ubytes) plan2[tt] = tt == 0 ? 0ull : n_uniq;
   }
-  if (s_lo == s_hi) return;
-  const uint32_t n_new = (uint32_t)(D.tile_new[t] >> 32);
-  if (!n_new) return;
+  if (s_lo == s_hi || !n_new) return;
   const unsigned long long base = new_blk_base[t >> 10] + new_local[t];
   const uint64_t u0 = base >> 32;
   uint64_t b0 = base & 0xFFFFFFFFull;
