@@ -17,7 +17,7 @@ budget = float(os.environ.get("SWT_SOAK_SECONDS", "150"))
 rng = np.random.default_rng(seed)
 print("soak seed", seed, flush=True)
 t_end = time.time() + budget
-stats = {"train": 0, "train_merges": 0, "bpe": 0, "bpe_tokens": 0, "wp": 0, "wp_tokens": 0, "shard": 0, "shard_merges": 0, "wptrain": 0, "wptrain_merges": 0}
+stats = {"train": 0, "train_merges": 0, "bpe": 0, "bpe_tokens": 0, "bpe_proper": 0, "bpe_proper_tokens": 0, "wp": 0, "wp_tokens": 0, "shard": 0, "shard_merges": 0, "wptrain": 0, "wptrain_merges": 0}
 
 
 def fail(what, **kw):
@@ -172,9 +172,62 @@ def wptrain_trial():
     stats["wptrain"] += 1; stats["wptrain_merges"] += len(want)
 
 
+def bpe_proper_trial():
+    """PROPER tables (every pair ranks above the merges that make its symbols: every merged string is made once) take the
+    word-lane kernel's fast path -- live-slot mask, lane refill, four lanes a word in the tail; texts with long words, many
+    short words per chunk, multi-byte symbols, spans over several chunks; direct and dedup paths, and single sentences."""
+    import ctypes as C
+    alpha = ALPHAS[int(rng.integers(len(ALPHAS)))]
+    base = list(alpha.replace("-", ""))
+    symbols, have, merges = list(base), set(base), []
+    for _ in range(int(rng.integers(3, 120))):
+        # prefer recent symbols so that chains of merges (long rounds) exist
+        pool = symbols[-12:] if rng.random() < 0.6 else symbols
+        l, r = pool[int(rng.integers(len(pool)))], symbols[int(rng.integers(len(symbols)))]
+        if len(l + r) > 28 or (l + r) in have or (l, r) in merges: continue
+        merges.append((l, r)); symbols.append(l + r); have.add(l + r)
+    if not merges: return
+    tok = S.FastBPE(); tok.merges_list = list(merges); tok._build_table()
+    lib = N.lib()
+    lib.swt_debug_bpe_table_info.restype = C.c_int
+    lib.swt_debug_bpe_table_info.argtypes = [C.c_void_p, C.c_int]
+    if lib.swt_debug_bpe_table_info(tok._table._h, 2) != 1: fail("bpe proper: the table was not recognised as proper", merges=merges[:40])
+    orc = O.OracleBPE(merges)
+    n_sent = int(rng.integers(1, 400))
+    shape = int(rng.integers(4))
+    texts = []
+    for _ in range(n_sent):
+        if shape == 0:    # many short words
+            words = ["".join(base[int(c)] for c in rng.integers(0, len(base), size=int(rng.integers(1, 5)))) for _ in range(int(rng.integers(0, 120)))]
+        elif shape == 1:  # words around the 32-slot mask and beyond
+            words = ["".join(base[int(c)] for c in rng.integers(0, len(base), size=int(rng.integers(20, 70)))) for _ in range(int(rng.integers(0, 12)))]
+        elif shape == 2:  # built from the table's own symbols: long chains of merges
+            words = ["".join(symbols[int(c)] for c in rng.integers(0, len(symbols), size=int(rng.integers(1, 6)))) for _ in range(int(rng.integers(0, 40)))]
+        else:
+            words = ["".join(base[int(c)] for c in rng.integers(0, len(base), size=int(rng.integers(1, 40)))) for _ in range(int(rng.integers(0, 30)))]
+        sep = "." if rng.random() < 0.2 else " "
+        texts.append((" " if rng.random() < 0.1 else "") + sep.join(words) + ("!" if rng.random() < 0.3 else ""))
+    oids, ooff = orc.tokenize_batch_ids(texts)
+    for mode in (N.DEDUP_NEVER, N.DEDUP_ALWAYS):
+        tok._table.set_option(N.OPT_DEDUP, mode)
+        ids, off = tok.encode_ids_batch(texts)
+        if not (np.array_equal(off, ooff) and np.array_equal(ids, oids)):
+            bad = next((i for i in range(len(texts)) if off[i + 1] != ooff[i + 1] or not np.array_equal(ids[int(off[i]):int(off[i + 1])], oids[int(ooff[i]):int(ooff[i + 1])])), -1)
+            fail("bpe proper batch", alpha=alpha, merges=merges[:60], mode=mode, n=len(texts), shape=shape, first_bad=bad, text=texts[bad][:200] if bad >= 0 else None)
+    tok._table.set_option(N.OPT_DEDUP, 0)
+    for t in texts[:6]:
+        ids, off = tok.encode_ids_batch([t]); o1, oo1 = orc.tokenize_batch_ids([t])
+        if not (np.array_equal(off, oo1) and np.array_equal(ids, o1)): fail("bpe proper single", alpha=alpha, merges=merges[:60], text=t[:200])
+    stats["bpe_proper"] += 1; stats["bpe_proper_tokens"] += int(oids.size)
+    tok._table.close()
+
+
+only = os.environ.get("SWT_SOAK_ONLY")
+trials = (train_trial, bpe_trial, wp_trial, shard_trial, wptrain_trial, bpe_proper_trial)
+if only: trials = tuple(f for f in trials if f.__name__ in only.split(","))
 k = 0
 while time.time() < t_end:
-    (train_trial, bpe_trial, wp_trial, shard_trial, wptrain_trial)[k % 5]()
+    trials[k % len(trials)]()
     k += 1
     if k % 30 == 0: print(k, stats, flush=True)
 print("soak ok: seed", seed, stats, flush=True)
