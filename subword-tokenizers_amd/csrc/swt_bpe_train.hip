@@ -2215,13 +2215,24 @@ __global__ __launch_bounds__(kTrainThreads) void wp_step_kernel(const uint32_t *
       wp_tie_by_index(sym, woff, n_words, C, a.mx, n, n_synced);
     }
   }
-  // ---- the last workgroup to get here decides
+  // ---- the last workgroup to get here decides.  Everything the workgroups tell each other in this launch travels in device-scope
+  // atomics (best_pos, the ticket), so all the ticket needs is that this workgroup's atomics have been performed: a workgroup-scope
+  // fence (a wait for the outstanding memory operations) and the barrier.  __threadfence() -- a device-scope fence -- writes the
+  // XCD's L2 back and invalidates it, once per workgroup and step (SWT_WP_THREADFENCE=1 in the environment of the build: the old form).
+#ifdef SWT_WP_THREADFENCE
   __threadfence();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#endif
   __syncthreads();
   if (threadIdx.x == 0) s_last = atomicAdd(&st->ticket, 1ull) == (unsigned long long)gridDim.x - 1ull ? 1u : 0u;
   __syncthreads();
   if (!s_last || threadIdx.x != 0) return;
+#ifdef SWT_WP_THREADFENCE
   __threadfence();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#endif
   st->ticket = 0;
   unsigned long long key = a.key, pos = kEmptyKey;
   if (!dry && a.mx && a.tied >= 2) {

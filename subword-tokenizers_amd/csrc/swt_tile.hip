@@ -42,13 +42,14 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const T *__restrict__ t
   for (int w = 0; w < wave; w++) wb += wsum[w];
   if (i < n_tiles) tile_base[i] = (T)(wb + x - v);
   if (tid == 1023) {
-    blk_tot[blockIdx.x] = wb + x;
-    __threadfence();  // agent-scope release of blk_tot before the ticket
+    // the total travels in a device-scope store and is read back by device-scope loads below, so the ticket only has to wait until
+    // the store has been performed -- no device-scope FENCE (which writes the XCD's L2 back and invalidates it, once per workgroup)
+    __hip_atomic_store(&blk_tot[blockIdx.x], wb + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
   }
   __syncthreads();
   if (!is_last) return;
-  __threadfence();  // agent-scope acquire: every other workgroup's total is visible
   if (tid == 0) carry_s = 0;
   __syncthreads();
   for (uint32_t base = 0; base < gridDim.x; base += 1024) {
