@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: this script measured a form that did not stay in the tree (see profiles/r03_experiments/); its build flag / environment knob exists only in the commit it ran against.
 # dedup word table with the word's first 14 bytes in the slot (SWT_DD_NO_PREFIX=1: every compare goes to the text, as before)
 set -o pipefail
 export TMPDIR=/tmp

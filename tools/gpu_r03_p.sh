@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: this script measured a form that did not stay in the tree (see profiles/r03_experiments/); its build flag / environment knob exists only in the commit it ran against.
 # bpe_lane_kernel: where the time goes, by leaving phases out (-DSWT_LANE_ABL=n builds on the box; their results are wrong)
 #   1 no merge rounds (D)   2 + no word list (W)   3 + no pair probes in the split   4 + no split at all (staging, E/F skeleton only)
 set -o pipefail

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: this script measured a form that did not stay in the tree (see profiles/r03_experiments/); its build flag / environment knob exists only in the commit it ran against.
 # bpe_lane_kernel (refill form): SQ counters, then the phase ablation
 set -o pipefail
 export TMPDIR=/tmp

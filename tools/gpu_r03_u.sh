@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: this script measured a form that did not stay in the tree (see profiles/r03_experiments/); its build flag / environment knob exists only in the commit it ran against.
 # two-launch form (self-planning tiles + gather_blocks): diagnosis, BPE parity tests, bench against the four-launch form
 set -o pipefail
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: this script measured a form that did not stay in the tree (see profiles/r03_experiments/); its build flag / environment knob exists only in the commit it ran against.
 # bpe_lane_group_kernel: tiles per workgroup (rebuilds on the box)
 set -o pipefail
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: this script measured a form that did not stay in the tree (see profiles/r03_experiments/); its build flag / environment knob exists only in the commit it ran against.
 # dedup front end in two launches (SWT_DD_WARM = the share of tiles in the first one; 0 = one launch)
 set -o pipefail
 export TMPDIR=/tmp
